@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE binary.
+
+Run in the dev container only (needs oracle/_ref/shafa, built by `make -C oracle` from the
+sources under /root/reference).  The fixtures are DATA: deterministic inputs plus the files the
+reference wrote for them (.rle / .freq / .cod / .shaf, decoded round trips) and, for large
+outputs, SHA-256 + size only.  No reference source text is stored.
+
+    python tests/golden/make_golden.py
+
+Every case directory gets a manifest.json:
+    {"cmds": [[argv...], ...], "files": {name: {"size": n, "sha256": h, "stored": bool}}, ...}
+"""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.path.join(ROOT, "oracle", "_ref", "shafa")
+STORE_LIMIT = 400 * 1024  # files above this are recorded by hash only
+
+
+# ---------------------------------------------------------------- deterministic inputs
+def splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)).astype(np.uint64)
+    x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)).astype(np.uint64)
+    return x ^ (x >> np.uint64(31))
+
+
+def gen_bytes(seed, n, table=None, first=0):
+    """Same stream as oracle/shafa_oracle.c orc_gen_bytes and the HIP generator."""
+    with np.errstate(over="ignore"):
+        i = np.arange(first, first + n, dtype=np.uint64)
+        w = splitmix64(np.uint64(seed) + (i >> np.uint64(2)))
+        r16 = ((w >> (np.uint64(16) * (i & np.uint64(3)))) & np.uint64(0xFFFF)).astype(np.int64)
+    if table is None:
+        return (r16 >> 8).astype(np.uint8)
+    return table[r16]
+
+
+def zipf_table(s=1.2, nsym=256):
+    """2^16-entry inverse CDF: table[r] = smallest k with cdf(k) * 65536 > r."""
+    w = np.arange(1, nsym + 1, dtype=np.float64) ** (-s)
+    cdf = np.cumsum(w) / np.sum(w)
+    edges = np.minimum(np.floor(cdf * 65536.0 + 0.5).astype(np.int64), 65536)
+    edges[-1] = 65536
+    table = np.zeros(65536, dtype=np.uint8)
+    lo = 0
+    for k in range(nsym):
+        table[lo:edges[k]] = k
+        lo = max(lo, edges[k])
+    return table
+
+
+def runs_stream(seed, n, table, p=0.35):
+    """Zipf symbol repeated for a geometric run length (gives RLE something to do)."""
+    syms = gen_bytes(seed, n, table)
+    u = gen_bytes(seed ^ 0x5DEECE66D, n).astype(np.float64) / 256.0 + 1.0 / 512.0
+    runlen = (np.floor(np.log(u) / np.log(1.0 - p)) + 1).astype(np.int64)
+    out = np.repeat(syms, runlen)[:n]
+    assert out.size == n
+    return out.astype(np.uint8)
+
+
+def edge_stream():
+    """Crafted run lengths around every threshold of f.c:38-52, incl. a run over a block edge."""
+    parts = []
+    rng_fill = gen_bytes(77, 70000)
+    rng_fill = np.where(rng_fill < 2, 7, rng_fill).astype(np.uint8)  # filler without zeros/ones
+    k = 0
+    for sym in (0x41, 0x00, 0xFF):
+        for L in list(range(1, 6)) + list(range(254, 261)) + list(range(509, 516)) + [765, 769]:
+            parts.append(np.full(L, sym, dtype=np.uint8))
+            parts.append(np.array([rng_fill[k] | 2, (rng_fill[k + 1] | 2) ^ 1], dtype=np.uint8))
+            k += 2
+    body = np.concatenate(parts)
+    # a 300-byte run straddling the 65536 boundary
+    pad = 65536 - 150 - body.size
+    assert pad > 0
+    filler = (gen_bytes(78, pad) | 1).astype(np.uint8)
+    filler[-1] = 0x11
+    stream = np.concatenate([body, filler, np.full(300, 0x42, dtype=np.uint8)])
+    tail = (gen_bytes(79, 70000 - stream.size) | 1).astype(np.uint8)
+    tail[0] = 0x13
+    out = np.concatenate([stream, tail])
+    assert out.size == 70000
+    return out
+
+
+def textlike_stream(seed, n):
+    """Geometric-ish symbol distribution: a few hot symbols and a long tail of rare ones,
+    so that Shannon-Fano code lengths spread from 1-2 bits to 16+ bits."""
+    w = 0.62 ** np.arange(256, dtype=np.float64)
+    cdf = np.cumsum(w) / np.sum(w)
+    edges = np.minimum(np.floor(cdf * 65536.0 + 0.5).astype(np.int64), 65536)
+    edges[-1] = 65536
+    table = np.zeros(65536, dtype=np.uint8)
+    lo = 0
+    perm = (np.arange(256) * 37 + 11) % 256  # scatter symbol ids
+    for k in range(256):
+        table[lo:edges[k]] = perm[k]
+        lo = max(lo, edges[k])
+    out = gen_bytes(seed, n, table)
+    # make sure every symbol appears at least once in block 0 (rare => long codes)
+    out[1000:1256] = np.arange(256, dtype=np.uint8)
+    return out
+
+
+# ---------------------------------------------------------------- running the reference
+def sha(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def run_case(name, files_in, cmds, note="", store_inputs=True, expect_rc=None):
+    """files_in: {fname: bytes}; cmds: list of argv lists (without the binary), run in order in a
+    scratch dir; files whose name starts with 'decoded__' are produced by copying after -m d."""
+    out_dir = os.path.join(HERE, name)
+    shutil.rmtree(out_dir, ignore_errors=True)
+    os.makedirs(out_dir)
+    man = {"note": note, "cmds": [], "files": {}, "inputs": sorted(files_in)}
+    with tempfile.TemporaryDirectory() as tmp:
+        for fn, data in files_in.items():
+            with open(os.path.join(tmp, fn), "wb") as f:
+                f.write(data)
+        for step in cmds:
+            if step[0] == "__copy__":   # ["__copy__", src, dst]
+                shutil.copyfile(os.path.join(tmp, step[1]), os.path.join(tmp, step[2]))
+                man["cmds"].append(step)
+                continue
+            if step[0] == "__rm__":
+                os.remove(os.path.join(tmp, step[1]))
+                man["cmds"].append(step)
+                continue
+            r = subprocess.run([REF] + step, cwd=tmp, capture_output=True, timeout=300)
+            man["cmds"].append({"argv": step, "rc": r.returncode,
+                                "stderr": r.stderr.decode("utf-8", "replace")})
+        for fn in sorted(os.listdir(tmp)):
+            p = os.path.join(tmp, fn)
+            size = os.path.getsize(p)
+            is_input = fn in files_in
+            stored = size <= STORE_LIMIT and (store_inputs or not is_input)
+            if fn.startswith(("decoded__", "orig__", "keep__")):
+                stored = False          # copies of other files: the hash is enough
+            man["files"][fn] = {"size": size, "sha256": sha(p), "stored": stored}
+            if stored:
+                shutil.copyfile(p, os.path.join(out_dir, fn))
+    with open(os.path.join(out_dir, "manifest.json"), "w") as f:
+        json.dump(man, f, indent=1, sort_keys=True)
+    total = sum(v["size"] for v in man["files"].values() if v["stored"])
+    print(f"{name}: {len(man['files'])} files, {total} bytes stored")
+
+
+def main():
+    if not os.path.exists(REF):
+        sys.exit("oracle/_ref/shafa missing: run `make -C oracle` in the dev container first")
+    zt = zipf_table(1.2)
+
+    # 1. Zipf-with-runs, default 64 KiB blocks, 4 blocks incl. a partial one; full F->T->C then
+    #    all three decode modes.
+    d = runs_stream(1234, 212345, zt).tobytes()
+    run_case("runs_default", {"x": d}, [
+        ["x"],                                   # f+t+c  -> x.rle x.rle.freq x.rle.cod x.rle.shaf
+        ["__copy__", "x", "orig__x"], ["__rm__", "x"],
+        ["x.rle.shaf"],                          # d: SF + RLE -> x
+        ["__copy__", "x", "decoded__sf_rle"], ["__rm__", "x"],
+        ["__copy__", "x.rle", "keep__x.rle"],
+        ["x.rle.shaf", "-m", "d", "-d", "s"],    # SF only -> x.rle
+        ["__copy__", "x.rle", "decoded__sf_only"],
+        ["x.rle", "-m", "d"],                    # RLE only (needs x.rle.freq) -> x
+        ["__copy__", "x", "decoded__rle_only"],
+    ], note="212345 B Zipf(1.2) symbols with geometric runs; default -b (64 KiB)")
+
+    # 2. crafted run-length edges, RLE forced
+    run_case("edges_forced_rle", {"e": edge_stream().tobytes()}, [
+        ["e", "-m", "f", "-c", "r"], ["e.rle.freq", "-m", "t"], ["e.rle", "-m", "c"],
+        ["__copy__", "e", "orig__e"], ["__rm__", "e"],
+        ["e.rle.shaf"], ["__copy__", "e", "decoded__sf_rle"],
+    ], note="runs of 1-5, 254-260, 509-515, 765, 769 of 0x41/0x00/0xFF; 300-run over the 64 KiB edge")
+
+    # 3. uniform: RLE rejected by block 0 -> @N@ path
+    run_case("uniform_no_rle", {"u": gen_bytes(42, 150000).tobytes()}, [
+        ["u"], ["__copy__", "u", "orig__u"], ["__rm__", "u"],
+        ["u.shaf"], ["__copy__", "u", "decoded__sf"],
+    ], note="150000 uniform bytes; RLE rejected (<5 %), .freq/.cod/.shaf of the raw blocks")
+
+    # 4. uniform with RLE forced (RLE expands) and -c f (both .freq files)
+    run_case("uniform_forced_both", {"v": gen_bytes(43, 100000).tobytes()}, [
+        ["v", "-m", "f", "-c", "r"],
+        ["__copy__", "v.rle", "keep__v.rle"], ["__copy__", "v.rle.freq", "keep__v.rle.freq"],
+    ], note="forced RLE on incompressible data")
+    run_case("runs_force_freq", {"w": runs_stream(99, 90000, zt).tobytes()}, [
+        ["w", "-m", "f", "-c", "f"],
+    ], note="-c f: x.freq (@N@) next to x.rle/x.rle.freq (@R@)")
+
+    # 5. config[0]: one 640 KiB block, -b K, Module F; runs variant (accepted) and uniform (rejected)
+    run_case("cfg0_K_runs", {"k": runs_stream(7, 655360, zt).tobytes()}, [
+        ["k", "-m", "f", "-b", "K"],
+    ], note="BASELINE config[0]: single 640 KiB block, -b K, Module F; input = runs_stream(7, 655360)",
+        store_inputs=False)
+    run_case("cfg0_K_uniform", {"k": gen_bytes(8, 655360).tobytes()}, [
+        ["k", "-m", "f", "-b", "K"],
+    ], note="BASELINE config[0] uniform variant; input = gen_bytes(8, 655360)", store_inputs=False)
+
+    # 6. text-like: code lengths from 1 to 16+ bits, 8 MiB-class block size flag but small file
+    run_case("textlike_m", {"t": textlike_stream(5, 300000).tobytes()}, [
+        ["t", "-b", "m"], ["__copy__", "t", "orig__t"], ["__rm__", "t"],
+        ["t.shaf"], ["__copy__", "t", "decoded__sf"],
+    ], note="geometric symbol distribution; long Shannon-Fano codes; one block at -b m")
+
+    # 7. size limits (f.c:220,366): 1024 B is accepted, 1023 B is _FILE_TOO_SMALL
+    run_case("tiny_1024", {"a": runs_stream(3, 1024, zt).tobytes()}, [["a"]])
+    run_case("tiny_1023", {"a": runs_stream(3, 1023, zt).tobytes()}, [["a"]])
+
+    # 8. Module T alone on hand-made .freq files: single symbol, ties, Fibonacci (deep codes)
+    def freq_text(blocks, mode="N"):
+        s = f"@{mode}@{len(blocks)}"
+        for size, fr in blocks:
+            s += f"@{size}@"
+            prev = None
+            for i, v in enumerate(fr):
+                if prev is None or v != prev:
+                    s += str(v)
+                prev = v
+                if i != 255:
+                    s += ";"
+        return (s + "@0").encode()
+
+    single = [0] * 256
+    single[65] = 5000
+    ties = [100] * 256
+    fib = [0] * 256
+    a, b = 1, 1
+    for i in range(40):
+        fib[(i * 7) % 256] = a
+        a, b = b, a + b
+    two = [0] * 256
+    two[3] = 10
+    two[200] = 10
+    geo = [max(1, int(60000 * 0.5 ** i)) for i in range(256)]
+    run_case("t_handmade", {"h.freq": freq_text([(5000, single), (25600, ties), (sum(fib), fib),
+                                                 (20, two), (sum(geo), geo)])}, [
+        ["h.freq", "-m", "t"],
+    ], note="Module T on hand-made histograms: single symbol (all codes empty), all ties, "
+            "Fibonacci (deep tree), two symbols, geometric with a long tail of ones")
+
+    # 9. CLI behaviour samples (exit codes + stderr text)
+    run_case("cli_errors", {"z": runs_stream(11, 5000, zt).tobytes()}, [
+        ["z", "-m", "f", "-m", "c"],          # c after f without t: error after F ran (shafa.c:193)
+        ["z", "-m", "x"],                     # bad option value
+        ["nonexistent"],                      # file can't be accessed
+        ["z", "-m", "d", "-d", "s"],          # wrong extension
+        ["z", "extra"],                       # two files
+    ], note="argv errors: return codes and stderr texts")
+
+
+if __name__ == "__main__":
+    main()
