@@ -1,0 +1,147 @@
+/*
+ * shafa_hip.h — C-ABI of libshafa_hip.so: the MI355X (gfx950) implementation of Shafa's per-block
+ * hot path (Modules F, C, D).  Plain C, plain pointers and sizes, no C++/torch types.
+ *
+ * The reference (Fytex/Shafa-CD) has no plugin/FFI interface; its seam is the per-block
+ * `process` callback handed to multithread_create (utils/multithread.h:45) and the direct calls
+ * in f.c.  Each entry point below replaces one of those static functions (cited per function,
+ * paths relative to /root/reference/src/modules/).  Return values are the reference's
+ * _modules_error numbers (utils/errors.h:5-16) plus SHAFA_DEVICE_ERROR.
+ *
+ * Two layers:
+ *   1. host-buffer, one block per call, synchronous  (shafa_hip_*)   — what the C host's
+ *      f/c/d drivers call in place of f.c:248,310,325, c.c:411, d.c:342,735.
+ *   2. device-resident, many blocks per launch, asynchronous on a caller stream (shafa_hipd_*)
+ *      — used by the streaming drivers, bench.py and the multi-GPU sharding; every pointer named
+ *      d_* is a DEVICE pointer, every h_* a HOST pointer.
+ *
+ * Threading: entry points may be called from one thread at a time per process (the reference's
+ * drivers call from the main thread only, multithread.c:55-60).  No entry point throws or exits.
+ */
+#ifndef SHAFA_HIP_H
+#define SHAFA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHAFA_HIP_ABI_VERSION 1
+
+/* utils/errors.h:5-16 (_modules_error), same numbers */
+enum shafa_error {
+    SHAFA_SUCCESS = 0,
+    SHAFA_OUTSIDE_MODULE = 1,
+    SHAFA_LACK_OF_MEMORY = 2,
+    SHAFA_FILE_INACCESSIBLE = 3,
+    SHAFA_FILE_UNRECOGNIZABLE = 4,
+    SHAFA_FILE_STREAM_FAILED = 5,
+    SHAFA_FILE_TOO_SMALL = 6,
+    SHAFA_THREAD_CREATION_FAILED = 7,
+    SHAFA_THREAD_TERMINATION_FAILED = 8,
+    SHAFA_DEVICE_ERROR = 9            /* HIP runtime failure / no GPU; see shafa_hip_last_error() */
+};
+
+/* One block's Shannon-Fano table, the binary form of one "c0;c1;...;c255" .cod block
+ * (t.c:353-361; parsed by c.c:115-177 and d.c:466-504): len[s] = code length in bits
+ * (0 = symbol absent, max 255), bits[s] = the code MSB-first, zero padded. */
+typedef struct shafa_code_table {
+    uint8_t len[256];
+    uint8_t bits[256][32];
+} shafa_code_table;
+
+/* RLE decode output limit of the reference: 64 MiB + 1 KiB (d.c:129-169). */
+#define SHAFA_RLE_DECODE_MAX ((size_t)67108864 + 1024)
+
+/* ------------------------------------------------------------------ lifecycle */
+int shafa_hip_abi_version(void);
+int shafa_hip_device_count(void);            /* 0 when no GPU is visible; never fails */
+int shafa_hip_init(int device);              /* select device, create the library's stream/workspace */
+void shafa_hip_shutdown(void);
+const char *shafa_hip_last_error(void);      /* text of the last SHAFA_DEVICE_ERROR */
+
+/* ------------------------------------------------------------------ layer 1: host buffers, one block */
+
+/* make_freq (f.c:63-79): 256-bin byte histogram, 64-bit bins. */
+int shafa_hip_hist256(const uint8_t *in, size_t n, uint64_t freq[256]);
+
+/* block_compression (f.c:29-55) [+ make_freq of the RLE bytes, f.c:310, when freq_out != NULL].
+ * out_cap must be >= 2n+3 (f.c:244) or the worst case is refused with SHAFA_LACK_OF_MEMORY. */
+int shafa_hip_rle_encode(const uint8_t *in, size_t n, uint8_t *out, size_t out_cap, size_t *out_n,
+                         uint64_t *freq_out /* [256] or NULL */);
+
+/* compress_to_buffer + binary_coding (c.c:52-237): concatenate the block's codes MSB-first,
+ * zero-pad the last byte; *out_n = ceil(bits/8).  A data symbol with an empty code in a table that
+ * holds non-empty codes is SHAFA_FILE_UNRECOGNIZABLE; an all-empty table gives 0 bytes (c.c:156). */
+int shafa_hip_sf_encode(const uint8_t *in, size_t n, const shafa_code_table *table,
+                        uint8_t *out, size_t out_cap, size_t *out_n);
+
+/* create_tree + shafa_block_decompressor (d.c:466-551): decode exactly n_symbols symbols.
+ * Malformed table / missing branch / exhausted input is SHAFA_FILE_UNRECOGNIZABLE. */
+int shafa_hip_sf_decode(const uint8_t *in, size_t in_n, const shafa_code_table *table,
+                        uint8_t *out, size_t n_symbols);
+
+/* rle_block_decompressor (d.c:116-197); more than SHAFA_RLE_DECODE_MAX bytes of output is
+ * SHAFA_FILE_UNRECOGNIZABLE (d.c:165-168), more than out_cap is SHAFA_LACK_OF_MEMORY. */
+int shafa_hip_rle_decode(const uint8_t *in, size_t in_n, uint8_t *out, size_t out_cap, size_t *out_n);
+
+/* ------------------------------------------------------------------ layer 2: device buffers, batches
+ *
+ * A batch is nblocks independent blocks.  Block b's input is the h_in_n[b] bytes at
+ * d_in + h_in_off[b]; its output region is the h_out_cap[b] bytes at d_out + h_out_off[b]
+ * (all four are host arrays of nblocks entries; every offset must be a multiple of 16).
+ * Calls enqueue work on `stream` (a hipStream_t passed as void*; NULL = the null stream) and
+ * return without synchronising; results in device memory are valid after the stream is synchronised.
+ * shafa_hipd_finish() synchronises the stream and returns the batch's first error, filling the
+ * optional host arrays.
+ */
+typedef struct shafa_hipd_batch shafa_hipd_batch;
+
+/* Allocate a reusable batch context (device workspace, pinned staging) for up to max_blocks blocks
+ * of up to max_block_bytes input bytes each (for RLE/SF decode: of the LARGER of input and output). */
+int shafa_hipd_batch_create(int max_blocks, size_t max_block_bytes, shafa_hipd_batch **out);
+void shafa_hipd_batch_destroy(shafa_hipd_batch *b);
+
+/* make_freq per block: d_freq[b*256 + s], 64-bit counts. */
+int shafa_hipd_hist256(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
+                       const uint64_t *h_in_off, const uint64_t *h_in_n, uint64_t *d_freq);
+
+/* block_compression per block; d_out_n[b] = RLE size; d_freq (may be NULL) = histogram of the RLE bytes. */
+int shafa_hipd_rle_encode(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
+                          const uint64_t *h_in_off, const uint64_t *h_in_n, uint8_t *d_out,
+                          const uint64_t *h_out_off, const uint64_t *h_out_cap,
+                          uint64_t *d_out_n, uint64_t *d_freq);
+
+/* binary_coding per block; d_out_n[b] = ceil(bits/8). */
+int shafa_hipd_sf_encode(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
+                         const uint64_t *h_in_off, const uint64_t *h_in_n,
+                         const shafa_code_table *h_tables, uint8_t *d_out, const uint64_t *h_out_off,
+                         const uint64_t *h_out_cap, uint64_t *d_out_n);
+
+/* shafa_block_decompressor per block: block b decodes h_n_symbols[b] symbols from the h_in_n[b]
+ * bytes at d_in + h_in_off[b] into d_out + h_out_off[b] (which must hold h_n_symbols[b] bytes). */
+int shafa_hipd_sf_decode(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
+                         const uint64_t *h_in_off, const uint64_t *h_in_n,
+                         const shafa_code_table *h_tables, const uint64_t *h_n_symbols,
+                         uint8_t *d_out, const uint64_t *h_out_off);
+
+/* rle_block_decompressor per block; d_out_n[b] = decoded size. */
+int shafa_hipd_rle_decode(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
+                          const uint64_t *h_in_off, const uint64_t *h_in_n, uint8_t *d_out,
+                          const uint64_t *h_out_off, const uint64_t *h_out_cap, uint64_t *d_out_n);
+
+/* Synchronise `stream`, return the first per-block error of the calls enqueued since the last
+ * finish (SHAFA_SUCCESS if none).  h_block_err (nblocks ints, may be NULL) receives every block's code. */
+int shafa_hipd_finish(shafa_hipd_batch *b, void *stream, int nblocks, int *h_block_err);
+
+/* Synthetic byte streams for bench/tests (no reference counterpart; same stream as the oracle's
+ * orc_gen_bytes): byte i = map[r16(seed, first_index + i)] or r16 >> 8 when d_map65536 == NULL. */
+int shafa_hipd_gen_bytes(void *stream, uint64_t seed, uint64_t first_index,
+                         const uint8_t *d_map65536, uint8_t *d_out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHAFA_HIP_H */

@@ -1,0 +1,331 @@
+// api.hip — the C-ABI of libshafa_hip.so (include/shafa_hip.h): lifecycle, batch contexts and the
+// host-buffer one-block wrappers that stand where the reference calls block_compression / make_freq
+// (f.c:248,310,325), compress_to_buffer (c.c:411) and the decompressors (d.c:342,735).
+#include "common.hpp"
+#include "internal.hpp"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+// ------------------------------------------------------------------------------------------------
+// error text
+// ------------------------------------------------------------------------------------------------
+static char g_last_error[512] = "";
+
+int shafa_set_hip_error(hipError_t e, const char *what)
+{
+    snprintf(g_last_error, sizeof(g_last_error), "%s: %s", what, hipGetErrorString(e));
+    return SHAFA_DEVICE_ERROR;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch context
+// ------------------------------------------------------------------------------------------------
+int batch_reserve(Batch *b, size_t bytes)
+{
+    if (bytes <= b->ws_bytes) return SHAFA_SUCCESS;
+    if (b->d_ws) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(b->d_ws));
+        b->d_ws = nullptr;
+        b->ws_bytes = 0;
+    }
+    const size_t want = bytes + bytes / 8 + 4096;
+    HIP_TRY(hipMalloc(&b->d_ws, want));
+    b->ws_bytes = want;
+    return SHAFA_SUCCESS;
+}
+
+void *batch_stage(Batch *b, hipStream_t st, size_t bytes)
+{
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (bytes > b->stage_bytes) {          // grow: wait for copies that still read the old arena
+        if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
+        if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+        if (b->h_stage) hipHostFree(b->h_stage);
+        b->h_stage = nullptr;
+        b->stage_bytes = 0;
+        const size_t want = 2 * bytes + (1 << 20);
+        if (hipHostMalloc((void **)&b->h_stage, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+        b->stage_bytes = want;
+        b->stage_used = 0;
+    }
+    if (b->stage_used + bytes > b->stage_bytes) {
+        if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+        b->stage_used = 0;
+    }
+    void *p = b->h_stage + b->stage_used;
+    b->stage_used += bytes;
+    return p;
+}
+
+extern "C" {
+
+int shafa_hip_abi_version(void) { return SHAFA_HIP_ABI_VERSION; }
+
+int shafa_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *shafa_hip_last_error(void) { return g_last_error; }
+
+int shafa_hipd_batch_create(int max_blocks, size_t max_block_bytes, shafa_hipd_batch **out)
+{
+    if (!out || max_blocks <= 0) return SHAFA_OUTSIDE_MODULE;
+    Batch *b = (Batch *)calloc(1, sizeof(Batch));
+    if (!b) return SHAFA_LACK_OF_MEMORY;
+    b->max_blocks = max_blocks;
+    b->max_block_bytes = max_block_bytes;
+    hipError_t e = hipMalloc((void **)&b->d_err, (size_t)max_blocks * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(b->d_err, 0, (size_t)max_blocks * sizeof(int));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_err, (size_t)max_blocks * sizeof(int), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        if (b->d_err) hipFree(b->d_err);
+        free(b);
+        return shafa_set_hip_error(e, "shafa_hipd_batch_create");
+    }
+    *out = (shafa_hipd_batch *)b;
+    return SHAFA_SUCCESS;
+}
+
+void shafa_hipd_batch_destroy(shafa_hipd_batch *hb)
+{
+    Batch *b = (Batch *)hb;
+    if (!b) return;
+    hipDeviceSynchronize();
+    if (b->d_ws) hipFree(b->d_ws);
+    if (b->h_stage) hipHostFree(b->h_stage);
+    if (b->d_err) hipFree(b->d_err);
+    if (b->h_err) hipHostFree(b->h_err);
+    free(b);
+}
+
+int shafa_hipd_hist256(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
+                       const uint64_t *h_in_off, const uint64_t *h_in_n, uint64_t *d_freq)
+{
+    return hist_launch((Batch *)b, (hipStream_t)stream, nblocks, d_in, h_in_off, h_in_n, d_freq);
+}
+
+int shafa_hipd_rle_encode(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
+                          const uint64_t *h_in_off, const uint64_t *h_in_n, uint8_t *d_out,
+                          const uint64_t *h_out_off, const uint64_t *h_out_cap,
+                          uint64_t *d_out_n, uint64_t *d_freq)
+{
+    return rleenc_launch((Batch *)b, (hipStream_t)stream, nblocks, d_in, h_in_off, h_in_n, d_out, h_out_off,
+                         h_out_cap, d_out_n, d_freq);
+}
+
+int shafa_hipd_sf_encode(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
+                         const uint64_t *h_in_off, const uint64_t *h_in_n,
+                         const shafa_code_table *h_tables, uint8_t *d_out, const uint64_t *h_out_off,
+                         const uint64_t *h_out_cap, uint64_t *d_out_n)
+{
+    return sfenc_launch((Batch *)b, (hipStream_t)stream, nblocks, d_in, h_in_off, h_in_n, h_tables, d_out,
+                        h_out_off, h_out_cap, d_out_n);
+}
+
+int shafa_hipd_sf_decode(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
+                         const uint64_t *h_in_off, const uint64_t *h_in_n,
+                         const shafa_code_table *h_tables, const uint64_t *h_n_symbols,
+                         uint8_t *d_out, const uint64_t *h_out_off)
+{
+    return sfdec_launch((Batch *)b, (hipStream_t)stream, nblocks, d_in, h_in_off, h_in_n, h_tables,
+                        h_n_symbols, d_out, h_out_off);
+}
+
+int shafa_hipd_rle_decode(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
+                          const uint64_t *h_in_off, const uint64_t *h_in_n, uint8_t *d_out,
+                          const uint64_t *h_out_off, const uint64_t *h_out_cap, uint64_t *d_out_n)
+{
+    return rledec_launch((Batch *)b, (hipStream_t)stream, nblocks, d_in, h_in_off, h_in_n, d_out, h_out_off,
+                         h_out_cap, d_out_n);
+}
+
+int shafa_hipd_finish(shafa_hipd_batch *hb, void *stream, int nblocks, int *h_block_err)
+{
+    Batch *b = (Batch *)hb;
+    hipStream_t st = (hipStream_t)stream;
+    if (nblocks > b->max_blocks) nblocks = b->max_blocks;
+    if (nblocks < 0) nblocks = 0;
+    if (nblocks) {
+        HIP_TRY(hipMemcpyAsync(b->h_err, b->d_err, (size_t)nblocks * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemsetAsync(b->d_err, 0, (size_t)nblocks * sizeof(int), st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    b->stage_used = 0;
+    int first = SHAFA_SUCCESS;
+    for (int i = 0; i < nblocks; ++i) {
+        if (h_block_err) h_block_err[i] = b->h_err[i];
+        if (!first && b->h_err[i]) first = b->h_err[i];
+    }
+    if (first == SHAFA_DEVICE_ERROR)
+        snprintf(g_last_error, sizeof(g_last_error), "kernel reported a lost predecessor tile (spin bound hit)");
+    return first;
+}
+
+int shafa_hipd_gen_bytes(void *stream, uint64_t seed, uint64_t first_index, const uint8_t *d_map65536,
+                         uint8_t *d_out, size_t n)
+{
+    return gen_launch((hipStream_t)stream, seed, first_index, d_map65536, d_out, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// layer 1: host buffers, one block per call, synchronous
+// ------------------------------------------------------------------------------------------------
+static struct {
+    bool ready;
+    int device;
+    hipStream_t stream;
+    Batch *batch;
+    u8 *d_a; size_t a_bytes;     // input staging on the device
+    u8 *d_b; size_t b_bytes;     // output staging on the device
+    u64 *d_small;                // 256 u64 histogram + 1 u64 size
+} g;
+
+static int ensure_dev(u8 **p, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap) return SHAFA_SUCCESS;
+    if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; *cap = 0; }
+    const size_t want = ((bytes + (bytes >> 3) + 4096) + 255) & ~(size_t)255;
+    HIP_TRY(hipMalloc((void **)p, want));
+    *cap = want;
+    return SHAFA_SUCCESS;
+}
+
+int shafa_hip_init(int device)
+{
+    if (g.ready && g.device == device) return SHAFA_SUCCESS;
+    if (g.ready) shafa_hip_shutdown();
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        snprintf(g_last_error, sizeof(g_last_error), "no HIP device visible");
+        return SHAFA_DEVICE_ERROR;
+    }
+    if (device < 0 || device >= n) return SHAFA_OUTSIDE_MODULE;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    shafa_hipd_batch *bh = nullptr;
+    int rc = shafa_hipd_batch_create(1, (size_t)1 << 27, &bh);
+    if (rc) return rc;
+    g.batch = (Batch *)bh;
+    HIP_TRY(hipMalloc((void **)&g.d_small, 257 * sizeof(u64)));
+    g.device = device;
+    g.ready = true;
+    return SHAFA_SUCCESS;
+}
+
+void shafa_hip_shutdown(void)
+{
+    if (!g.ready) return;
+    hipDeviceSynchronize();
+    shafa_hipd_batch_destroy((shafa_hipd_batch *)g.batch);
+    if (g.d_a) hipFree(g.d_a);
+    if (g.d_b) hipFree(g.d_b);
+    if (g.d_small) hipFree(g.d_small);
+    hipStreamDestroy(g.stream);
+    memset(&g, 0, sizeof(g));
+}
+
+static int lazy_init(void) { return g.ready ? SHAFA_SUCCESS : shafa_hip_init(0); }
+
+static int upload(const uint8_t *in, size_t n)
+{
+    int rc = ensure_dev(&g.d_a, &g.a_bytes, n + 64);
+    if (rc) return rc;
+    if (n) HIP_TRY(hipMemcpyAsync(g.d_a, in, n, hipMemcpyHostToDevice, g.stream));
+    return SHAFA_SUCCESS;
+}
+
+int shafa_hip_hist256(const uint8_t *in, size_t n, uint64_t freq[256])
+{
+    int rc = lazy_init();
+    if (rc) return rc;
+    if ((rc = upload(in, n))) return rc;
+    const u64 off[1] = {0}, len[1] = {n};
+    if ((rc = hist_launch(g.batch, g.stream, 1, g.d_a, off, len, g.d_small))) return rc;
+    HIP_TRY(hipMemcpyAsync(freq, g.d_small, 256 * sizeof(u64), hipMemcpyDeviceToHost, g.stream));
+    return shafa_hipd_finish((shafa_hipd_batch *)g.batch, g.stream, 1, nullptr);
+}
+
+int shafa_hip_rle_encode(const uint8_t *in, size_t n, uint8_t *out, size_t out_cap, size_t *out_n,
+                         uint64_t *freq_out)
+{
+    int rc = lazy_init();
+    if (rc) return rc;
+    if (out_cap < 2 * n + 3) return SHAFA_LACK_OF_MEMORY;      // f.c:244 worst case
+    if ((rc = upload(in, n))) return rc;
+    const size_t cap = (2 * n + 3 + 15) & ~(size_t)15;
+    if ((rc = ensure_dev(&g.d_b, &g.b_bytes, cap))) return rc;
+    const u64 ioff[1] = {0}, ilen[1] = {n}, ooff[1] = {0}, ocap[1] = {cap};
+    if ((rc = rleenc_launch(g.batch, g.stream, 1, g.d_a, ioff, ilen, g.d_b, ooff, ocap, g.d_small + 256,
+                            freq_out ? g.d_small : nullptr))) return rc;
+    u64 sz = 0;
+    HIP_TRY(hipMemcpyAsync(&sz, g.d_small + 256, sizeof(u64), hipMemcpyDeviceToHost, g.stream));
+    if (freq_out) HIP_TRY(hipMemcpyAsync(freq_out, g.d_small, 256 * sizeof(u64), hipMemcpyDeviceToHost, g.stream));
+    rc = shafa_hipd_finish((shafa_hipd_batch *)g.batch, g.stream, 1, nullptr);
+    if (rc) return rc;
+    if (sz > out_cap) return SHAFA_LACK_OF_MEMORY;
+    if (sz) HIP_TRY(hipMemcpy(out, g.d_b, sz, hipMemcpyDeviceToHost));
+    *out_n = (size_t)sz;
+    return SHAFA_SUCCESS;
+}
+
+int shafa_hip_sf_encode(const uint8_t *in, size_t n, const shafa_code_table *table,
+                        uint8_t *out, size_t out_cap, size_t *out_n)
+{
+    int rc = lazy_init();
+    if (rc) return rc;
+    if ((rc = upload(in, n))) return rc;
+    const size_t cap = (out_cap + 15) & ~(size_t)15;
+    if ((rc = ensure_dev(&g.d_b, &g.b_bytes, cap + 16))) return rc;
+    // the device region is the caller's capacity (rounded down to keep the bound exact)
+    const u64 ioff[1] = {0}, ilen[1] = {n}, ooff[1] = {0}, ocap[1] = {out_cap};
+    if ((rc = sfenc_launch(g.batch, g.stream, 1, g.d_a, ioff, ilen, table, g.d_b, ooff, ocap, g.d_small + 256))) return rc;
+    u64 sz = 0;
+    HIP_TRY(hipMemcpyAsync(&sz, g.d_small + 256, sizeof(u64), hipMemcpyDeviceToHost, g.stream));
+    rc = shafa_hipd_finish((shafa_hipd_batch *)g.batch, g.stream, 1, nullptr);
+    if (rc) return rc;
+    if (sz > out_cap) return SHAFA_LACK_OF_MEMORY;
+    if (sz) HIP_TRY(hipMemcpy(out, g.d_b, sz, hipMemcpyDeviceToHost));
+    *out_n = (size_t)sz;
+    return SHAFA_SUCCESS;
+}
+
+int shafa_hip_sf_decode(const uint8_t *in, size_t in_n, const shafa_code_table *table,
+                        uint8_t *out, size_t n_symbols)
+{
+    int rc = lazy_init();
+    if (rc) return rc;
+    if ((rc = upload(in, in_n))) return rc;
+    if ((rc = ensure_dev(&g.d_b, &g.b_bytes, n_symbols + 64))) return rc;
+    const u64 ioff[1] = {0}, ilen[1] = {in_n}, ooff[1] = {0}, ns[1] = {n_symbols};
+    if ((rc = sfdec_launch(g.batch, g.stream, 1, g.d_a, ioff, ilen, table, ns, g.d_b, ooff))) return rc;
+    rc = shafa_hipd_finish((shafa_hipd_batch *)g.batch, g.stream, 1, nullptr);
+    if (rc) return rc;
+    if (n_symbols) HIP_TRY(hipMemcpy(out, g.d_b, n_symbols, hipMemcpyDeviceToHost));
+    return SHAFA_SUCCESS;
+}
+
+int shafa_hip_rle_decode(const uint8_t *in, size_t in_n, uint8_t *out, size_t out_cap, size_t *out_n)
+{
+    int rc = lazy_init();
+    if (rc) return rc;
+    if ((rc = upload(in, in_n))) return rc;
+    size_t cap = out_cap < SHAFA_RLE_DECODE_MAX ? out_cap : SHAFA_RLE_DECODE_MAX;
+    if ((rc = ensure_dev(&g.d_b, &g.b_bytes, cap + 64))) return rc;
+    const u64 ioff[1] = {0}, ilen[1] = {in_n}, ooff[1] = {0}, ocap[1] = {cap};
+    if ((rc = rledec_launch(g.batch, g.stream, 1, g.d_a, ioff, ilen, g.d_b, ooff, ocap, g.d_small + 256))) return rc;
+    u64 sz = 0;
+    HIP_TRY(hipMemcpyAsync(&sz, g.d_small + 256, sizeof(u64), hipMemcpyDeviceToHost, g.stream));
+    rc = shafa_hipd_finish((shafa_hipd_batch *)g.batch, g.stream, 1, nullptr);
+    if (rc) return rc;
+    if (sz) HIP_TRY(hipMemcpy(out, g.d_b, sz, hipMemcpyDeviceToHost));
+    *out_n = (size_t)sz;
+    return SHAFA_SUCCESS;
+}
+
+}  // extern "C"

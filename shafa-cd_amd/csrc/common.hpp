@@ -1,0 +1,94 @@
+// common.hpp — shared device/host helpers for libshafa_hip (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/shafa_hip.h"
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// Tile descriptors for single-pass chained scans ("decoupled look-back").
+// One 64-bit word per tile: status in the top 2 bits, value in the low 62.  The word is written and
+// read with relaxed agent-scope atomics: the payload IS the flag, so no fence is needed and the
+// protocol does not depend on dispatch order or XCD placement (MI355X_MICROARCH §visibility, R2).
+// Every descriptor word is zeroed by a hipMemsetAsync node ahead of the launch.
+// ---------------------------------------------------------------------------------------------
+#define DESC_EMPTY 0ull
+#define DESC_AGG 1ull     // value = this tile's own aggregate
+#define DESC_PREFIX 2ull  // value = inclusive prefix up to and including this tile
+#define DESC_VALUE_MASK ((1ull << 62) - 1)
+
+__device__ __forceinline__ void desc_store(u64 *p, u64 status, u64 value)
+{
+    __hip_atomic_store(p, (status << 62) | (value & DESC_VALUE_MASK), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 desc_load(const u64 *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Spin bound for every inter-workgroup wait: a lost predecessor sets the block's error instead of
+// hanging the GPU.
+#define SPIN_LIMIT (1u << 22)
+
+// ---------------------------------------------------------------------------------------------
+// wave / workgroup primitives (wave = 64 lanes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan_add(T v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_reduce_add(T v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ u32 bswap32(u32 x) { return __builtin_bswap32(x); }
+
+// (hi:lo) >> sh, low 32 bits; sh in [0,31]
+__device__ __forceinline__ u32 funnel_r(u32 hi, u32 lo, u32 sh)
+{
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+
+// first error wins per block (codes are small positive ints; keep the first non-zero)
+__device__ __forceinline__ void set_error(int *err, int code)
+{
+    atomicCAS(err, 0, code);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+#define HIP_TRY(expr)                                                     \
+    do {                                                                  \
+        hipError_t _e = (expr);                                           \
+        if (_e != hipSuccess) return shafa_set_hip_error(_e, #expr);      \
+    } while (0)
+
+int shafa_set_hip_error(hipError_t e, const char *what);
+
+static inline u64 ceil_div_u64(u64 a, u64 b) { return (a + b - 1) / b; }

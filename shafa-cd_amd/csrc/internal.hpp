@@ -1,0 +1,56 @@
+// internal.hpp — structures shared between the C-ABI layer (api.hip) and the kernel launchers.
+#pragma once
+
+#include "common.hpp"
+
+#include <string.h>
+#include <vector>
+
+// Reusable per-batch context behind the opaque shafa_hipd_batch handle.
+struct Batch {
+    int max_blocks;
+    size_t max_block_bytes;
+    void *d_ws;            // device workspace (grow-only; grown outside timed regions by warm-up calls)
+    size_t ws_bytes;
+    u8 *h_stage;           // pinned host staging for parameter blocks / tables (bump allocated,
+    size_t stage_bytes;    //   reset by shafa_hipd_finish, which synchronises the stream)
+    size_t stage_used;
+    int *d_err;            // one error code per block (first error wins)
+    int *h_err;            // pinned mirror
+};
+
+// make sure the device workspace holds `bytes`
+int batch_reserve(Batch *b, size_t bytes);
+// bump-allocate `bytes` of pinned staging (synchronises `st` and rewinds when the arena is full)
+void *batch_stage(Batch *b, hipStream_t st, size_t bytes);
+
+// ---- per-op parameter records (device arrays) --------------------------------------------------
+struct EncBlk {
+    const u8 *in;
+    u8 *out;
+    u64 n;
+    u64 out_cap;
+    u64 *out_n;
+    int *err;
+    const void *lut;
+    u32 desc_base;
+    u32 n_tiles;
+    u32 ticket;
+    u32 pad;
+};
+
+// ---- launchers (one per reference function) ------------------------------------------------------
+int hist_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
+                const u64 *h_in_n, u64 *d_freq);
+int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
+                 const u64 *h_in_n, const shafa_code_table *h_tables, u8 *d_out, const u64 *h_out_off,
+                 const u64 *h_out_cap, u64 *d_out_n);
+int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
+                 const u64 *h_in_n, const shafa_code_table *h_tables, const u64 *h_n_symbols, u8 *d_out,
+                 const u64 *h_out_off);
+int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
+                  const u64 *h_in_n, u8 *d_out, const u64 *h_out_off, const u64 *h_out_cap, u64 *d_out_n,
+                  u64 *d_freq);
+int rledec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
+                  const u64 *h_in_n, u8 *d_out, const u64 *h_out_off, const u64 *h_out_cap, u64 *d_out_n);
+int gen_launch(hipStream_t st, u64 seed, u64 first, const u8 *d_map, u8 *d_out, size_t n);

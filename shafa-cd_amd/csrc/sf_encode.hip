@@ -1,0 +1,499 @@
+// sf_encode.hip — Module C hot path: Shannon-Fano bit-pack encode on gfx950.
+//
+// Replaces compress_to_buffer + binary_coding (reference c.c:52-237): the block's code bit-strings
+// concatenated MSB-first, zero padded to a byte.  One launch handles many independent blocks.
+//
+// Design (single pass over the input, HBM-bound, no MFMA):
+//   * a workgroup takes one tile (8-16 KiB of symbols) of one block, in ticket order per block, so a
+//     tile's predecessors have always started (deadlock-free for any dispatch order);
+//   * every lane loads 16 contiguous symbols per item with one coalesced 16-byte load, looks their
+//     {code,len} up in an LDS table, and concatenates them into G-symbol groups of <= 64 bits;
+//   * item bit totals are scanned wave -> workgroup; the tile total is chained across tiles with a
+//     decoupled look-back on one 64-bit {status,value} word per tile (relaxed agent-scope atomics);
+//   * groups are OR-ed into a zeroed LDS bit-stream at tile-local bit offsets, then the stream is
+//     funnel-shifted by (global bit offset mod 32) and stored as whole words, coalesced.  A tile owns
+//     every output word that BEGINS inside it; the few leading bits of its first word that belong to
+//     the previous tile are re-encoded from the input (<= 31 bits), so no output word is written
+//     twice, there are no global atomics and no pre-zeroing of the output.
+//
+// Algorithmic HBM bytes per block: n read + ceil(sum(freq*len)/8) written.
+#include "common.hpp"
+#include "internal.hpp"
+
+namespace {
+
+constexpr int ENC_THREADS = 256;
+constexpr int ENC_STAGE_WORDS = 5120;   // LDS bit-stream window per round (20 KiB)
+
+// ------------------------------------------------------------------------------------------------
+// look-back over one block's tile descriptors; wave 0 only, all 64 lanes.  Returns the exclusive
+// prefix (sum of the aggregates of tiles 0..k-1).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 lookback_sum(const u64 *desc, int k, int *err)
+{
+    const int lane = lane_id();
+    u64 excl = 0;
+    int j = k - 1;
+    for (;;) {
+        const int idx = j - lane;
+        u64 d = 0;
+        u32 spins = 0;
+        for (;;) {
+            d = (idx >= 0) ? desc_load(desc + idx) : (DESC_PREFIX << 62);
+            if (__all((d >> 62) != DESC_EMPTY)) break;
+            if (++spins > SPIN_LIMIT) {          // lost predecessor: flag instead of hanging
+                if (lane == 0) set_error(err, SHAFA_DEVICE_ERROR);
+                if ((d >> 62) == DESC_EMPTY) d = (DESC_PREFIX << 62);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const u64 val = d & DESC_VALUE_MASK;
+        const u64 pmask = __ballot((d >> 62) == DESC_PREFIX);
+        if (pmask) {
+            const int pl = __ffsll((unsigned long long)pmask) - 1;
+            excl += wave_reduce_add<u64>(lane <= pl ? val : 0ull);
+            break;
+        }
+        excl += wave_reduce_add<u64>(val);
+        j -= 64;
+    }
+    return excl;
+}
+
+// OR an L-bit group (right-aligned in g, 1 <= L <= 64) into the LDS bit-stream at tile-local bit q.
+// stage points at local word `wlo`; words outside [wlo, wlo+wcount) are skipped (other rounds).
+__device__ __forceinline__ void emit_group(u32 *stage, u32 wlo, u32 wcount, u64 g, u32 L, u32 q)
+{
+    if (L == 0) return;
+    const u64 hi = g << (64 - L);                 // left-aligned
+    const u32 sh = q & 31;
+    const u64 x = hi >> sh;
+    const u32 w0 = (u32)(x >> 32), w1 = (u32)x;
+    const u32 w2 = (u32)((((u64)(u32)hi) << 32) >> sh);
+    const u32 i0 = (q >> 5) - wlo;                 // wraps for words before the window
+    if (w0 && i0 < wcount) atomicOr(stage + i0, w0);
+    if (w1 && i0 + 1 < wcount) atomicOr(stage + i0 + 1, w1);
+    if (w2 && i0 + 2 < wcount) atomicOr(stage + i0 + 2, w2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// table entry formats
+// ------------------------------------------------------------------------------------------------
+template <int G> struct Ent;
+template <> struct Ent<4> {                       // Lmax <= 16: code | len << 16
+    typedef u32 type;
+    static __device__ __forceinline__ u32 len(u32 e) { return e >> 16; }
+    static __device__ __forceinline__ u32 code(u32 e) { return e & 0xFFFFu; }
+};
+template <> struct Ent<2> {                       // Lmax <= 32: code | len << 32
+    typedef u64 type;
+    static __device__ __forceinline__ u32 len(u64 e) { return (u32)(e >> 32); }
+    static __device__ __forceinline__ u32 code(u64 e) { return (u32)e; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// shared tail of both kernels: chain the tile total, compute the lead bits, run the rounds.
+// EmitFn(stage, wlo, wcount) ORs this thread's bits of the window into the stage.
+// LeadFn(need) returns the last `need` bits (1..31) of the stream that precedes the tile.
+// ------------------------------------------------------------------------------------------------
+struct EncShared {
+    u32 stage[ENC_STAGE_WORDS + 4];   // [0] = carry/lead word, [1..] = window
+    u32 wtot[16];
+    u32 tile;
+    u32 pad;
+    u64 prefix;
+};
+
+template <typename EmitFn, typename LeadFn>
+__device__ __forceinline__ void encode_tail(EncShared &sh, const EncBlk &blk, u64 *desc, int k,
+                                            u32 tile_bits, EmitFn emit, LeadFn lead_bits)
+{
+    const int tid = threadIdx.x;
+    u64 *bdesc = desc + blk.desc_base;
+    const bool last = (k == (int)blk.n_tiles - 1);
+
+    if (wave_id() == 0) {
+        u64 B = 0;
+        if (k > 0) {
+            if (tid == 0) desc_store(bdesc + k, DESC_AGG, tile_bits);
+            B = lookback_sum(bdesc, k, blk.err);
+        }
+        if (tid == 0) {
+            desc_store(bdesc + k, DESC_PREFIX, B + tile_bits);
+            sh.prefix = B;
+            const u32 s = (u32)B & 31;
+            sh.stage[0] = s ? lead_bits(s) : 0u;
+        }
+    }
+    // zero the window (stage[0] is owned by thread 0 above)
+    for (int i = tid; i < ENC_STAGE_WORDS; i += ENC_THREADS) sh.stage[1 + i] = 0;
+    __syncthreads();
+
+    const u64 B = sh.prefix;
+    const u64 E = B + tile_bits;
+    const u32 s = (u32)B & 31;
+    const u64 wg_lo = B >> 5;
+    const u64 wg_hi = last ? ((E + 31) >> 5) : (E >> 5);
+    const u32 OW = (u32)(wg_hi - wg_lo);
+    const u64 total_bytes = (E + 7) >> 3;          // meaningful for the last tile only
+    const u32 need_words = OW;                     // rounds only have to cover the words we store
+    u32 *out32 = (u32 *)blk.out;
+
+    for (u32 r0 = 0; r0 < need_words; r0 += ENC_STAGE_WORDS) {
+        if (r0) {   // later rounds (tile expands beyond one window): carry the last word, re-zero
+            __syncthreads();
+            u32 carry = 0;
+            if (tid == 0) carry = sh.stage[ENC_STAGE_WORDS];
+            __syncthreads();
+            for (int i = tid; i < ENC_STAGE_WORDS; i += ENC_THREADS) sh.stage[1 + i] = 0;
+            if (tid == 0) sh.stage[0] = carry;
+            __syncthreads();
+        }
+        emit(sh.stage + 1, r0, (u32)ENC_STAGE_WORDS);
+        __syncthreads();
+        const u32 jend = (OW < r0 + ENC_STAGE_WORDS) ? OW : r0 + ENC_STAGE_WORDS;
+        for (u32 j = r0 + tid; j < jend; j += ENC_THREADS) {
+            const u32 li = j - r0;
+            const u32 w = funnel_r(sh.stage[li], sh.stage[li + 1], s);
+            const u64 W = wg_lo + j;
+            if (last && W == wg_hi - 1 && total_bytes < 4 * (W + 1)) {
+                const u32 nb = (u32)(total_bytes - 4 * W);     // 1..3 bytes of the final word
+                if (total_bytes <= blk.out_cap) {
+                    for (u32 q = 0; q < nb; ++q) blk.out[4 * W + q] = (u8)(w >> (24 - 8 * q));
+                } else set_error(blk.err, SHAFA_LACK_OF_MEMORY);
+            } else if (4 * (W + 1) <= blk.out_cap) {
+                out32[W] = bswap32(w);
+            } else set_error(blk.err, SHAFA_LACK_OF_MEMORY);
+        }
+    }
+    if (last && tid == 0) *blk.out_n = total_bytes;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fast kernel: Lmax <= 16 (G = 4, 16 KiB tiles) or Lmax <= 32 (G = 2, 8 KiB tiles)
+// ------------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(ENC_THREADS) void sf_encode_fast(const EncBlk *__restrict__ blks, int nblk,
+                                                              u64 *desc, u32 *tickets)
+{
+    typedef typename Ent<G>::type ent_t;
+    constexpr int ITEMS = G;                 // 16-byte items per thread
+    constexpr int NGRP = 16 / G;             // groups per item
+    constexpr int TILE = ENC_THREADS * 16 * ITEMS;
+
+    __shared__ __attribute__((aligned(16))) EncShared sh;
+    __shared__ __attribute__((aligned(16))) ent_t lut[256];
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x % nblk;
+    const EncBlk blk = blks[b];
+    if ((u32)(blockIdx.x / nblk) >= blk.n_tiles) return;
+
+    if (tid == 0) sh.tile = atomicAdd(tickets + blk.ticket, 1u);
+    lut[tid] = ((const ent_t *)blk.lut)[tid];
+    __syncthreads();
+    const int k = (int)sh.tile;
+    const u64 tile_start = (u64)k * TILE;
+
+    // ---- load + look up + group -----------------------------------------------------------------
+    u64 grp[ITEMS][NGRP];
+    u32 glen[ITEMS][NGRP];
+    u32 itot[ITEMS];
+    bool bad = false;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const u64 idx = tile_start + (u64)it * (ENC_THREADS * 16) + (u64)tid * 16;
+        u32 wds[4] = {0, 0, 0, 0};
+        int nvalid = 0;
+        if (idx + 16 <= blk.n) {
+            const uint4 v = *(const uint4 *)(blk.in + idx);
+            wds[0] = v.x; wds[1] = v.y; wds[2] = v.z; wds[3] = v.w;
+            nvalid = 16;
+        } else if (idx < blk.n) {
+            nvalid = (int)(blk.n - idx);
+#pragma unroll
+            for (int q = 0; q < 16; ++q)     // static indices: keeps wds[] in registers
+                if (q < nvalid) wds[q >> 2] |= (u32)blk.in[idx + q] << (8 * (q & 3));
+        }
+        ent_t e[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const u32 sym = (wds[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            ent_t x = lut[sym];
+            if (j >= nvalid) x = 0;
+            else if (Ent<G>::len(x) == 0) bad = true;
+            e[j] = x;
+        }
+        u32 tot = 0;
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+            u64 acc = 0;
+            u32 L = 0;
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const ent_t x = e[g * G + j];
+                const u32 l = Ent<G>::len(x);
+                acc = (acc << l) | Ent<G>::code(x);
+                L += l;
+            }
+            grp[it][g] = acc;
+            glen[it][g] = L;
+            tot += L;
+        }
+        itot[it] = tot;
+    }
+    if (bad) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
+
+    // ---- scan item totals: wave scan, then 16 wave totals through LDS ---------------------------
+    u32 incl[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) incl[it] = wave_incl_scan_add<u32>(itot[it]);
+    if (lane_id() == 63) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) sh.wtot[it * 4 + wave_id()] = incl[it];
+    }
+    __syncthreads();
+    u32 ioff[ITEMS];
+    u32 run = 0;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w == wave_id()) ioff[it] = run + incl[it] - itot[it];
+            run += sh.wtot[it * 4 + w];
+        }
+    }
+    const u32 tile_bits = run;
+
+    auto emit = [&](u32 *stage, u32 wlo, u32 wcount) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            u32 q = ioff[it];
+#pragma unroll
+            for (int g = 0; g < NGRP; ++g) {
+                emit_group(stage, wlo, wcount, grp[it][g], glen[it][g], q);
+                q += glen[it][g];
+            }
+        }
+    };
+    auto lead = [&](u32 need) -> u32 {   // last `need` bits of the stream before this tile
+        u64 acc = 0;
+        u32 got = 0;
+        for (u64 p = tile_start; p > 0 && got < need;) {
+            --p;
+            const ent_t x = lut[blk.in[p]];
+            acc |= (u64)Ent<G>::code(x) << got;
+            got += Ent<G>::len(x);
+        }
+        return (u32)acc & ((1u << need) - 1u);
+    };
+    encode_tail(sh, blk, desc, k, tile_bits, emit, lead);
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic kernel: any code length up to 255 bits (hand-made / foreign .cod tables).  One symbol per
+// lane and step, 1024-symbol tiles; the table (len + 32 code bytes per symbol) is read from global.
+// ------------------------------------------------------------------------------------------------
+constexpr int GEN_SYMS = 4;                       // symbols per thread
+constexpr int GEN_TILE = ENC_THREADS * GEN_SYMS;  // 1024 symbols, <= 32640 bytes of output
+
+// bits [from, from+cnt) of symbol s's code (cnt <= 32), right-aligned
+__device__ __forceinline__ u32 code_bits(const shafa_code_table *t, u32 s, u32 from, u32 cnt)
+{
+    u32 v = 0;
+    for (u32 i = 0; i < cnt; ++i) {
+        const u32 bit = from + i;
+        v = (v << 1) | ((t->bits[s][bit >> 3] >> (7 - (bit & 7))) & 1u);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(ENC_THREADS) void sf_encode_generic(const EncBlk *__restrict__ blks, int nblk,
+                                                                 u64 *desc, u32 *tickets)
+{
+    __shared__ __attribute__((aligned(16))) EncShared sh;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x % nblk;
+    const EncBlk blk = blks[b];
+    if ((u32)(blockIdx.x / nblk) >= blk.n_tiles) return;
+    if (tid == 0) sh.tile = atomicAdd(tickets + blk.ticket, 1u);
+    __syncthreads();
+    const int k = (int)sh.tile;
+    const u64 tile_start = (u64)k * GEN_TILE;
+    const shafa_code_table *tab = (const shafa_code_table *)blk.lut;
+
+    u32 sym[GEN_SYMS], len[GEN_SYMS];
+    u32 tot = 0;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < GEN_SYMS; ++j) {
+        const u64 idx = tile_start + (u64)tid * GEN_SYMS + j;
+        sym[j] = 0; len[j] = 0;
+        if (idx < blk.n) {
+            sym[j] = blk.in[idx];
+            len[j] = tab->len[sym[j]];
+            if (len[j] == 0) bad = true;
+        }
+        tot += len[j];
+    }
+    if (bad) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
+
+    const u32 incl = wave_incl_scan_add<u32>(tot);
+    if (lane_id() == 63) sh.wtot[wave_id()] = incl;
+    __syncthreads();
+    u32 run = 0, off = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w == wave_id()) off = run + incl - tot;
+        run += sh.wtot[w];
+    }
+    const u32 tile_bits = run;
+
+    auto emit = [&](u32 *stage, u32 wlo, u32 wcount) {
+        u32 q = off;
+#pragma unroll
+        for (int j = 0; j < GEN_SYMS; ++j) {
+            for (u32 done = 0; done < len[j]; done += 32) {
+                const u32 c = (len[j] - done) < 32 ? (len[j] - done) : 32;
+                emit_group(stage, wlo, wcount, code_bits(tab, sym[j], done, c), c, q + done);
+            }
+            q += len[j];
+        }
+    };
+    auto lead = [&](u32 need) -> u32 {
+        u32 acc = 0, got = 0;
+        for (u64 p = tile_start; p > 0 && got < need;) {
+            --p;
+            const u32 s = blk.in[p];
+            const u32 l = tab->len[s];
+            const u32 take = (need - got) < l ? (need - got) : l;   // the code's LAST `take` bits
+            if (take) acc |= code_bits(tab, s, l - take, take) << got;
+            got += take;
+        }
+        return acc;
+    };
+    encode_tail(sh, blk, desc, k, tile_bits, emit, lead);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host launcher
+// ------------------------------------------------------------------------------------------------
+int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
+                 const u64 *h_in_n, const shafa_code_table *h_tables, u8 *d_out, const u64 *h_out_off,
+                 const u64 *h_out_cap, u64 *d_out_n)
+{
+    if (nblocks <= 0) return SHAFA_SUCCESS;
+    if (nblocks > bt->max_blocks) return SHAFA_LACK_OF_MEMORY;
+
+    // classify blocks: 0 = nothing to launch (empty table or empty block), 1 = G4, 2 = G2, 3 = generic
+    int cls_count[4] = {0, 0, 0, 0};
+    std::vector<int> cls(nblocks);
+    u64 total_tiles[4] = {0, 0, 0, 0};
+    u32 max_tiles[4] = {0, 0, 0, 0};
+    static const u64 tile_syms[4] = {1, 256 * 16 * 4, 256 * 16 * 2, GEN_TILE};
+    for (int b = 0; b < nblocks; ++b) {
+        if ((h_in_off[b] & 15) || (h_out_off[b] & 15)) return SHAFA_OUTSIDE_MODULE;
+        const u64 n = h_in_n[b];
+        int lmax = 0;
+        for (int s = 0; s < 256; ++s) lmax = h_tables[b].len[s] > lmax ? h_tables[b].len[s] : lmax;
+        int c = (lmax == 0 || n == 0) ? 0 : (lmax <= 16 ? 1 : (lmax <= 32 ? 2 : 3));
+        cls[b] = c;
+        cls_count[c]++;
+        if (c) {
+            const u64 t = ceil_div_u64(n, tile_syms[c]);
+            total_tiles[c] += t;
+            if (t > max_tiles[c]) max_tiles[c] = (u32)t;
+        }
+    }
+    const u64 ndesc = total_tiles[1] + total_tiles[2] + total_tiles[3];
+
+    // device workspace: [desc u64 * ndesc][tickets u32 * nblocks][EncBlk * nblocks][tables]
+    size_t off = 0;
+    const size_t o_desc = off; off += ndesc * 8;
+    const size_t o_tick = off; off += (size_t)nblocks * 4; off = (off + 15) & ~(size_t)15;
+    const size_t o_zero_end = off;
+    const size_t o_blk = off; off += (size_t)nblocks * sizeof(EncBlk); off = (off + 15) & ~(size_t)15;
+    const size_t o_tab = off;
+    size_t tab_bytes = 0;
+    for (int b = 0; b < nblocks; ++b)
+        tab_bytes += cls[b] == 1 ? 1024 : cls[b] == 2 ? 2048 : cls[b] == 3 ? ((sizeof(shafa_code_table) + 15) & ~15ul) : 0;
+    off += tab_bytes;
+    int rc = batch_reserve(bt, off);
+    if (rc) return rc;
+    u8 *ws = (u8 *)bt->d_ws;
+
+    // host staging: EncBlk array + tables, one H2D copy
+    const size_t stage_bytes = off - o_blk;
+    u8 *hs = (u8 *)batch_stage(bt, st, stage_bytes);
+    if (!hs) return SHAFA_LACK_OF_MEMORY;
+    EncBlk *hb = (EncBlk *)hs;
+    u8 *htab = hs + (o_tab - o_blk);
+    size_t tpos = 0;
+    u32 dbase = 0;
+    // blocks of one class are contiguous in the param array (class order 1,2,3), each class is one launch
+    int cls_first[4] = {0, 0, 0, 0};
+    int pos = 0;
+    for (int c = 1; c <= 3; ++c) {
+        cls_first[c] = pos;
+        for (int b = 0; b < nblocks; ++b) {
+            if (cls[b] != c) continue;
+            EncBlk &e = hb[pos];
+            const u64 n = h_in_n[b];
+            e.in = d_in + h_in_off[b];
+            e.out = d_out + h_out_off[b];
+            e.n = n;
+            e.out_cap = h_out_cap[b];
+            e.out_n = d_out_n + b;
+            e.err = bt->d_err + b;
+            e.desc_base = dbase;
+            e.n_tiles = (u32)ceil_div_u64(n, tile_syms[c]);
+            e.ticket = (u32)pos;
+            dbase += e.n_tiles;
+            e.lut = ws + o_tab + tpos;
+            const shafa_code_table &t = h_tables[b];
+            if (c == 1) {
+                u32 *l = (u32 *)(htab + tpos);
+                for (int s = 0; s < 256; ++s) {
+                    u32 code = 0;
+                    for (int q = 0; q < t.len[s]; ++q) code = (code << 1) | ((t.bits[s][q >> 3] >> (7 - (q & 7))) & 1u);
+                    l[s] = code | ((u32)t.len[s] << 16);
+                }
+                tpos += 1024;
+            } else if (c == 2) {
+                u64 *l = (u64 *)(htab + tpos);
+                for (int s = 0; s < 256; ++s) {
+                    u64 code = 0;
+                    for (int q = 0; q < t.len[s]; ++q) code = (code << 1) | ((t.bits[s][q >> 3] >> (7 - (q & 7))) & 1u);
+                    l[s] = code | ((u64)t.len[s] << 32);
+                }
+                tpos += 2048;
+            } else {
+                memcpy(htab + tpos, &t, sizeof(t));
+                tpos += (sizeof(shafa_code_table) + 15) & ~15ul;
+            }
+            ++pos;
+        }
+    }
+    if (o_zero_end) HIP_TRY(hipMemsetAsync(ws, 0, o_zero_end, st));
+    HIP_TRY(hipMemcpyAsync(ws + o_blk, hs, stage_bytes, hipMemcpyHostToDevice, st));
+    for (int b = 0; b < nblocks; ++b)
+        if (cls[b] == 0) HIP_TRY(hipMemsetAsync(d_out_n + b, 0, 8, st));
+
+    const EncBlk *dblk = (const EncBlk *)(ws + o_blk);
+    u64 *ddesc = (u64 *)(ws + o_desc);
+    u32 *dtick = (u32 *)(ws + o_tick);
+    if (cls_count[1])
+        hipLaunchKernelGGL(sf_encode_fast<4>, dim3(max_tiles[1] * cls_count[1]), dim3(ENC_THREADS), 0, st,
+                           dblk + cls_first[1], cls_count[1], ddesc, dtick);
+    if (cls_count[2])
+        hipLaunchKernelGGL(sf_encode_fast<2>, dim3(max_tiles[2] * cls_count[2]), dim3(ENC_THREADS), 0, st,
+                           dblk + cls_first[2], cls_count[2], ddesc, dtick);
+    if (cls_count[3])
+        hipLaunchKernelGGL(sf_encode_generic, dim3(max_tiles[3] * cls_count[3]), dim3(ENC_THREADS), 0, st,
+                           dblk + cls_first[3], cls_count[3], ddesc, dtick);
+    HIP_TRY(hipGetLastError());
+    return SHAFA_SUCCESS;
+}

@@ -1,0 +1,73 @@
+/*
+ * sfcodes.c — Module T core: Shannon-Fano code construction for one 256-bin histogram
+ * (reference t.c:74-210).  Host-side by design: 256 symbols per block is
+ * microseconds of work and the result (one shafa_code_table) feeds the HIP encode/decode kernels.
+ *
+ * Rule set (what makes the output bit-exact with the reference's .cod):
+ *   - symbols ordered by frequency, descending, ties by ascending symbol (stable sort, t.c:87);
+ *   - only symbols with a non-zero count take part (t.c:202-210); one such symbol => empty code;
+ *   - a range [a,b] of ranks is cut after rank d, the first d at which |2*left - total| stops
+ *     strictly decreasing (t.c:138-149): '0' is appended to a..d, '1' to d+1..b, then both halves
+ *     are cut the same way (t.c:187-193).
+ */
+#include "shafa_host.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { uint64_t count; int sym; } ranked;
+
+static int by_count_desc(const void *pa, const void *pb)
+{
+    const ranked *a = pa, *b = pb;
+    if (a->count != b->count) return a->count < b->count ? 1 : -1;
+    return a->sym - b->sym;
+}
+
+void shafa_sf_build_codes(const uint64_t freq[256], shafa_code_table *out)
+{
+    ranked r[256];
+    int used = 0;
+    for (int s = 0; s < 256; ++s) {
+        r[s].count = freq[s];
+        r[s].sym = s;
+        used += freq[s] != 0;
+    }
+    qsort(r, 256, sizeof(ranked), by_count_desc);
+
+    /* cum[i] = sum of the first i ranked counts: range totals in O(1) */
+    uint64_t cum[257];
+    cum[0] = 0;
+    for (int i = 0; i < 256; ++i) cum[i + 1] = cum[i] + r[i].count;
+
+    memset(out, 0, sizeof(*out));
+    if (used < 2) return;
+
+    /* explicit stack of rank ranges; a parent is always cut before its halves */
+    struct { int a, b; } stack[512];
+    int top = 0;
+    stack[top].a = 0; stack[top].b = used - 1; ++top;
+    while (top) {
+        --top;
+        const int a = stack[top].a, b = stack[top].b;
+        if (a == b) continue;
+        const int64_t total = (int64_t)(cum[b + 1] - cum[a]);
+        int cut = a;
+        int64_t best = total;
+        for (int i = a; i <= b; ++i) {
+            int64_t d = 2 * (int64_t)(cum[i + 1] - cum[a]) - total;
+            if (d < 0) d = -d;
+            if (d >= best) break;
+            best = d;
+            cut = i;
+        }
+        for (int i = a; i <= b; ++i) {
+            const int s = r[i].sym;
+            const unsigned n = out->len[s];
+            if (i > cut) out->bits[s][n / 8] |= (uint8_t)(0x80 >> (n % 8));
+            out->len[s] = (uint8_t)(n + 1);
+        }
+        stack[top].a = cut + 1; stack[top].b = b; ++top;
+        stack[top].a = a; stack[top].b = cut; ++top;
+    }
+}

@@ -1,0 +1,84 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/shafa_hip.h declares (no compute calls — there is no GPU here), and the C host's formats and
+Module T agree with the reference-generated golden files."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle_lib import parse_blocks_text
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def declared_symbols(header):
+    with open(header) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(shafa_hipd?_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(shafa):
+    syms = declared_symbols(os.path.join(ROOT, "include", "shafa_hip.h"))
+    assert len(syms) >= 18, syms
+    L = ctypes.CDLL(shafa.LIB_PATH)
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, f"declared in include/shafa_hip.h but not exported: {missing}"
+    assert L.shafa_hip_abi_version() == 1
+    assert ctypes.sizeof(shafa.CodeTable) == 256 + 256 * 32
+
+
+def test_no_gpu_is_reported_not_faked(shafa):
+    """Without a GPU the product path must fail loudly (no CPU fallback)."""
+    L = shafa.lib()
+    if L.shafa_hip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    assert L.shafa_hip_init(0) == shafa.DEVICE_ERROR
+    with pytest.raises(shafa.ShafaError) as e:
+        shafa.hist256(np.zeros(100, dtype=np.uint8))
+    assert e.value.code == shafa.DEVICE_ERROR
+
+
+def rd(case, fn):
+    with open(os.path.join(GOLD, case, fn), "rb") as f:
+        return f.read()
+
+
+@pytest.mark.parametrize("case,stem", [("runs_default", "x.rle"), ("edges_forced_rle", "e.rle"),
+                                       ("uniform_no_rle", "u"), ("textlike_m", "t"), ("t_handmade", "h")])
+def test_host_module_t_and_formats_match_reference_files(shafa, case, stem):
+    fmode, fblocks = parse_blocks_text(rd(case, stem + ".freq"))
+    cmode, cblocks = parse_blocks_text(rd(case, stem + ".cod"))
+    for (fsize, ftext), (csize, ctext) in zip(fblocks, cblocks):
+        rc, freq = shafa.freq_parse(ftext)
+        assert rc == 0
+        assert shafa.freq_format(freq) == ftext
+        tab = shafa.sf_build_codes(freq)
+        assert shafa.cod_format(tab) == ctext
+        rc, tab2 = shafa.cod_parse(ctext)
+        assert rc == 0 and bytes(tab2.bits) == bytes(tab.bits) and bytes(tab2.len) == bytes(tab.len)
+
+
+def test_host_parsers_reject_malformed(shafa):
+    assert shafa.freq_parse(b";" * 255)[0] == shafa.FILE_UNRECOGNIZABLE          # field 0 must be a number
+    assert shafa.freq_parse(b"1" + b";" * 254)[0] == shafa.FILE_UNRECOGNIZABLE   # 255 fields
+    assert shafa.freq_parse(b"1" + b";" * 256)[0] == shafa.FILE_UNRECOGNIZABLE   # 257 fields
+    assert shafa.freq_parse(b"1" + b";" * 255)[0] == 0
+    assert shafa.cod_parse(b"0;1" + b";" * 254)[0] == 0
+    assert shafa.cod_parse(b"0;2" + b";" * 254)[0] == shafa.FILE_UNRECOGNIZABLE
+    assert shafa.cod_parse(b"0;1" + b";" * 252)[0] == shafa.FILE_UNRECOGNIZABLE
+    assert shafa.cod_parse(b"0" * 256 + b";" * 255)[0] == shafa.FILE_UNRECOGNIZABLE  # > 255 bits
+
+
+def test_block_split_and_rle_rule(shafa):
+    H = shafa.host()
+    bs, last = ctypes.c_uint64(65536), ctypes.c_uint64(0)
+    assert H.shafa_block_count(212345, ctypes.byref(bs), ctypes.byref(last)) == 4 and last.value == 212345 - 3 * 65536
+    assert H.shafa_block_count(131072, ctypes.byref(bs), ctypes.byref(last)) == 2 and last.value == 65536
+    bs = ctypes.c_uint64(100)
+    H.shafa_block_count(5000, ctypes.byref(bs), ctypes.byref(last))
+    assert bs.value == 512                                                     # file.c:61-65 clamp
+    assert H.shafa_rle_worthwhile(1000, 950, False) and not H.shafa_rle_worthwhile(1000, 951, False)
+    assert H.shafa_rle_worthwhile(1000, 2000, True)
