@@ -79,8 +79,11 @@ int shafa_hipd_batch_create(int max_blocks, size_t max_block_bytes, shafa_hipd_b
     if (!b) return SHAFA_LACK_OF_MEMORY;
     b->max_blocks = max_blocks;
     b->max_block_bytes = max_block_bytes;
+    b->h_hosterr = (int *)calloc((size_t)max_blocks, sizeof(int));
+    if (!b->h_hosterr) { free(b); return SHAFA_LACK_OF_MEMORY; }
     hipError_t e = hipMalloc((void **)&b->d_err, (size_t)max_blocks * sizeof(int));
     if (e == hipSuccess) e = hipMemset(b->d_err, 0, (size_t)max_blocks * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&b->d_par_hist, (size_t)max_blocks * 32);
     if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_err, (size_t)max_blocks * sizeof(int), hipHostMallocDefault);
     if (e != hipSuccess) {
         if (b->d_err) hipFree(b->d_err);
@@ -99,7 +102,9 @@ void shafa_hipd_batch_destroy(shafa_hipd_batch *hb)
     if (b->d_ws) hipFree(b->d_ws);
     if (b->h_stage) hipHostFree(b->h_stage);
     if (b->d_err) hipFree(b->d_err);
+    if (b->d_par_hist) hipFree(b->d_par_hist);
     if (b->h_err) hipHostFree(b->h_err);
+    free(b->h_hosterr);
     free(b);
 }
 
@@ -158,8 +163,10 @@ int shafa_hipd_finish(shafa_hipd_batch *hb, void *stream, int nblocks, int *h_bl
     b->stage_used = 0;
     int first = SHAFA_SUCCESS;
     for (int i = 0; i < nblocks; ++i) {
-        if (h_block_err) h_block_err[i] = b->h_err[i];
-        if (!first && b->h_err[i]) first = b->h_err[i];
+        const int e = b->h_hosterr[i] ? b->h_hosterr[i] : b->h_err[i];
+        b->h_hosterr[i] = 0;
+        if (h_block_err) h_block_err[i] = e;
+        if (!first && e) first = e;
     }
     if (first == SHAFA_DEVICE_ERROR)
         snprintf(g_last_error, sizeof(g_last_error), "kernel reported a lost predecessor tile (spin bound hit)");

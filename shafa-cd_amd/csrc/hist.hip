@@ -16,16 +16,17 @@ constexpr int HIST_THREADS = 256;
 constexpr u64 HIST_CHUNK = 256 * 1024;
 constexpr int HIST_REP = 8;
 
-struct HistBlk { const u8 *in; u64 n; u64 *freq; };
+struct HistBlk { const u8 *in; u64 n; u64 *freq; const u64 *n_dev; };
 
 __global__ __launch_bounds__(HIST_THREADS) void hist256_kernel(const HistBlk *__restrict__ blks)
 {
     __shared__ u32 h[256 * HIST_REP];
     const int tid = threadIdx.x;
     const HistBlk blk = blks[blockIdx.y];
+    const u64 n = blk.n_dev ? *blk.n_dev : blk.n;      // size produced on the device (RLE output)
     const u64 start = (u64)blockIdx.x * HIST_CHUNK;
-    if (start >= blk.n) return;
-    const u64 end = (start + HIST_CHUNK < blk.n) ? start + HIST_CHUNK : blk.n;
+    if (start >= n) return;
+    const u64 end = (start + HIST_CHUNK < n) ? start + HIST_CHUNK : n;
 
     for (int i = tid; i < 256 * HIST_REP; i += HIST_THREADS) h[i] = 0;
     __syncthreads();
@@ -53,14 +54,13 @@ __global__ __launch_bounds__(HIST_THREADS) void hist256_kernel(const HistBlk *__
 
 }  // namespace
 
-int hist_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
-                const u64 *h_in_n, u64 *d_freq)
+// h_in_n[b] is the block size, or (with d_n != NULL) an upper bound of the size the device wrote to d_n[b]
+int hist_launch_dev(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
+                    const u64 *h_in_n, const u64 *d_n, u64 *d_freq)
 {
     if (nblocks <= 0) return SHAFA_SUCCESS;
     if (nblocks > bt->max_blocks) return SHAFA_LACK_OF_MEMORY;
     const size_t pbytes = (size_t)nblocks * sizeof(HistBlk);
-    int rc = batch_reserve(bt, pbytes);
-    if (rc) return rc;
     HistBlk *hp = (HistBlk *)batch_stage(bt, st, pbytes);
     if (!hp) return SHAFA_LACK_OF_MEMORY;
     u64 max_n = 0;
@@ -69,13 +69,20 @@ int hist_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u6
         hp[b].in = d_in + h_in_off[b];
         hp[b].n = h_in_n[b];
         hp[b].freq = d_freq + (size_t)b * 256;
+        hp[b].n_dev = d_n ? d_n + b : nullptr;
         if (hp[b].n > max_n) max_n = hp[b].n;
     }
     HIP_TRY(hipMemsetAsync(d_freq, 0, (size_t)nblocks * 256 * sizeof(u64), st));
     if (max_n == 0) return SHAFA_SUCCESS;
-    HIP_TRY(hipMemcpyAsync(bt->d_ws, hp, pbytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(bt->d_par_hist, hp, pbytes, hipMemcpyHostToDevice, st));
     const dim3 grid((u32)ceil_div_u64(max_n, HIST_CHUNK), (u32)nblocks);
-    hipLaunchKernelGGL(hist256_kernel, grid, dim3(HIST_THREADS), 0, st, (const HistBlk *)bt->d_ws);
+    hipLaunchKernelGGL(hist256_kernel, grid, dim3(HIST_THREADS), 0, st, (const HistBlk *)bt->d_par_hist);
     HIP_TRY(hipGetLastError());
     return SHAFA_SUCCESS;
+}
+
+int hist_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
+                const u64 *h_in_n, u64 *d_freq)
+{
+    return hist_launch_dev(bt, st, nblocks, d_in, h_in_off, h_in_n, nullptr, d_freq);
 }

@@ -15,8 +15,11 @@ struct Batch {
     u8 *h_stage;           // pinned host staging for parameter blocks / tables (bump allocated,
     size_t stage_bytes;    //   reset by shafa_hipd_finish, which synchronises the stream)
     size_t stage_used;
+    void *d_par_hist;      // max_blocks * 32 B of hist256 parameters (separate from d_ws: hist256 may
+                           //   run right after another op that still owns the workspace)
     int *d_err;            // one error code per block (first error wins)
     int *h_err;            // pinned mirror
+    int *h_hosterr;        // errors found on the host while preparing a launch (malformed tables)
 };
 
 // make sure the device workspace holds `bytes`
@@ -42,6 +45,8 @@ struct EncBlk {
 // ---- launchers (one per reference function) ------------------------------------------------------
 int hist_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                 const u64 *h_in_n, u64 *d_freq);
+int hist_launch_dev(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
+                    const u64 *h_in_n, const u64 *d_n, u64 *d_freq);
 int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                  const u64 *h_in_n, const shafa_code_table *h_tables, u8 *d_out, const u64 *h_out_off,
                  const u64 *h_out_cap, u64 *d_out_n);

@@ -1,3 +1,353 @@
+// rle_encode.hip — Module F hot path: RLE tokenisation (reference f.c:29-55 block_compression).
+//
+// Closed form per element, so a run of any length — up to the whole 64 MiB block —
+// is tokenised in parallel.  With head(i)/end(i) the bounds of i's maximal run,
+//     r = (i - head(i)) mod 255          e = min(255, end(i) - i)
+//     r == 0 : emit {0, s, e} if s == 0 or e >= 4, else the literal s
+//     r  > 0 : emit the literal s if s != 0 and r + e < 4, else nothing
+// r needs the run length that enters a tile from the left (a chained look-back over tiles that are
+// one single run), e needs at most 255 bytes of look-ahead (a halo read).  Output offsets are an
+// exclusive scan of the emit sizes, chained across tiles by a second look-back.  Tiles are taken in
+// ticket order per block (deadlock-free for any dispatch order); tokens are staged in LDS and stored
+// as aligned words.
+//
+// Algorithmic HBM bytes per block: n read + rle_n written.
 #include "common.hpp"
 #include "internal.hpp"
-int rleenc_launch(Batch *, hipStream_t, int, const u8 *, const u64 *, const u64 *, u8 *, const u64 *, const u64 *, u64 *, u64 *) { return SHAFA_OUTSIDE_MODULE; }
+
+namespace {
+
+constexpr int RLE_THREADS = 256;
+constexpr int RLE_TILE = RLE_THREADS * 16;
+constexpr int RLE_STAGE = 2 * RLE_TILE + 64;
+
+struct RleBlk {
+    const u8 *in;
+    u8 *out;
+    u64 n;
+    u64 out_cap;
+    u64 *out_n;
+    int *err;
+    u32 desc_base;
+    u32 n_tiles;
+    u32 ticket;
+    u32 pad;
+};
+
+struct Seg { u32 f, v; };
+
+// forward: combine(left a, right b) — b's run absorbs a's when b is "all one run that continues"
+__device__ __forceinline__ Seg comb_f(Seg a, Seg b) { return Seg{a.f & b.f, b.f ? a.v + b.v : b.v}; }
+// backward: combine(left a, right b) — a's run absorbs b's
+__device__ __forceinline__ Seg comb_b(Seg a, Seg b) { return Seg{a.f & b.f, a.f ? a.v + b.v : a.v}; }
+
+#define RUN_C_BIT 40
+#define RUN_V_MASK ((1ull << RUN_C_BIT) - 1)
+
+// run length (from its true head inside the block) of the run that ends at the last byte of tile k-1
+__device__ __forceinline__ u64 lookback_run(const u64 *desc, int k, int *err)
+{
+    const int lane = lane_id();
+    u64 acc = 0;
+    int j = k - 1;
+    for (;;) {
+        const int idx = j - lane;
+        u64 d = 0;
+        u32 spins = 0;
+        for (;;) {
+            d = (idx >= 0) ? desc_load(desc + idx) : (DESC_PREFIX << 62);
+            if (__all((d >> 62) != DESC_EMPTY)) break;
+            if (++spins > SPIN_LIMIT) {
+                if (lane == 0) set_error(err, SHAFA_DEVICE_ERROR);
+                if ((d >> 62) == DESC_EMPTY) d = (DESC_PREFIX << 62);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const u64 val = d & RUN_V_MASK;
+        const bool stop = ((d >> 62) == DESC_PREFIX) || !((d >> RUN_C_BIT) & 1);
+        const u64 m = __ballot(stop);
+        if (m) {
+            const int pl = __ffsll((unsigned long long)m) - 1;
+            acc += wave_reduce_add<u64>(lane <= pl ? val : 0ull);
+            break;
+        }
+        acc += wave_reduce_add<u64>(val);
+        j -= 64;
+    }
+    return acc;
+}
+
+struct RleShared {
+    u32 stage[RLE_STAGE / 4];
+    Seg wf[4], wb[4];
+    u32 wsum[4];
+    u32 tile;
+    u32 R;          // run length entering the tile from the left
+    u32 H;          // bytes after the tile equal to its last byte (<= 255)
+    u32 pad;
+    u64 G;          // output byte offset of the tile
+};
+
+__global__ __launch_bounds__(RLE_THREADS) void rle_encode_kernel(const RleBlk *__restrict__ blks, int nblk,
+                                                                 u64 *desc_run, u64 *desc_sum, u32 *tickets)
+{
+    __shared__ __attribute__((aligned(16))) RleShared sh;
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int b = blockIdx.x % nblk;
+    const RleBlk blk = blks[b];
+    if ((u32)(blockIdx.x / nblk) >= blk.n_tiles) return;
+    if (tid == 0) sh.tile = atomicAdd(tickets + blk.ticket, 1u);
+    __syncthreads();
+    const int k = (int)sh.tile;
+    const u64 n = blk.n;
+    const u64 tile_start = (u64)k * RLE_TILE;
+    const u64 tile_end = (tile_start + RLE_TILE < n) ? tile_start + RLE_TILE : n;
+    const u64 pos = tile_start + (u64)tid * 16;
+    u64 *drun = desc_run + blk.desc_base, *dsum = desc_sum + blk.desc_base;
+
+    // ---- load 16 bytes; bytes past the block end become sentinels that never equal a neighbour ----
+    u32 x[16];
+    int nvalid = 0;
+    if (pos + 16 <= n) {
+        const uint4 v = *(const uint4 *)(blk.in + pos);
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j] = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        nvalid = 16;
+    } else {
+        nvalid = pos < n ? (int)(n - pos) : 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) x[j] = (j < nvalid) ? (u32)blk.in[pos + j] : (0x100u | (j & 1));
+    }
+    const u32 pb = (pos > 0 && pos <= n) ? (u32)blk.in[pos - 1] : 0x200u;
+    const u32 nb = (pos + 16 < n) ? (u32)blk.in[pos + 16] : 0x300u;
+
+    // ---- per-thread summaries ------------------------------------------------------------------------
+    bool uni = true;
+#pragma unroll
+    for (int j = 1; j < 16; ++j) uni &= (x[j] == x[0]);
+    u32 suf = 1, pre = 1;
+    {
+        bool go = true;
+#pragma unroll
+        for (int j = 14; j >= 0; --j) { go &= (x[j] == x[15]); suf += go ? 1u : 0u; }
+        go = true;
+#pragma unroll
+        for (int j = 1; j < 16; ++j) { go &= (x[j] == x[0]); pre += go ? 1u : 0u; }
+    }
+    const bool eq0 = (x[0] == pb), eq15 = (x[15] == nb);
+
+    // ---- segmented scans over the 256 threads: forward (run length entering from the left),
+    //      backward (run length continuing to the right) -------------------------------------------------
+    Seg fi = Seg{(u32)(uni && eq0), suf}, bi = Seg{(u32)(uni && eq15), pre};
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        Seg y = Seg{(u32)__shfl_up(fi.f, d, 64), (u32)__shfl_up(fi.v, d, 64)};
+        if (lane >= d) fi = comb_f(y, fi);
+        Seg z = Seg{(u32)__shfl_down(bi.f, d, 64), (u32)__shfl_down(bi.v, d, 64)};
+        if (lane + d < 64) bi = comb_b(bi, z);
+    }
+    if (lane == 63) sh.wf[wv] = fi;
+    if (lane == 0) sh.wb[wv] = bi;
+    // exclusive values inside the wave
+    Seg fe = Seg{(u32)__shfl_up(fi.f, 1, 64), (u32)__shfl_up(fi.v, 1, 64)};
+    if (lane == 0) fe = Seg{1u, 0u};
+    Seg be = Seg{(u32)__shfl_down(bi.f, 1, 64), (u32)__shfl_down(bi.v, 1, 64)};
+    if (lane == 63) be = Seg{1u, 0u};
+    __syncthreads();
+    Seg fcar = Seg{1u, 0u}, bcar = Seg{1u, 0u}, ftot = Seg{1u, 0u};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wv) fcar = comb_f(fcar, sh.wf[w]);
+        ftot = comb_f(ftot, sh.wf[w]);
+    }
+#pragma unroll
+    for (int w = 3; w >= 0; --w)
+        if (w > wv) bcar = comb_b(sh.wb[w], bcar);
+    const Seg fex = comb_f(fcar, fe);     // run ending just before this thread (inside the tile)
+    const Seg bex = comb_b(be, bcar);     // run starting just after this thread (inside the tile)
+
+    // ---- tile-level: run entering from the previous tile (look-back #1) and halo -----------------------
+    if (wv == 0) {
+        const bool tile_cont = ftot.f != 0;                 // the whole tile is one run that continues
+        const bool need_R = __shfl((int)eq0, 0, 64) != 0;   // first byte equals the byte before the tile
+        u64 R = 0;
+        if (tid == 0) {
+            if (tile_cont) desc_store(drun + k, DESC_AGG, (u64)ftot.v | (1ull << RUN_C_BIT));
+            else desc_store(drun + k, DESC_PREFIX, (u64)ftot.v);
+        }
+        if (need_R && k > 0) R = lookback_run(drun, k, blk.err);
+        if (tid == 0) {
+            if (tile_cont) desc_store(drun + k, DESC_PREFIX, R + ftot.v);
+            sh.R = (u32)(R % 255u);
+        }
+    } else if (wv == 1) {
+        u32 H = 0;
+        if (tile_end < n && tile_end == tile_start + RLE_TILE) {
+            const u32 lastb = (u32)blk.in[tile_end - 1];
+            const u64 q = tile_end + (u64)lane * 4;
+            u32 cnt = 0;
+            bool go = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32 c = (q + j < n) ? (u32)blk.in[q + j] : 0x400u;
+                go &= (c == lastb);
+                cnt += go ? 1u : 0u;
+            }
+            const u64 full = __ballot(cnt == 4);
+            const int l0 = (~full) ? (__ffsll((unsigned long long)~full) - 1) : 64;
+            const u32 c0 = (l0 < 64) ? (u32)__shfl((int)cnt, l0, 64) : 0u;
+            H = (u32)l0 * 4 + c0;
+            if (H > 255) H = 255;
+        }
+        if (lane == 0) sh.H = H;
+    }
+    __syncthreads();
+
+    // ---- per-element r, e, emit size ----------------------------------------------------------------------
+    const u32 cin = fex.v + (fex.f ? sh.R : 0u);          // run length (mod-255-safe) before this thread
+    const u32 aout = bex.v + (bex.f ? sh.H : 0u);         // run length after this thread
+    u32 r[16], e[16];
+    r[0] = eq0 ? (cin % 255u) : 0u;
+#pragma unroll
+    for (int j = 1; j < 16; ++j) {
+        const u32 nx = (r[j - 1] + 1 == 255u) ? 0u : r[j - 1] + 1;
+        r[j] = (x[j] == x[j - 1]) ? nx : 0u;
+    }
+    e[15] = 1 + (eq15 ? aout : 0u);
+#pragma unroll
+    for (int j = 14; j >= 0; --j) e[j] = (x[j] == x[j + 1]) ? e[j + 1] + 1 : 1u;
+    u32 emit[16];
+    u32 tot = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const u32 ee = e[j] > 255u ? 255u : e[j];
+        e[j] = ee;
+        u32 m;
+        if (r[j] == 0) m = (x[j] == 0 || ee >= 4) ? 3u : 1u;
+        else m = (x[j] != 0 && r[j] + ee < 4) ? 1u : 0u;
+        if (j >= nvalid) m = 0;
+        emit[j] = m;
+        tot += m;
+    }
+
+    // ---- output offsets: workgroup scan + look-back #2 ------------------------------------------------------
+    const u32 incl = wave_incl_scan_add<u32>(tot);
+    if (lane == 63) sh.wsum[wv] = incl;
+    __syncthreads();
+    u32 run = 0, off = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w == wv) off = run + incl - tot;
+        run += sh.wsum[w];
+    }
+    const u32 T = run;
+    if (wv == 0) {
+        u64 G = 0;
+        if (k > 0) {
+            if (tid == 0) desc_store(dsum + k, DESC_AGG, T);
+            G = lookback_sum(dsum, k, blk.err);
+        }
+        if (tid == 0) {
+            desc_store(dsum + k, DESC_PREFIX, G + T);
+            sh.G = G;
+        }
+    }
+    __syncthreads();
+    const u64 G = sh.G;
+    const u32 shift = (u32)G & 3;
+
+    // ---- tokens into LDS (byte offset keeps the global 4-byte phase), then aligned word stores -----------
+    u8 *st8 = (u8 *)sh.stage;
+    u32 o = shift + off;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (emit[j] == 3) {
+            st8[o] = 0; st8[o + 1] = (u8)x[j]; st8[o + 2] = (u8)e[j];
+            o += 3;
+        } else if (emit[j] == 1) {
+            st8[o] = (u8)x[j];
+            o += 1;
+        }
+    }
+    __syncthreads();
+    const u64 end_b = G + T;
+    if (end_b > blk.out_cap) {
+        if (tid == 0) set_error(blk.err, SHAFA_LACK_OF_MEMORY);
+    } else {
+        const u32 nwords = (shift + T + 3) >> 2;
+        const u64 gw0 = G >> 2;
+        for (u32 w = tid; w < nwords; w += RLE_THREADS) {
+            const u32 val = sh.stage[w];
+            const u64 byte0 = (gw0 + w) * 4;
+            if (byte0 >= G && byte0 + 4 <= end_b) {
+                ((u32 *)blk.out)[gw0 + w] = val;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (byte0 + q >= G && byte0 + q < end_b) blk.out[byte0 + q] = (u8)(val >> (8 * q));
+            }
+        }
+    }
+    if (k == (int)blk.n_tiles - 1 && tid == 0) *blk.out_n = end_b;
+}
+
+}  // namespace
+
+int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
+                  const u64 *h_in_n, u8 *d_out, const u64 *h_out_off, const u64 *h_out_cap, u64 *d_out_n,
+                  u64 *d_freq)
+{
+    if (nblocks <= 0) return SHAFA_SUCCESS;
+    if (nblocks > bt->max_blocks) return SHAFA_LACK_OF_MEMORY;
+    u64 ndesc = 0;
+    u32 max_tiles = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        if ((h_in_off[b] & 15) || (h_out_off[b] & 15)) return SHAFA_OUTSIDE_MODULE;
+        const u64 t = ceil_div_u64(h_in_n[b], RLE_TILE);
+        ndesc += t;
+        if (t > max_tiles) max_tiles = (u32)t;
+    }
+    // workspace: [desc_run][desc_sum][tickets] (zeroed) [RleBlk]
+    size_t off = 0;
+    const size_t o_run = off; off += ndesc * 8;
+    const size_t o_sum = off; off += ndesc * 8;
+    const size_t o_tick = off; off += (size_t)nblocks * 4; off = (off + 15) & ~(size_t)15;
+    const size_t o_zero_end = off;
+    const size_t o_blk = off; off += (size_t)nblocks * sizeof(RleBlk);
+    int rc = batch_reserve(bt, off);
+    if (rc) return rc;
+    u8 *ws = (u8 *)bt->d_ws;
+    RleBlk *hb = (RleBlk *)batch_stage(bt, st, (size_t)nblocks * sizeof(RleBlk));
+    if (!hb) return SHAFA_LACK_OF_MEMORY;
+    u32 dbase = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        RleBlk &e = hb[b];
+        e.in = d_in + h_in_off[b];
+        e.out = d_out + h_out_off[b];
+        e.n = h_in_n[b];
+        e.out_cap = h_out_cap[b];
+        e.out_n = d_out_n + b;
+        e.err = bt->d_err + b;
+        e.desc_base = dbase;
+        e.n_tiles = (u32)ceil_div_u64(h_in_n[b], RLE_TILE);
+        e.ticket = (u32)b;
+        e.pad = 0;
+        dbase += e.n_tiles;
+    }
+    HIP_TRY(hipMemsetAsync(ws, 0, o_zero_end, st));
+    HIP_TRY(hipMemsetAsync(d_out_n, 0, (size_t)nblocks * 8, st));      // empty blocks: size 0
+    HIP_TRY(hipMemcpyAsync(ws + o_blk, hb, (size_t)nblocks * sizeof(RleBlk), hipMemcpyHostToDevice, st));
+    if (max_tiles) {
+        hipLaunchKernelGGL(rle_encode_kernel, dim3(max_tiles * (u32)nblocks), dim3(RLE_THREADS), 0, st,
+                           (const RleBlk *)(ws + o_blk), nblocks, (u64 *)(ws + o_run), (u64 *)(ws + o_sum),
+                           (u32 *)(ws + o_tick));
+        HIP_TRY(hipGetLastError());
+    }
+    if (d_freq) {   // make_freq of the RLE bytes (f.c:310): sizes are on the device
+        rc = hist_launch_dev(bt, st, nblocks, d_out, h_out_off, h_out_cap, d_out_n, d_freq);
+        if (rc) return rc;
+    }
+    return SHAFA_SUCCESS;
+}

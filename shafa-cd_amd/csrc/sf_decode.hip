@@ -1,3 +1,513 @@
+// sf_decode.hip — Module D hot path: Shannon-Fano (prefix-code) decode on gfx950.
+//
+// Replaces create_tree + shafa_block_decompressor (reference d.c:466-551): a bit-serial tree walk
+// that stops after block_size symbols.  The .shaf format has no sync markers, so decoding a 64 MiB
+// block in parallel needs the codeword boundaries first.  They are found EXACTLY (no speculation):
+//
+//   next(p) = p + len(code that starts at bit p)     for every bit position p of the stream
+//
+// is a function graph; the true boundaries are the path from bit 0.  The stream is cut into 256-bit
+// chunks (one per lane, 256 chunks = one 8 KiB tile).  For a chunk starting at bit s the "entry" is
+// d = (first boundary >= s) - s, always < Lmax (max code length).  A backward dynamic programme over
+// the chunk's 256 bit positions gives exit(p) = entry of the NEXT chunk when p is a boundary, i.e.
+// the chunk's transition map T: entry -> next entry, for all Lmax entries at once, at a cost that does
+// not depend on Lmax or on how well the code self-synchronises (near-fixed-length codes of uniform
+// data never do).  Maps are then chased: lanes -> waves -> tiles -> block, which yields every chunk's
+// true entry; each chunk decodes its own symbols from there (count pass, scan, write pass).
+//
+//   sfd_sync    : DP per chunk, chunk maps + tile maps            (reads the stream once)
+//   sfd_tiles   : per block, chase the tile maps -> tile entries
+//   sfd_count   : chunk entries from the chunk maps, decode + count symbols per chunk
+//   sfd_offsets : per block, exclusive scan of tile counts -> output offsets (and "too short" check)
+//   sfd_write   : decode again and store the symbols
+//
+// Codes longer than the 11-bit LUT fall back to a bit-serial trie walk (any length up to 255).
+// Algorithmic HBM bytes per block: sf_n read + n_symbols written.
 #include "common.hpp"
 #include "internal.hpp"
-int sfdec_launch(Batch *, hipStream_t, int, const u8 *, const u64 *, const u64 *, const shafa_code_table *, const u64 *, u8 *, const u64 *) { return SHAFA_OUTSIDE_MODULE; }
+
+namespace {
+
+constexpr int DEC_THREADS = 256;
+constexpr int CH_BYTES = 32;                       // chunk = 256 bits per lane
+constexpr int CH_BITS = CH_BYTES * 8;
+constexpr int DTILE = DEC_THREADS * CH_BYTES;      // 8 KiB of stream per tile
+constexpr int HALO_WORDS = 16;                     // 64 bytes past the tile (windows + trie walks)
+constexpr int DATA_WORDS = DTILE / 4 + HALO_WORDS;
+constexpr int LUT_MAXK = 11;
+
+struct DecBlk {
+    const u8 *in;
+    u8 *out;
+    u64 in_n;
+    u64 n_sym;
+    int *err;
+    const u16 *lut;        // 2^K entries: sym | len << 8 ; 0 = longer than K bits (or no such code)
+    const u32 *trie;       // pairs {child0, child1}: 0x80000000|sym = leaf, 0xFFFFFFFF = missing
+    u32 K;
+    u32 lmax;
+    u32 tile_base;         // first tile of this block in the per-tile arrays
+    u32 n_tiles;
+};
+
+// stream words are kept big-endian in LDS, one pad word per 8 (chunk stride 9 words: no bank conflicts)
+__device__ __forceinline__ u32 widx(u32 w) { return w + (w >> 3); }
+
+struct Code { u32 len; u32 sym; bool ok; };
+
+// length (and symbol) of the code that starts at tile-local bit position p
+__device__ __forceinline__ Code code_at(const u32 *data, const u16 *lut, const u32 *trie, u32 K, u32 p)
+{
+    const u32 w = p >> 5, r = p & 31;
+    const u64 two = ((u64)data[widx(w)] << 32) | data[widx(w + 1)];
+    const u32 win = (u32)((two << r) >> 32);
+    const u32 e = lut[win >> (32 - K)];
+    Code c;
+    if (e) { c.len = e >> 8; c.sym = e & 0xFF; c.ok = true; return c; }
+    // slow path: walk the trie bit by bit (codes longer than K bits, or an incomplete tree)
+    u32 node = 0, q = p, depth = 0;
+    for (;;) {
+        const u32 bit = (data[widx(q >> 5)] >> (31 - (q & 31))) & 1u;
+        const u32 nx = trie[2 * node + bit];
+        ++q; ++depth;
+        if (nx == 0xFFFFFFFFu) { c.len = 1; c.sym = 0; c.ok = false; return c; }
+        if (nx & 0x80000000u) { c.len = depth; c.sym = nx & 0xFF; c.ok = true; return c; }
+        node = nx;
+        if (depth >= 255) { c.len = 1; c.sym = 0; c.ok = false; return c; }
+    }
+}
+
+// stage one tile (+halo) of the stream into LDS as big-endian words; bytes past in_n read as zero
+__device__ __forceinline__ void load_tile(u32 *data, const DecBlk &blk, u32 tile)
+{
+    const u64 base = (u64)tile * DTILE;
+    for (u32 i = threadIdx.x; i < DATA_WORDS / 4; i += DEC_THREADS) {
+        const u64 off = base + (u64)i * 16;
+        u32 w[4] = {0, 0, 0, 0};
+        if (off + 16 <= blk.in_n) {
+            const uint4 v = *(const uint4 *)(blk.in + off);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else if (off < blk.in_n) {
+            const int nv = (int)(blk.in_n - off);
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q < nv) w[q >> 2] |= (u32)blk.in[off + q] << (8 * (q & 3));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) data[widx(4 * i + q)] = bswap32(w[q]);
+    }
+}
+
+__device__ __forceinline__ void load_lut(u16 *lut, const DecBlk &blk)
+{
+    const u32 n32 = (1u << blk.K) / 2;            // K >= 1
+    for (u32 i = threadIdx.x; i < (n32 ? n32 : 1); i += DEC_THREADS)
+        ((u32 *)lut)[i] = ((const u32 *)blk.lut)[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// sfd_sync: chunk maps (global, [tile][d][chunk]) and tile maps ([tile][d])
+// dynamic LDS: data[DATA_WORDS*9/8+8] u32 | ring[R*256] u8 | lut[2^K] u16 | wfn[4*R] u8
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DEC_THREADS) void sfd_sync(const DecBlk *__restrict__ blks, u32 R,
+                                                        u8 *__restrict__ chunkfn, u8 *__restrict__ tilefn)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const DecBlk blk = blks[blockIdx.y];
+    const u32 tile = blockIdx.x;
+    if (tile >= blk.n_tiles) return;
+    u32 *data = (u32 *)smem;
+    u8 *ring = smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
+    u16 *lut = (u16 *)(ring + (size_t)R * DEC_THREADS);
+    u8 *wfn = (u8 *)(lut + (1u << LUT_MAXK));
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 lmax = blk.lmax, K = blk.K, Rm = R - 1;
+
+    load_tile(data, blk, tile);
+    load_lut(lut, blk);
+    __syncthreads();
+
+    // backward DP over the chunk's bit positions: ring[(p mod R)][tid] = exit(p)
+    const u32 cbase = tid * CH_BITS;
+    for (int p = CH_BITS - 1; p >= 0; --p) {
+        const Code c = code_at(data, lut, blk.trie, K, cbase + (u32)p);
+        const u32 nx = (u32)p + c.len;
+        u32 x;
+        if (nx >= (u32)CH_BITS) x = nx - CH_BITS;
+        else x = ring[((nx & Rm) << 8) + tid];
+        ring[(((u32)p & Rm) << 8) + tid] = (u8)x;
+    }
+    __syncthreads();
+
+    // chunk maps to global: rows d < lmax, 256 bytes each (coalesced)
+    u8 *cf = chunkfn + ((size_t)(blk.tile_base + tile) * R << 8);
+    for (u32 i = tid; i < lmax * (DEC_THREADS / 4); i += DEC_THREADS)
+        ((u32 *)cf)[i] = ((const u32 *)ring)[i];
+
+    // wave maps: lane d chases entry d through the wave's 64 chunks (d < lmax, in groups of 64)
+    for (u32 d0 = 0; d0 < lmax; d0 += 64) {
+        const u32 d = d0 + lane;
+        u32 v = d < lmax ? d : 0;
+        for (u32 c = 0; c < 64; ++c) v = ring[(v << 8) + wv * 64 + c];
+        if (d < lmax) wfn[wv * R + d] = (u8)v;
+    }
+    __syncthreads();
+    // tile map = wave 0 then 1, 2, 3
+    u8 *tf = tilefn + (size_t)(blk.tile_base + tile) * R;
+    for (u32 d = tid; d < lmax; d += DEC_THREADS) {
+        u32 v = d;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v = wfn[w * R + v];
+        tf[d] = (u8)v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sfd_tiles: per block, chase the tile maps from entry 0 -> entry of every tile
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DEC_THREADS) void sfd_tiles(const DecBlk *__restrict__ blks, u32 R,
+                                                         const u8 *__restrict__ tilefn, u8 *__restrict__ tile_entry)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];   // 256 * R bytes of maps + 256 entries
+    const DecBlk blk = blks[blockIdx.x];
+    u8 *maps = smem;
+    u8 *ent = smem + (size_t)R * DEC_THREADS;
+    const u32 tid = threadIdx.x;
+    u32 v = 0;                                   // carried by thread 0
+    for (u32 t0 = 0; t0 < blk.n_tiles; t0 += DEC_THREADS) {
+        const u32 nt = (blk.n_tiles - t0 < (u32)DEC_THREADS) ? blk.n_tiles - t0 : (u32)DEC_THREADS;
+        const u8 *src = tilefn + (size_t)(blk.tile_base + t0) * R;
+        for (u32 i = tid; i < nt * R / 4; i += DEC_THREADS) ((u32 *)maps)[i] = ((const u32 *)src)[i];
+        __syncthreads();
+        if (tid == 0) {
+            for (u32 t = 0; t < nt; ++t) { ent[t] = (u8)v; v = maps[t * R + v]; }
+        }
+        __syncthreads();
+        if (tid < nt) tile_entry[blk.tile_base + t0 + tid] = ent[tid];
+        __syncthreads();
+    }
+}
+
+// decode the chunk's own symbols starting at bit `entry`; Sink(sym, ok) per symbol.  Returns the count.
+// Only codes that end inside the stream (tile-local bit `limit`) are symbols: zero padding past the
+// last byte must not be counted, or a truncated stream would go unnoticed.
+template <typename Sink>
+__device__ __forceinline__ u32 decode_chunk(const u32 *data, const u16 *lut, const DecBlk &blk, u32 cbase,
+                                            u32 entry, u32 limit, Sink sink)
+{
+    u32 p = entry, cnt = 0;
+    while (p < (u32)CH_BITS) {
+        const Code c = code_at(data, lut, blk.trie, blk.K, cbase + p);
+        if (cbase + p + c.len > limit) break;
+        sink(c.sym, c.ok);
+        p += c.len;
+        ++cnt;
+    }
+    return cnt;
+}
+
+// tile-local bit index of the end of the stream (clamped to the staged window)
+__device__ __forceinline__ u32 tile_bit_limit(const DecBlk &blk, u32 tile)
+{
+    const u64 start = (u64)tile * DTILE;
+    const u64 left = blk.in_n > start ? blk.in_n - start : 0;
+    const u64 cap = (u64)DTILE + HALO_WORDS * 4;
+    return (u32)((left < cap ? left : cap) * 8);
+}
+
+// ------------------------------------------------------------------------------------------------
+// sfd_count: chunk entries (from the chunk maps) + symbols per chunk and per tile
+// dynamic LDS: data | maps[R*256] | lut | went[4] wfn[4*R] | ent[256]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DEC_THREADS) void sfd_count(const DecBlk *__restrict__ blks, u32 R,
+                                                         const u8 *__restrict__ chunkfn,
+                                                         const u8 *__restrict__ tile_entry,
+                                                         u8 *__restrict__ chunk_entry, u16 *__restrict__ chunk_cnt,
+                                                         u32 *__restrict__ tile_cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const DecBlk blk = blks[blockIdx.y];
+    const u32 tile = blockIdx.x;
+    if (tile >= blk.n_tiles) return;
+    u32 *data = (u32 *)smem;
+    u8 *maps = smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
+    u16 *lut = (u16 *)(maps + (size_t)R * DEC_THREADS);
+    u8 *wfn = (u8 *)(lut + (1u << LUT_MAXK));
+    u8 *ent = wfn + 4 * R;
+    u32 *wsum = (u32 *)(ent + DEC_THREADS);
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 lmax = blk.lmax;
+    const size_t gt = (size_t)blk.tile_base + tile;
+
+    load_tile(data, blk, tile);
+    load_lut(lut, blk);
+    const u8 *cf = chunkfn + (gt * R << 8);
+    for (u32 i = tid; i < lmax * (DEC_THREADS / 4); i += DEC_THREADS) ((u32 *)maps)[i] = ((const u32 *)cf)[i];
+    __syncthreads();
+
+    // wave maps (as in sfd_sync), then wave entries from the tile entry, then every chunk's entry
+    for (u32 d0 = 0; d0 < lmax; d0 += 64) {
+        const u32 d = d0 + lane;
+        u32 v = d < lmax ? d : 0;
+        for (u32 c = 0; c < 64; ++c) v = maps[(v << 8) + wv * 64 + c];
+        if (d < lmax) wfn[wv * R + d] = (u8)v;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        u32 v = tile_entry[gt];
+        for (u32 w = 0; w < wv; ++w) v = wfn[w * R + v];
+        for (u32 c = 0; c < 64; ++c) {
+            ent[wv * 64 + c] = (u8)v;
+            v = maps[(v << 8) + wv * 64 + c];
+        }
+    }
+    __syncthreads();
+
+    const u32 entry = ent[tid];
+    const u32 cnt = decode_chunk(data, lut, blk, tid * CH_BITS, entry, tile_bit_limit(blk, tile), [](u32, bool) {});
+    chunk_entry[gt * DEC_THREADS + tid] = (u8)entry;
+    chunk_cnt[gt * DEC_THREADS + tid] = (u16)cnt;
+    const u32 tot = wave_reduce_add<u32>(cnt);
+    if (lane == 0) wsum[wv] = tot;
+    __syncthreads();
+    if (tid == 0) tile_cnt[gt] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// sfd_offsets: per block, exclusive scan of the tile counts; stream too short => error
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DEC_THREADS) void sfd_offsets(const DecBlk *__restrict__ blks,
+                                                           const u32 *__restrict__ tile_cnt, u64 *__restrict__ tile_off)
+{
+    __shared__ u64 wtot[4];
+    __shared__ u64 carry;
+    const DecBlk blk = blks[blockIdx.x];
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (u32 t0 = 0; t0 < blk.n_tiles; t0 += DEC_THREADS) {
+        const u32 t = t0 + tid;
+        const u64 c = t < blk.n_tiles ? (u64)tile_cnt[blk.tile_base + t] : 0ull;
+        const u64 incl = wave_incl_scan_add<u64>(c);
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        u64 base = carry;
+        for (u32 w = 0; w < wv; ++w) base += wtot[w];
+        if (t < blk.n_tiles) tile_off[blk.tile_base + t] = base + incl - c;
+        __syncthreads();
+        if (tid == 0) carry += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+    }
+    if (tid == 0 && carry < blk.n_sym) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);   // ran out of bits
+}
+
+// ------------------------------------------------------------------------------------------------
+// sfd_write: decode every chunk from its entry and store the symbols (index < n_sym only)
+// dynamic LDS: data | lut | wsum
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(DEC_THREADS) void sfd_write(const DecBlk *__restrict__ blks,
+                                                         const u8 *__restrict__ chunk_entry,
+                                                         const u16 *__restrict__ chunk_cnt,
+                                                         const u64 *__restrict__ tile_off)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const DecBlk blk = blks[blockIdx.y];
+    const u32 tile = blockIdx.x;
+    if (tile >= blk.n_tiles) return;
+    u32 *data = (u32 *)smem;
+    u16 *lut = (u16 *)(smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4);
+    u32 *wsum = (u32 *)(lut + (1u << LUT_MAXK));
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t gt = (size_t)blk.tile_base + tile;
+    const u64 toff = tile_off[gt];
+    if (toff >= blk.n_sym) return;                      // the whole tile is padding / past the end
+
+    load_tile(data, blk, tile);
+    load_lut(lut, blk);
+    const u32 entry = chunk_entry[gt * DEC_THREADS + tid];
+    const u32 cnt = chunk_cnt[gt * DEC_THREADS + tid];
+    const u32 incl = wave_incl_scan_add<u32>(cnt);
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    u32 base = 0;
+    for (u32 w = 0; w < wv; ++w) base += wsum[w];
+    const u64 first = toff + base + incl - cnt;         // global index of this chunk's first symbol
+
+    u64 gi = first;
+    u32 acc = 0;
+    bool bad = false;
+    const u64 nsym = blk.n_sym;
+    u8 *out = blk.out;
+    decode_chunk(data, lut, blk, tid * CH_BITS, entry, tile_bit_limit(blk, tile), [&](u32 sym, bool ok) {
+        if (gi < nsym) {
+            if (!ok) bad = true;
+            acc |= sym << (8 * ((u32)gi & 3));
+            ++gi;
+            if (((u32)gi & 3) == 0) {                   // a 4-byte group is complete
+                if (gi - 4 >= first) *(u32 *)(out + gi - 4) = acc;
+                else for (u64 q = first; q < gi; ++q) out[q] = (u8)(acc >> (8 * ((u32)q & 3)));
+                acc = 0;
+            }
+        }
+    });
+    if ((u32)gi & 3) {                                  // trailing partial group
+        const u64 g0 = gi & ~3ull;
+        for (u64 q = (g0 > first ? g0 : first); q < gi; ++q) out[q] = (u8)(acc >> (8 * ((u32)q & 3)));
+    }
+    if (bad) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host: validate the table (prefix-free), build LUT + trie, launch the five kernels
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct HostTab {
+    std::vector<u32> trie;     // pairs
+    std::vector<u16> lut;
+    u32 K, lmax;
+    bool ok, empty;
+};
+
+void build_host_tab(const shafa_code_table &t, HostTab &h)
+{
+    h.trie.assign(2, 0xFFFFFFFFu);
+    h.ok = true;
+    h.lmax = 0;
+    for (int s = 0; s < 256; ++s) h.lmax = t.len[s] > h.lmax ? t.len[s] : h.lmax;
+    h.empty = h.lmax == 0;
+    h.K = h.lmax < (u32)LUT_MAXK ? (h.lmax ? h.lmax : 1) : (u32)LUT_MAXK;
+    h.lut.assign((size_t)1 << h.K, 0);
+    for (int s = 0; s < 256 && h.ok; ++s) {
+        const u32 L = t.len[s];
+        if (!L) continue;
+        u32 node = 0;
+        for (u32 q = 0; q < L; ++q) {
+            const u32 bit = (t.bits[s][q >> 3] >> (7 - (q & 7))) & 1u;
+            u32 &slot = h.trie[2 * node + bit];
+            if (q == L - 1) {
+                if (slot != 0xFFFFFFFFu) { h.ok = false; break; }          // duplicate / prefix of another
+                slot = 0x80000000u | (u32)s;
+            } else {
+                if (slot == 0xFFFFFFFFu) {
+                    slot = (u32)(h.trie.size() / 2);
+                    h.trie.push_back(0xFFFFFFFFu);
+                    h.trie.push_back(0xFFFFFFFFu);
+                } else if (slot & 0x80000000u) { h.ok = false; break; }     // passes through a leaf
+                node = h.trie[2 * node + bit];
+            }
+        }
+        if (h.ok && L <= h.K) {
+            u32 code = 0;
+            for (u32 q = 0; q < L; ++q) code = (code << 1) | ((t.bits[s][q >> 3] >> (7 - (q & 7))) & 1u);
+            const u32 lo = code << (h.K - L), cnt = 1u << (h.K - L);
+            for (u32 i = 0; i < cnt; ++i) h.lut[lo + i] = (u16)(s | (L << 8));
+        }
+    }
+}
+}  // namespace
+
+int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
+                 const u64 *h_in_n, const shafa_code_table *h_tables, const u64 *h_n_symbols, u8 *d_out,
+                 const u64 *h_out_off)
+{
+    if (nblocks <= 0) return SHAFA_SUCCESS;
+    if (nblocks > bt->max_blocks) return SHAFA_LACK_OF_MEMORY;
+
+    std::vector<HostTab> tabs(nblocks);
+    u32 lmax_all = 1, max_tiles = 0;
+    u64 total_tiles = 0;
+    size_t tab_bytes = 0;
+    std::vector<u32> ntiles(nblocks, 0);
+    for (int b = 0; b < nblocks; ++b) {
+        if ((h_in_off[b] & 15) || (h_out_off[b] & 15)) return SHAFA_OUTSIDE_MODULE;
+        build_host_tab(h_tables[b], tabs[b]);
+        HostTab &h = tabs[b];
+        bool run = h_n_symbols[b] > 0;
+        if (run && (!h.ok || h.empty)) {          // malformed table, or single-symbol block
+            bt->h_hosterr[b] = SHAFA_FILE_UNRECOGNIZABLE;
+            run = false;
+        }
+        if (run && h_in_n[b] == 0) { bt->h_hosterr[b] = SHAFA_FILE_UNRECOGNIZABLE; run = false; }
+        if (!run) continue;
+        ntiles[b] = (u32)ceil_div_u64(h_in_n[b], DTILE);
+        total_tiles += ntiles[b];
+        if (ntiles[b] > max_tiles) max_tiles = ntiles[b];
+        if (h.lmax > lmax_all) lmax_all = h.lmax;
+        tab_bytes += ((h.lut.size() * 2 + 15) & ~(size_t)15) + ((h.trie.size() * 4 + 15) & ~(size_t)15);
+    }
+    if (!total_tiles) return SHAFA_SUCCESS;
+    u32 R = 16;
+    while (R < lmax_all) R <<= 1;
+
+    // workspace layout
+    size_t off = 0;
+    const size_t o_blk = off; off += ((size_t)nblocks * sizeof(DecBlk) + 15) & ~(size_t)15;
+    const size_t o_tab = off; off += tab_bytes;
+    const size_t stage_bytes = off;
+    const size_t o_tilefn = off; off += (size_t)total_tiles * R; off = (off + 15) & ~(size_t)15;
+    const size_t o_tent = off; off += (size_t)total_tiles; off = (off + 15) & ~(size_t)15;
+    const size_t o_tcnt = off; off += (size_t)total_tiles * 4; off = (off + 15) & ~(size_t)15;
+    const size_t o_toff = off; off += (size_t)total_tiles * 8;
+    const size_t o_cent = off; off += (size_t)total_tiles * DEC_THREADS; off = (off + 15) & ~(size_t)15;
+    const size_t o_ccnt = off; off += (size_t)total_tiles * DEC_THREADS * 2; off = (off + 15) & ~(size_t)15;
+    const size_t o_cfn = off; off += (size_t)total_tiles * R * DEC_THREADS;
+    int rc = batch_reserve(bt, off);
+    if (rc) return rc;
+    u8 *ws = (u8 *)bt->d_ws;
+
+    u8 *hs = (u8 *)batch_stage(bt, st, stage_bytes);
+    if (!hs) return SHAFA_LACK_OF_MEMORY;
+    DecBlk *hb = (DecBlk *)hs;
+    size_t tpos = o_tab;
+    u32 tbase = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        DecBlk &e = hb[b];
+        memset(&e, 0, sizeof(e));
+        e.in = d_in + h_in_off[b];
+        e.out = d_out + h_out_off[b];
+        e.in_n = h_in_n[b];
+        e.n_sym = h_n_symbols[b];
+        e.err = bt->d_err + b;
+        e.n_tiles = ntiles[b];
+        e.tile_base = tbase;
+        tbase += ntiles[b];
+        if (!ntiles[b]) continue;
+        HostTab &h = tabs[b];
+        e.K = h.K;
+        e.lmax = h.lmax;
+        e.lut = (const u16 *)(ws + tpos);
+        memcpy(hs + tpos, h.lut.data(), h.lut.size() * 2);
+        tpos += (h.lut.size() * 2 + 15) & ~(size_t)15;
+        e.trie = (const u32 *)(ws + tpos);
+        memcpy(hs + tpos, h.trie.data(), h.trie.size() * 4);
+        tpos += (h.trie.size() * 4 + 15) & ~(size_t)15;
+    }
+    HIP_TRY(hipMemcpyAsync(ws, hs, stage_bytes, hipMemcpyHostToDevice, st));
+
+    const DecBlk *dblk = (const DecBlk *)(ws + o_blk);
+    const size_t lds_data = (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
+    const size_t lds_lut = (size_t)(1u << LUT_MAXK) * 2;
+    const size_t lds_sync = lds_data + (size_t)R * DEC_THREADS + lds_lut + 4 * R + 64;
+    const size_t lds_count = lds_data + (size_t)R * DEC_THREADS + lds_lut + 4 * R + DEC_THREADS + 64;
+    const size_t lds_write = lds_data + lds_lut + 64;
+    const size_t lds_tiles = (size_t)R * DEC_THREADS + DEC_THREADS;
+    if (lds_tiles > 65536 || lds_sync > 65536) {     // long codes (R = 256): more than the default 64 KiB
+        HIP_TRY(hipFuncSetAttribute((const void *)sfd_sync, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sync));
+        HIP_TRY(hipFuncSetAttribute((const void *)sfd_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count));
+        HIP_TRY(hipFuncSetAttribute((const void *)sfd_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tiles));
+    }
+    const dim3 grid_t(max_tiles, (u32)nblocks), grid_b((u32)nblocks);
+    hipLaunchKernelGGL(sfd_sync, grid_t, dim3(DEC_THREADS), lds_sync, st, dblk, R, ws + o_cfn, ws + o_tilefn);
+    hipLaunchKernelGGL(sfd_tiles, grid_b, dim3(DEC_THREADS), lds_tiles, st, dblk, R, (const u8 *)(ws + o_tilefn),
+                       ws + o_tent);
+    hipLaunchKernelGGL(sfd_count, grid_t, dim3(DEC_THREADS), lds_count, st, dblk, R, (const u8 *)(ws + o_cfn),
+                       (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt), (u32 *)(ws + o_tcnt));
+    hipLaunchKernelGGL(sfd_offsets, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u32 *)(ws + o_tcnt),
+                       (u64 *)(ws + o_toff));
+    hipLaunchKernelGGL(sfd_write, grid_t, dim3(DEC_THREADS), lds_write, st, dblk, (const u8 *)(ws + o_cent),
+                       (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff));
+    HIP_TRY(hipGetLastError());
+    return SHAFA_SUCCESS;
+}

@@ -25,42 +25,6 @@ namespace {
 constexpr int ENC_THREADS = 256;
 constexpr int ENC_STAGE_WORDS = 5120;   // LDS bit-stream window per round (20 KiB)
 
-// ------------------------------------------------------------------------------------------------
-// look-back over one block's tile descriptors; wave 0 only, all 64 lanes.  Returns the exclusive
-// prefix (sum of the aggregates of tiles 0..k-1).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 lookback_sum(const u64 *desc, int k, int *err)
-{
-    const int lane = lane_id();
-    u64 excl = 0;
-    int j = k - 1;
-    for (;;) {
-        const int idx = j - lane;
-        u64 d = 0;
-        u32 spins = 0;
-        for (;;) {
-            d = (idx >= 0) ? desc_load(desc + idx) : (DESC_PREFIX << 62);
-            if (__all((d >> 62) != DESC_EMPTY)) break;
-            if (++spins > SPIN_LIMIT) {          // lost predecessor: flag instead of hanging
-                if (lane == 0) set_error(err, SHAFA_DEVICE_ERROR);
-                if ((d >> 62) == DESC_EMPTY) d = (DESC_PREFIX << 62);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        const u64 val = d & DESC_VALUE_MASK;
-        const u64 pmask = __ballot((d >> 62) == DESC_PREFIX);
-        if (pmask) {
-            const int pl = __ffsll((unsigned long long)pmask) - 1;
-            excl += wave_reduce_add<u64>(lane <= pl ? val : 0ull);
-            break;
-        }
-        excl += wave_reduce_add<u64>(val);
-        j -= 64;
-    }
-    return excl;
-}
-
 // OR an L-bit group (right-aligned in g, 1 <= L <= 64) into the LDS bit-stream at tile-local bit q.
 // stage points at local word `wlo`; words outside [wlo, wlo+wcount) are skipped (other rounds).
 __device__ __forceinline__ void emit_group(u32 *stage, u32 wlo, u32 wcount, u64 g, u32 L, u32 q)

@@ -13,6 +13,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_first():
+    """Load torch's HIP runtime before libshafa_hip.so pulls in the system one: with the opposite
+    order torch cannot see the GPU in this process (two copies of libamdhip64)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import oracle_lib

@@ -1,0 +1,239 @@
+"""GPU parity tests, part 2: RLE encode/decode (Module F/D) and Shannon-Fano decode (Module D),
+through the C-ABI, bit-exact against the oracle and the reference-generated golden files."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from oracle_lib import parse_blocks_text, parse_shaf
+from test_gpu_parity import first_diff, long_code_case, rd, streams, to_shafa_table
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1, 2, 3, 15, 16, 17, 255, 256, 257, 4095, 4096, 4097, 8191, 12288, 65536, 262144 + 5, 1048576 + 77]
+
+
+def rle_inputs(oracle, shafa):
+    import golden.make_golden as mg
+    zt = shafa.zipf_table(1.2)
+    s = streams(oracle, shafa)
+    cases = {"edges": mg.edge_stream()}
+    for n in SIZES:
+        cases[f"runs_{n}"] = mg.runs_stream(31 + n, n, zt)
+        cases[f"uniform_{n}"] = s["uniform"](n)
+        cases[f"two_{n}"] = s["two"](n)
+    for n in [1, 254, 255, 256, 4096, 4097, 8192 + 3, 255 * 40, 300000, 1 << 20]:
+        cases[f"zeros_{n}"] = np.zeros(n, dtype=np.uint8)          # one giant run of the escaped byte
+        cases[f"same_{n}"] = np.full(n, 0x5A, dtype=np.uint8)      # one giant run of a plain byte
+    # runs that start/stop exactly at tile edges, and a 0/1 alternation (max expansion)
+    a = np.full(3 * 4096, 7, dtype=np.uint8)
+    a[4096:8192] = 9
+    cases["tile_aligned_runs"] = a
+    alt = np.zeros(20000, dtype=np.uint8)
+    alt[1::2] = 1
+    cases["alternating_zero"] = alt
+    b = np.full(9000, 3, dtype=np.uint8)
+    b[4095] = 4
+    b[4096 + 254] = 4
+    cases["run_cut_near_tile_edge"] = b
+    return cases
+
+
+# ----------------------------------------------------------------------------- K2 rle_encode
+def test_rle_encode_matches_oracle(oracle, shafa):
+    bad = []
+    for name, data in rle_inputs(oracle, shafa).items():
+        want = oracle.rle_encode(data)
+        got, freq = shafa.rle_encode(data, want_freq=True)
+        if got.tobytes() != want.tobytes():
+            bad.append(f"{name}: {first_diff(got, want)}")
+        elif not (freq == oracle.hist256(want)).all():
+            bad.append(f"{name}: fused histogram differs")
+    assert not bad, "\n".join(bad[:12])
+
+
+@pytest.mark.parametrize("case,fn", [("runs_default", "x"), ("edges_forced_rle", "e"), ("uniform_forced_both", "v"),
+                                     ("runs_force_freq", "w"), ("tiny_1024", "a")])
+def test_rle_encode_matches_reference_files(shafa, case, fn):
+    data, ref = rd(case, fn), rd(case, fn + ".rle")
+    _, fblocks = parse_blocks_text(rd(case, fn + ".rle.freq"))
+    pos = 0
+    for i, (size, ftext) in enumerate(fblocks):
+        blk = data[i * 65536:(i + 1) * 65536]
+        got, freq = shafa.rle_encode(blk, want_freq=True)
+        assert got.size == size and got.tobytes() == ref[pos:pos + size], f"{case} block {i}: {first_diff(got, ref[pos:pos + size])}"
+        assert shafa.freq_format(freq) == ftext
+        pos += size
+
+
+# ----------------------------------------------------------------------------- K5 rle_decode
+def test_rle_decode_matches_oracle(oracle, shafa):
+    bad = []
+    for name, data in rle_inputs(oracle, shafa).items():
+        rle = oracle.rle_encode(data)
+        got = shafa.rle_decode(rle)
+        if got.tobytes() != np.asarray(data).tobytes():
+            bad.append(f"{name}: {first_diff(got, data)}")
+    assert not bad, "\n".join(bad[:12])
+
+
+def test_rle_decode_hand_made_streams(oracle, shafa):
+    cases = {
+        "count0_is_literal": bytes([0, 65, 0, 66, 0, 67, 3]),
+        "zero_sym": bytes([0, 0, 5, 1, 0, 0, 1]),
+        "triples_only": bytes([0, 0, 255] * 5000),               # non-zero bytes never adjacent: chained maps
+        "zero_count_zero_sym": bytes([0, 0, 0] * 3000 + [7]),
+        "mixed": bytes(([0, 9, 200] + [1, 2, 3] + [0, 0, 1]) * 3000),
+    }
+    for name, raw in cases.items():
+        rc, want = oracle.rle_decode(raw)
+        assert rc == 0
+        got = shafa.rle_decode(raw)
+        assert got.tobytes() == want.tobytes(), f"{name}: {first_diff(got, want)}"
+    # a triple cut by the block end is refused (the reference over-reads there)
+    for raw in (bytes([65, 0, 66]), bytes([65, 0]), bytes([1] * 5000 + [0, 3])):
+        rc, _ = shafa.rle_decode(raw, raw_rc=True)
+        assert rc == shafa.FILE_UNRECOGNIZABLE
+    # output limit 64 MiB + 1 KiB (d.c:165-168) and caller capacity
+    n_tr = (shafa.RLE_DECODE_MAX // 255) + 1
+    big = np.tile(np.array([0, 1, 255], dtype=np.uint8), n_tr)
+    rc, _ = shafa.rle_decode(big, cap=shafa.RLE_DECODE_MAX, raw_rc=True)
+    assert rc == shafa.FILE_UNRECOGNIZABLE
+    rc, _ = shafa.rle_decode(bytes([0, 1, 255] * 100), cap=1000, raw_rc=True)
+    assert rc == shafa.LACK_OF_MEMORY
+    rc, out = shafa.rle_decode(b"", raw_rc=True)
+    assert rc == 0 and out.size == 0
+
+
+# ----------------------------------------------------------------------------- K4 sf_decode
+def decode_roundtrip(oracle, shafa, data, otab):
+    rc, enc = oracle.sf_encode(data, otab)
+    assert rc == 0
+    got = shafa.sf_decode(enc, to_shafa_table(shafa, otab), len(data))
+    return got, enc
+
+
+@pytest.mark.parametrize("kind", ["uniform", "zipf", "two"])
+def test_sf_decode_matches_oracle_sizes(oracle, shafa, kind):
+    gen = streams(oracle, shafa)[kind]
+    bad = []
+    for n in SIZES:
+        if n < 2:
+            continue
+        data = gen(n)
+        otab = oracle.sf_build(oracle.hist256(data))
+        if otab.lens().max() == 0:
+            continue
+        got, enc = decode_roundtrip(oracle, shafa, data, otab)
+        if got.tobytes() != data.tobytes():
+            bad.append(f"{kind} n={n} enc={enc.size}: {first_diff(got, data)}")
+    assert not bad, "\n".join(bad[:12])
+
+
+def test_sf_decode_long_codes(oracle, shafa):
+    import golden.make_golden as mg
+    data = mg.textlike_stream(5, 200000)                      # lengths up to 16: LUT + trie
+    otab = oracle.sf_build(oracle.hist256(data))
+    got, _ = decode_roundtrip(oracle, shafa, data, otab)
+    assert got.tobytes() == data.tobytes(), first_diff(got, data)
+    for nsyms, n in ((30, 150000), (60, 50000)):              # up to 29 / 52 bits: trie path, R = 32 / 64
+        otab, data = long_code_case(oracle, n, nsyms, 0.5, 21)
+        got, _ = decode_roundtrip(oracle, shafa, data, otab)
+        assert got.tobytes() == data.tobytes(), f"nsyms={nsyms} lmax={otab.lens().max()}: {first_diff(got, data)}"
+
+
+def test_sf_decode_ignores_padding_and_trailing_bytes(oracle, shafa):
+    data = streams(oracle, shafa)["zipf"](50001)
+    otab = oracle.sf_build(oracle.hist256(data))
+    rc, enc = oracle.sf_encode(data, otab)
+    tab = to_shafa_table(shafa, otab)
+    padded = np.concatenate([enc, np.zeros(100, dtype=np.uint8)])
+    assert shafa.sf_decode(padded, tab, data.size).tobytes() == data.tobytes()
+    assert shafa.sf_decode(enc, tab, 1234).tobytes() == data[:1234].tobytes()    # stop on symbol count
+
+
+def test_sf_decode_error_semantics(oracle, shafa):
+    f = np.zeros(256, dtype=np.uint64)
+    f[7] = 100
+    tab = to_shafa_table(shafa, oracle.sf_build(f))                 # single symbol: all codes empty
+    rc, _ = shafa.sf_decode(b"", tab, 100, raw_rc=True)
+    assert rc == shafa.FILE_UNRECOGNIZABLE
+    rc, out = shafa.sf_decode(b"", tab, 0, raw_rc=True)
+    assert rc == 0
+    bad = shafa.CodeTable.from_strings(["0", "01"] + [""] * 254)     # not prefix-free
+    rc, _ = shafa.sf_decode(bytes(10), bad, 5, raw_rc=True)
+    assert rc == shafa.FILE_UNRECOGNIZABLE
+    inc = shafa.CodeTable.from_strings(["00", "01", "10"] + [""] * 253)   # incomplete tree: '11' missing
+    rc, out = shafa.sf_decode(bytes([0b00011000]), inc, 4, raw_rc=True)
+    assert rc == 0 and out.tolist() == [0, 1, 2, 0]
+    rc, _ = shafa.sf_decode(bytes([0b00110000]), inc, 3, raw_rc=True)
+    assert rc == shafa.FILE_UNRECOGNIZABLE
+    data = streams(oracle, shafa)["uniform"](5000)
+    otab = oracle.sf_build(oracle.hist256(data))
+    rc, enc = oracle.sf_encode(data, otab)
+    rc, _ = shafa.sf_decode(enc[:2000], to_shafa_table(shafa, otab), 5000, raw_rc=True)   # stream too short
+    assert rc == shafa.FILE_UNRECOGNIZABLE
+
+
+@pytest.mark.parametrize("case,stem", [("runs_default", "x.rle"), ("edges_forced_rle", "e.rle"),
+                                       ("uniform_no_rle", "u"), ("textlike_m", "t"), ("tiny_1024", "a.rle")])
+def test_sf_decode_matches_reference_files(shafa, case, stem):
+    """HIP decode of the reference's .shaf payloads with its .cod == the file the reference encoded."""
+    data = rd(case, stem)
+    _, cblocks = parse_blocks_text(rd(case, stem + ".cod"))
+    payloads = parse_shaf(rd(case, stem + ".shaf"))
+    pos = 0
+    for i, ((size, ctext), payload) in enumerate(zip(cblocks, payloads)):
+        rc, tab = shafa.cod_parse(ctext)
+        got = shafa.sf_decode(payload, tab, size)
+        assert got.tobytes() == data[pos:pos + size], f"{case} block {i}: {first_diff(got, data[pos:pos + size])}"
+        pos += size
+
+
+def test_full_pipeline_roundtrip_batch(oracle, shafa):
+    """F -> T -> C -> D on device-resident blocks in single launches (the shape bench.py uses)."""
+    import torch
+    import golden.make_golden as mg
+    dev = torch.device("cuda:0")
+    zt = shafa.zipf_table(1.2)
+    nb, bs = 5, 1 << 20
+    host = np.concatenate([mg.runs_stream(100 + b, bs, zt) for b in range(nb)])
+    host[3 * bs:4 * bs] = 0x33                                       # one block that is a single run
+    d_in = torch.from_numpy(host).to(dev)
+    st = torch.cuda.Stream()
+    bt = shafa.Batch(nb, 2 * bs + 16)
+    off = [b * bs for b in range(nb)]
+    rcap = 2 * bs + 16
+    roff = [b * rcap for b in range(nb)]
+    d_rle = torch.empty(nb * rcap, dtype=torch.uint8, device=dev)
+    d_rn = torch.zeros(nb, dtype=torch.int64, device=dev)
+    d_freq = torch.zeros(nb * 256, dtype=torch.int64, device=dev)
+    bt.rle_encode(st, d_in, off, [bs] * nb, d_rle, roff, [rcap] * nb, d_rn, d_freq)
+    bt.finish(st, nb)
+    rn = d_rn.cpu().numpy().astype(np.int64)
+    freq = d_freq.cpu().numpy().astype(np.uint64).reshape(nb, 256)
+    rle_host = d_rle.cpu().numpy()
+    for b in range(nb):
+        want = oracle.rle_encode(host[b * bs:(b + 1) * bs])
+        got = rle_host[roff[b]:roff[b] + rn[b]]
+        assert got.tobytes() == want.tobytes(), f"rle block {b}: {first_diff(got, want)}"
+        assert (freq[b] == oracle.hist256(want)).all()
+    tables = [shafa.sf_build_codes(freq[b]) for b in range(nb)]
+    d_sf = torch.empty(nb * rcap, dtype=torch.uint8, device=dev)
+    d_sn = torch.zeros(nb, dtype=torch.int64, device=dev)
+    bt.sf_encode(st, d_rle, roff, rn, tables, d_sf, roff, [rcap] * nb, d_sn)
+    bt.finish(st, nb)
+    sn = d_sn.cpu().numpy().astype(np.int64)
+    d_back = torch.empty(nb * rcap, dtype=torch.uint8, device=dev)
+    bt.sf_decode(st, d_sf, roff, sn, tables, rn, d_back, roff)
+    bt.finish(st, nb)
+    back = d_back.cpu().numpy()
+    for b in range(nb):
+        assert back[roff[b]:roff[b] + rn[b]].tobytes() == rle_host[roff[b]:roff[b] + rn[b]].tobytes(), f"sf roundtrip block {b}"
+    d_orig = torch.empty(nb * bs, dtype=torch.uint8, device=dev)
+    d_on = torch.zeros(nb, dtype=torch.int64, device=dev)
+    bt.rle_decode(st, d_back, roff, rn, d_orig, off, [bs] * nb, d_on)
+    bt.finish(st, nb)
+    assert (d_on.cpu().numpy() == bs).all()
+    assert torch.equal(d_orig, d_in), "D(C(T(F(x)))) != x"

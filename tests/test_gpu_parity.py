@@ -82,38 +82,43 @@ def test_sf_encode_matches_oracle_sizes(oracle, shafa, kind):
         assert got.tobytes() == want.tobytes(), f"{kind} n={n} lmax={otab.lens().max()}: {first_diff(got, want)}"
 
 
-def test_sf_encode_long_codes_and_generic(oracle, shafa):
-    import golden.make_golden as mg
-    # G=2 path: code lengths 17..32
-    data = mg.textlike_stream(5, 200000)
-    got, want, otab = encode_case(oracle, shafa, data)
-    assert 16 < otab.lens().max() <= 32, otab.lens().max()
-    assert got.tobytes() == want.tobytes(), first_diff(got, want)
-    # generic path: Fibonacci histogram gives codes longer than 32 bits
+def long_code_case(oracle, n, nsyms, ratio, seed):
+    """Histogram with geometrically decaying counts -> deep Shannon-Fano tree; data uses every symbol."""
     freq = np.zeros(256, dtype=np.uint64)
-    a, b = 1, 1
-    for i in range(60):
-        freq[(i * 7) % 256] = a
-        a, b = b, a + b
+    for i in range(nsyms):
+        freq[(i * 7) % 256] = max(1, int(2.0 ** 50 * ratio ** i))
     otab = oracle.sf_build(freq)
-    assert otab.lens().max() > 32
-    syms = np.nonzero(freq)[0].astype(np.uint8)
-    data = syms[oracle.gen_bytes(9, 50000) % syms.size]
+    syms = np.array([(i * 7) % 256 for i in range(nsyms)], dtype=np.uint8)
+    # mostly frequent symbols, rare ones sprinkled in
+    r = oracle.gen_bytes(seed, n).astype(np.int64)
+    idx = np.minimum((r * r * nsyms) // (255 * 255 + 1), nsyms - 1)
+    data = syms[idx]
+    data[:nsyms] = syms
+    return otab, data
+
+
+def test_sf_encode_long_codes_and_generic(oracle, shafa):
+    # G=2 path: code lengths 17..32
+    otab, data = long_code_case(oracle, 200000, 30, 0.5, 9)
+    assert 16 < otab.lens().max() <= 32, otab.lens().max()
     rc, want = oracle.sf_encode(data, otab)
-    assert rc == 0
     got = shafa.sf_encode(data, to_shafa_table(shafa, otab))
-    assert got.tobytes() == want.tobytes(), first_diff(got, want)
+    assert rc == 0 and got.tobytes() == want.tobytes(), first_diff(got, want)
+    # generic path: codes longer than 32 bits
+    otab, data = long_code_case(oracle, 50000, 60, 0.5, 10)
+    assert otab.lens().max() > 32, otab.lens().max()
+    rc, want = oracle.sf_encode(data, otab)
+    got = shafa.sf_encode(data, to_shafa_table(shafa, otab))
+    assert rc == 0 and got.tobytes() == want.tobytes(), first_diff(got, want)
 
 
 def test_sf_encode_expanding_tile_multi_round(oracle, shafa):
-    """Only rare symbols (16-bit codes): a 16 KiB tile expands to 32 KiB, more than one LDS window."""
-    freq = np.ones(256, dtype=np.uint64)
-    freq[0] = 1 << 40
-    freq[1] = 1 << 39
-    otab = oracle.sf_build(freq)
+    """Only rare symbols (12..16-bit codes): a 16 KiB tile expands to > 24 KiB, more than one LDS window."""
+    otab, _ = long_code_case(oracle, 1000, 17, 0.5, 3)
     lens = otab.lens()
-    rare = np.nonzero(lens >= 14)[0].astype(np.uint8)
-    assert rare.size > 8 and lens.max() <= 16
+    assert lens.max() == 16
+    rare = np.nonzero(lens >= 12)[0].astype(np.uint8)
+    assert rare.size >= 4
     data = rare[oracle.gen_bytes(4, 70000) % rare.size]
     rc, want = oracle.sf_encode(data, otab)
     got = shafa.sf_encode(data, to_shafa_table(shafa, otab))
