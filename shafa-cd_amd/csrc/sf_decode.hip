@@ -35,6 +35,8 @@ constexpr int DTILE = DEC_THREADS * CH_BYTES;      // 8 KiB of stream per tile
 constexpr int HALO_WORDS = 16;                     // 64 bytes past the tile (windows + trie walks)
 constexpr int DATA_WORDS = DTILE / 4 + HALO_WORDS;
 constexpr int LUT_MAXK = 11;
+constexpr int LUT2_MAX = 4096;                     // level-2 entries kept in LDS (8 KiB)
+constexpr int LEN_MAXK = 13;                       // length-only LUT of the packed DP: 8 KiB
 
 struct DecBlk {
     const u8 *in;
@@ -42,12 +44,17 @@ struct DecBlk {
     u64 in_n;
     u64 n_sym;
     int *err;
-    const u16 *lut;        // 2^K entries: sym | len << 8 ; 0 = longer than K bits (or no such code)
+    const u16 *lut;        // level 1, 2^K entries: sym | len << 8 ; 0x8000 | (nb-1) << 12 | base = level-2
+                           //   group (next nb bits index lut2[base..]) ; 0 = go to the trie
+    const u16 *lut2;       // level 2 (codes of K+1 .. K+8 bits): sym | len << 8 ; 0 = go to the trie
+    const u8 *lenlut;      // 2^K1 entries: len only (DP of the packed path); 0 = longer than K1 bits
     const u32 *trie;       // pairs {child0, child1}: 0x80000000|sym = leaf, 0xFFFFFFFF = missing
     u32 K;
+    u32 K1;
     u32 lmax;
     u32 tile_base;         // first tile of this block in the per-tile arrays
     u32 n_tiles;
+    u32 n_l2;              // level-2 entries
 };
 
 // stream words are kept big-endian in LDS, one pad word per 8 (chunk stride 9 words: no bank conflicts)
@@ -61,8 +68,12 @@ __device__ __forceinline__ Code code_at(const u32 *data, const u16 *lut, const u
     const u32 w = p >> 5, r = p & 31;
     const u64 two = ((u64)data[widx(w)] << 32) | data[widx(w + 1)];
     const u32 win = (u32)((two << r) >> 32);
-    const u32 e = lut[win >> (32 - K)];
+    u32 e = lut[win >> (32 - K)];
     Code c;
+    if (e & 0x8000u) {                              // codes of K+1..K+8 bits: one more table
+        const u32 nb = ((e >> 12) & 7u) + 1;
+        e = lut[(1u << LUT_MAXK) + (e & 0xFFFu) + ((win << K) >> (32 - nb))];
+    }
     if (e) { c.len = e >> 8; c.sym = e & 0xFF; c.ok = true; return c; }
     // slow path: walk the trie bit by bit (codes longer than K bits, or an incomplete tree)
     u32 node = 0, q = p, depth = 0;
@@ -103,13 +114,15 @@ __device__ __forceinline__ void load_lut(u16 *lut, const DecBlk &blk)
     const u32 n32 = (1u << blk.K) / 2;            // K >= 1
     for (u32 i = threadIdx.x; i < (n32 ? n32 : 1); i += DEC_THREADS)
         ((u32 *)lut)[i] = ((const u32 *)blk.lut)[i];
+    u32 *l2 = (u32 *)(lut + (1u << LUT_MAXK));
+    for (u32 i = threadIdx.x; i < (blk.n_l2 + 1) / 2; i += DEC_THREADS) l2[i] = ((const u32 *)blk.lut2)[i];
 }
 
 // ------------------------------------------------------------------------------------------------
 // sfd_sync: chunk maps (global, [tile][d][chunk]) and tile maps ([tile][d])
 // dynamic LDS: data[DATA_WORDS*9/8+8] u32 | ring[R*256] u8 | lut[2^K] u16 | wfn[4*R] u8
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(DEC_THREADS) void sfd_sync(const DecBlk *__restrict__ blks, u32 R,
+__global__ __launch_bounds__(DEC_THREADS) void sfd_sync(const DecBlk *__restrict__ blks, u32 R, u32 l2cap,
                                                         u8 *__restrict__ chunkfn, u8 *__restrict__ tilefn)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
@@ -119,7 +132,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_sync(const DecBlk *__restrict
     u32 *data = (u32 *)smem;
     u8 *ring = smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
     u16 *lut = (u16 *)(ring + (size_t)R * DEC_THREADS);
-    u8 *wfn = (u8 *)(lut + (1u << LUT_MAXK));
+    u8 *wfn = (u8 *)(lut + (1u << LUT_MAXK) + l2cap);
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 lmax = blk.lmax, K = blk.K, Rm = R - 1;
 
@@ -188,6 +201,117 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tiles(const DecBlk *__restric
     }
 }
 
+// ================================================================================================
+// Packed path (every block of the launch has Lmax <= 16): a chunk map is 16 nibbles in one u64,
+// the DP ring lives in registers, code lengths come from a byte LUT of up to 13 index bits.
+// ================================================================================================
+
+// code length at tile-local bit p by trie walk (codes longer than the LUT index, or missing branch: 1)
+__device__ __noinline__ u32 slow_len(const u32 *data, const u32 *trie, u32 p)
+{
+    u32 node = 0, q = p, depth = 0;
+    for (;;) {
+        const u32 bit = (data[widx(q >> 5)] >> (31 - (q & 31))) & 1u;
+        const u32 nx = trie[2 * node + bit];
+        ++q; ++depth;
+        if (nx == 0xFFFFFFFFu) return 1;
+        if (nx & 0x80000000u) return depth;
+        node = nx;
+        if (depth >= 255) return 1;
+    }
+}
+
+__device__ __forceinline__ u32 nib(u64 m, u32 v) { return (u32)(m >> (4 * v)) & 15u; }
+
+// sfd_sync16: dynamic LDS: data | lenlut[2^13] u8 | cmap[256] u64 | wmap[4] u64
+__global__ __launch_bounds__(DEC_THREADS) void sfd_sync16(const DecBlk *__restrict__ blks,
+                                                          u64 *__restrict__ chunkfn, u64 *__restrict__ tilefn)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const DecBlk blk = blks[blockIdx.y];
+    const u32 tile = blockIdx.x;
+    if (tile >= blk.n_tiles) return;
+    u32 *data = (u32 *)smem;
+    u8 *lenlut = smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
+    u64 *cmap = (u64 *)(lenlut + (1u << LEN_MAXK));
+    u64 *wmap = cmap + DEC_THREADS;
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 K1 = blk.K1;
+
+    load_tile(data, blk, tile);
+    for (u32 i = tid; i < (1u << K1) / 4 + 1; i += DEC_THREADS)
+        if (i < ((1u << K1) + 3) / 4) ((u32 *)lenlut)[i] = ((const u32 *)blk.lenlut)[i];
+    __syncthreads();
+
+    // backward DP; nibble j of `ring` = exit(p + 1 + j).  Positions 256..271 (the next chunk's first
+    // bits) have exit = their offset, which is the initial ring.
+    u64 ring = 0xFEDCBA9876543210ull;
+    const u32 cw = tid * (CH_BITS / 32);
+    const u32 sh = 32 - K1;
+    u32 w1 = data[widx(cw + 8)];
+    for (int wi = 7; wi >= 0; --wi) {
+        const u32 w0 = data[widx(cw + wi)];
+        u32 len[32];
+#pragma unroll
+        for (int r = 31; r >= 0; --r) {
+            const u32 win = r ? __builtin_amdgcn_alignbit(w0, w1, 32 - r) : w0;
+            len[r] = lenlut[win >> sh];
+        }
+#pragma unroll
+        for (int r = 31; r >= 0; --r) {
+            u32 l = len[r];
+            if (__builtin_expect(l == 0, 0)) l = slow_len(data, blk.trie, (cw + wi) * 32 + r);
+            const u32 x = nib(ring, l - 1);
+            ring = (ring << 4) | x;
+        }
+        w1 = w0;
+    }
+    // ring nibble d = exit(d) = this chunk's map
+    chunkfn[((size_t)blk.tile_base + tile) * DEC_THREADS + tid] = ring;
+    cmap[tid] = ring;
+    __syncthreads();
+    // wave map: lane d (< 16) chases entry d through the wave's 64 chunks
+    if (lane < 16) {
+        u32 v = lane;
+        for (u32 c = 0; c < 64; ++c) v = nib(cmap[wv * 64 + c], v);
+        u64 m = (u64)v << (4 * lane);
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) m |= __shfl_xor(m, d, 64);
+        if (lane == 0) wmap[wv] = m;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        u32 v = tid;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v = nib(wmap[w], v);
+        u64 m = (u64)v << (4 * tid);
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) m |= __shfl_xor(m, d, 64);
+        if (tid == 0) tilefn[(size_t)blk.tile_base + tile] = m;
+    }
+}
+
+// sfd_tiles16: per block, chase the packed tile maps
+__global__ __launch_bounds__(DEC_THREADS) void sfd_tiles16(const DecBlk *__restrict__ blks,
+                                                           const u64 *__restrict__ tilefn, u8 *__restrict__ tile_entry)
+{
+    __shared__ u64 maps[DEC_THREADS];
+    __shared__ u8 ent[DEC_THREADS];
+    const DecBlk blk = blks[blockIdx.x];
+    const u32 tid = threadIdx.x;
+    u32 v = 0;
+    for (u32 t0 = 0; t0 < blk.n_tiles; t0 += DEC_THREADS) {
+        const u32 nt = (blk.n_tiles - t0 < (u32)DEC_THREADS) ? blk.n_tiles - t0 : (u32)DEC_THREADS;
+        if (tid < nt) maps[tid] = tilefn[(size_t)blk.tile_base + t0 + tid];
+        __syncthreads();
+        if (tid == 0)
+            for (u32 t = 0; t < nt; ++t) { ent[t] = (u8)v; v = nib(maps[t], v); }
+        __syncthreads();
+        if (tid < nt) tile_entry[blk.tile_base + t0 + tid] = ent[tid];
+        __syncthreads();
+    }
+}
+
 // decode the chunk's own symbols starting at bit `entry`; Sink(sym, ok) per symbol.  Returns the count.
 // Only codes that end inside the stream (tile-local bit `limit`) are symbols: zero padding past the
 // last byte must not be counted, or a truncated stream would go unnoticed.
@@ -219,7 +343,8 @@ __device__ __forceinline__ u32 tile_bit_limit(const DecBlk &blk, u32 tile)
 // sfd_count: chunk entries (from the chunk maps) + symbols per chunk and per tile
 // dynamic LDS: data | maps[R*256] | lut | went[4] wfn[4*R] | ent[256]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(DEC_THREADS) void sfd_count(const DecBlk *__restrict__ blks, u32 R,
+template <bool PACKED>
+__global__ __launch_bounds__(DEC_THREADS) void sfd_count(const DecBlk *__restrict__ blks, u32 R, u32 l2cap,
                                                          const u8 *__restrict__ chunkfn,
                                                          const u8 *__restrict__ tile_entry,
                                                          u8 *__restrict__ chunk_entry, u16 *__restrict__ chunk_cnt,
@@ -230,10 +355,10 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_count(const DecBlk *__restric
     const u32 tile = blockIdx.x;
     if (tile >= blk.n_tiles) return;
     u32 *data = (u32 *)smem;
-    u8 *maps = smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
-    u16 *lut = (u16 *)(maps + (size_t)R * DEC_THREADS);
-    u8 *wfn = (u8 *)(lut + (1u << LUT_MAXK));
-    u8 *ent = wfn + 4 * R;
+    u8 *maps = smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4;      // PACKED: 256 u64, else R*256 u8
+    u16 *lut = (u16 *)(maps + (PACKED ? (size_t)DEC_THREADS * 8 : (size_t)R * DEC_THREADS));
+    u8 *wfn = (u8 *)(lut + (1u << LUT_MAXK) + l2cap);                      // PACKED: 4 u64
+    u8 *ent = wfn + (PACKED ? 32 : 4 * R);
     u32 *wsum = (u32 *)(ent + DEC_THREADS);
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 lmax = blk.lmax;
@@ -241,24 +366,50 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_count(const DecBlk *__restric
 
     load_tile(data, blk, tile);
     load_lut(lut, blk);
-    const u8 *cf = chunkfn + (gt * R << 8);
-    for (u32 i = tid; i < lmax * (DEC_THREADS / 4); i += DEC_THREADS) ((u32 *)maps)[i] = ((const u32 *)cf)[i];
+    if (PACKED) {
+        ((u64 *)maps)[tid] = ((const u64 *)chunkfn)[gt * DEC_THREADS + tid];
+    } else {
+        const u8 *cf = chunkfn + (gt * R << 8);
+        for (u32 i = tid; i < lmax * (DEC_THREADS / 4); i += DEC_THREADS) ((u32 *)maps)[i] = ((const u32 *)cf)[i];
+    }
     __syncthreads();
 
     // wave maps (as in sfd_sync), then wave entries from the tile entry, then every chunk's entry
-    for (u32 d0 = 0; d0 < lmax; d0 += 64) {
-        const u32 d = d0 + lane;
-        u32 v = d < lmax ? d : 0;
-        for (u32 c = 0; c < 64; ++c) v = maps[(v << 8) + wv * 64 + c];
-        if (d < lmax) wfn[wv * R + d] = (u8)v;
-    }
-    __syncthreads();
-    if (lane == 0) {
-        u32 v = tile_entry[gt];
-        for (u32 w = 0; w < wv; ++w) v = wfn[w * R + v];
-        for (u32 c = 0; c < 64; ++c) {
-            ent[wv * 64 + c] = (u8)v;
-            v = maps[(v << 8) + wv * 64 + c];
+    if (PACKED) {
+        const u64 *cm = (const u64 *)maps;
+        u64 *wm = (u64 *)wfn;
+        if (lane < 16) {
+            u32 v = lane;
+            for (u32 c = 0; c < 64; ++c) v = nib(cm[wv * 64 + c], v);
+            u64 m = (u64)v << (4 * lane);
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) m |= __shfl_xor(m, d, 64);
+            if (lane == 0) wm[wv] = m;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            u32 v = tile_entry[gt];
+            for (u32 w = 0; w < wv; ++w) v = nib(wm[w], v);
+            for (u32 c = 0; c < 64; ++c) {
+                ent[wv * 64 + c] = (u8)v;
+                v = nib(cm[wv * 64 + c], v);
+            }
+        }
+    } else {
+        for (u32 d0 = 0; d0 < lmax; d0 += 64) {
+            const u32 d = d0 + lane;
+            u32 v = d < lmax ? d : 0;
+            for (u32 c = 0; c < 64; ++c) v = maps[(v << 8) + wv * 64 + c];
+            if (d < lmax) wfn[wv * R + d] = (u8)v;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            u32 v = tile_entry[gt];
+            for (u32 w = 0; w < wv; ++w) v = wfn[w * R + v];
+            for (u32 c = 0; c < 64; ++c) {
+                ent[wv * 64 + c] = (u8)v;
+                v = maps[(v << 8) + wv * 64 + c];
+            }
         }
     }
     __syncthreads();
@@ -305,7 +456,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_offsets(const DecBlk *__restr
 // sfd_write: decode every chunk from its entry and store the symbols (index < n_sym only)
 // dynamic LDS: data | lut | wsum
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(DEC_THREADS) void sfd_write(const DecBlk *__restrict__ blks,
+__global__ __launch_bounds__(DEC_THREADS) void sfd_write(const DecBlk *__restrict__ blks, u32 l2cap,
                                                          const u8 *__restrict__ chunk_entry,
                                                          const u16 *__restrict__ chunk_cnt,
                                                          const u64 *__restrict__ tile_off)
@@ -316,7 +467,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_write(const DecBlk *__restric
     if (tile >= blk.n_tiles) return;
     u32 *data = (u32 *)smem;
     u16 *lut = (u16 *)(smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4);
-    u32 *wsum = (u32 *)(lut + (1u << LUT_MAXK));
+    u32 *wsum = (u32 *)(lut + (1u << LUT_MAXK) + l2cap);
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t gt = (size_t)blk.tile_base + tile;
     const u64 toff = tile_off[gt];
@@ -365,8 +516,9 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_write(const DecBlk *__restric
 namespace {
 struct HostTab {
     std::vector<u32> trie;     // pairs
-    std::vector<u16> lut;
-    u32 K, lmax;
+    std::vector<u16> lut, lut2;
+    std::vector<u8> lenlut;
+    u32 K, K1, lmax;
     bool ok, empty;
 };
 
@@ -379,6 +531,14 @@ void build_host_tab(const shafa_code_table &t, HostTab &h)
     h.empty = h.lmax == 0;
     h.K = h.lmax < (u32)LUT_MAXK ? (h.lmax ? h.lmax : 1) : (u32)LUT_MAXK;
     h.lut.assign((size_t)1 << h.K, 0);
+    h.K1 = h.lmax < (u32)LEN_MAXK ? (h.lmax ? h.lmax : 1) : (u32)LEN_MAXK;
+    h.lenlut.assign(((size_t)1 << h.K1) + 4, 0);
+    auto code_of = [&](int s) {
+        u64 code = 0;       // only the first 32 bits are ever needed here
+        const u32 L = t.len[s] < 32 ? t.len[s] : 32;
+        for (u32 q = 0; q < L; ++q) code = (code << 1) | ((t.bits[s][q >> 3] >> (7 - (q & 7))) & 1u);
+        return (u32)code;   // first min(len,32) bits, right-aligned
+    };
     for (int s = 0; s < 256 && h.ok; ++s) {
         const u32 L = t.len[s];
         if (!L) continue;
@@ -399,12 +559,43 @@ void build_host_tab(const shafa_code_table &t, HostTab &h)
             }
         }
         if (h.ok && L <= h.K) {
-            u32 code = 0;
-            for (u32 q = 0; q < L; ++q) code = (code << 1) | ((t.bits[s][q >> 3] >> (7 - (q & 7))) & 1u);
+            const u32 code = code_of(s);
             const u32 lo = code << (h.K - L), cnt = 1u << (h.K - L);
             for (u32 i = 0; i < cnt; ++i) h.lut[lo + i] = (u16)(s | (L << 8));
         }
+        if (h.ok && L <= h.K1) {
+            const u32 code = code_of(s);
+            const u32 lo = code << (h.K1 - L), cnt = 1u << (h.K1 - L);
+            memset(h.lenlut.data() + lo, (int)L, cnt);
+        }
     }
+    if (!h.ok) return;
+    // level 2: group the codes of K+1..K+8 bits by their first K bits
+    for (int s = 0; s < 256; ++s) {
+        const u32 L = t.len[s];
+        if (L <= h.K || L > h.K + 8) continue;
+        const u32 pre = code_of(s) >> (L > 32 ? 32 - h.K : L - h.K);      // L <= K+8 <= 19 here
+        if (h.lut[pre]) continue;                                           // group already built
+        u32 maxl = 0;
+        for (int s2 = 0; s2 < 256; ++s2) {
+            const u32 L2 = t.len[s2];
+            if (L2 > h.K && L2 <= h.K + 8 && (code_of(s2) >> (L2 - h.K)) == pre && L2 > maxl) maxl = L2;
+        }
+        const u32 nb = maxl - h.K;
+        const u32 base = (u32)h.lut2.size();
+        if (base + (1u << nb) > (u32)LUT2_MAX) continue;                    // no room: these codes use the trie
+        h.lut2.resize(base + (1u << nb), 0);
+        for (int s2 = 0; s2 < 256; ++s2) {
+            const u32 L2 = t.len[s2];
+            if (L2 > h.K && L2 <= h.K + nb && (code_of(s2) >> (L2 - h.K)) == pre) {
+                const u32 sub = code_of(s2) & ((1u << (L2 - h.K)) - 1);
+                const u32 lo = sub << (h.K + nb - L2), cnt = 1u << (h.K + nb - L2);
+                for (u32 i = 0; i < cnt; ++i) h.lut2[base + lo + i] = (u16)(s2 | (L2 << 8));
+            }
+        }
+        h.lut[pre] = (u16)(0x8000u | ((nb - 1) << 12) | base);
+    }
+    if (h.lut2.size() & 1) h.lut2.push_back(0);
 }
 }  // namespace
 
@@ -416,7 +607,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     if (nblocks > bt->max_blocks) return SHAFA_LACK_OF_MEMORY;
 
     std::vector<HostTab> tabs(nblocks);
-    u32 lmax_all = 1, max_tiles = 0;
+    u32 lmax_all = 1, max_tiles = 0, max_l2 = 0;
     u64 total_tiles = 0;
     size_t tab_bytes = 0;
     std::vector<u32> ntiles(nblocks, 0);
@@ -435,7 +626,9 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         total_tiles += ntiles[b];
         if (ntiles[b] > max_tiles) max_tiles = ntiles[b];
         if (h.lmax > lmax_all) lmax_all = h.lmax;
-        tab_bytes += ((h.lut.size() * 2 + 15) & ~(size_t)15) + ((h.trie.size() * 4 + 15) & ~(size_t)15);
+        tab_bytes += ((h.lut.size() * 2 + 15) & ~(size_t)15) + ((h.trie.size() * 4 + 15) & ~(size_t)15) +
+                     ((h.lenlut.size() + 15) & ~(size_t)15) + ((h.lut2.size() * 2 + 16 + 15) & ~(size_t)15);
+        if (h.lut2.size() > max_l2) max_l2 = (u32)h.lut2.size();
     }
     if (!total_tiles) return SHAFA_SUCCESS;
     u32 R = 16;
@@ -446,13 +639,14 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const size_t o_blk = off; off += ((size_t)nblocks * sizeof(DecBlk) + 15) & ~(size_t)15;
     const size_t o_tab = off; off += tab_bytes;
     const size_t stage_bytes = off;
-    const size_t o_tilefn = off; off += (size_t)total_tiles * R; off = (off + 15) & ~(size_t)15;
+    const size_t o_tilefn = off; off += (size_t)total_tiles * (R < 8 ? 8 : R); off = (off + 15) & ~(size_t)15;
     const size_t o_tent = off; off += (size_t)total_tiles; off = (off + 15) & ~(size_t)15;
     const size_t o_tcnt = off; off += (size_t)total_tiles * 4; off = (off + 15) & ~(size_t)15;
     const size_t o_toff = off; off += (size_t)total_tiles * 8;
     const size_t o_cent = off; off += (size_t)total_tiles * DEC_THREADS; off = (off + 15) & ~(size_t)15;
     const size_t o_ccnt = off; off += (size_t)total_tiles * DEC_THREADS * 2; off = (off + 15) & ~(size_t)15;
-    const size_t o_cfn = off; off += (size_t)total_tiles * R * DEC_THREADS;
+    const bool packed = (R == 16);
+    const size_t o_cfn = off; off += packed ? (size_t)total_tiles * DEC_THREADS * 8 : (size_t)total_tiles * R * DEC_THREADS;
     int rc = batch_reserve(bt, off);
     if (rc) return rc;
     u8 *ws = (u8 *)bt->d_ws;
@@ -476,7 +670,15 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         if (!ntiles[b]) continue;
         HostTab &h = tabs[b];
         e.K = h.K;
+        e.K1 = h.K1;
         e.lmax = h.lmax;
+        e.lut2 = (const u16 *)(ws + tpos);
+        e.n_l2 = (u32)h.lut2.size();
+        if (h.lut2.size()) memcpy(hs + tpos, h.lut2.data(), h.lut2.size() * 2);
+        tpos += (h.lut2.size() * 2 + 16 + 15) & ~(size_t)15;
+        e.lenlut = ws + tpos;
+        memcpy(hs + tpos, h.lenlut.data(), h.lenlut.size());
+        tpos += (h.lenlut.size() + 15) & ~(size_t)15;
         e.lut = (const u16 *)(ws + tpos);
         memcpy(hs + tpos, h.lut.data(), h.lut.size() * 2);
         tpos += (h.lut.size() * 2 + 15) & ~(size_t)15;
@@ -488,25 +690,39 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
 
     const DecBlk *dblk = (const DecBlk *)(ws + o_blk);
     const size_t lds_data = (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
-    const size_t lds_lut = (size_t)(1u << LUT_MAXK) * 2;
+    const size_t lds_lut = (size_t)(1u << LUT_MAXK) * 2 + (size_t)((max_l2 + 8) & ~7u) * 2;
     const size_t lds_sync = lds_data + (size_t)R * DEC_THREADS + lds_lut + 4 * R + 64;
     const size_t lds_count = lds_data + (size_t)R * DEC_THREADS + lds_lut + 4 * R + DEC_THREADS + 64;
     const size_t lds_write = lds_data + lds_lut + 64;
     const size_t lds_tiles = (size_t)R * DEC_THREADS + DEC_THREADS;
     if (lds_tiles > 65536 || lds_sync > 65536) {     // long codes (R = 256): more than the default 64 KiB
         HIP_TRY(hipFuncSetAttribute((const void *)sfd_sync, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sync));
-        HIP_TRY(hipFuncSetAttribute((const void *)sfd_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count));
+        HIP_TRY(hipFuncSetAttribute((const void *)sfd_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count));
         HIP_TRY(hipFuncSetAttribute((const void *)sfd_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tiles));
     }
+    const u32 l2cap = (max_l2 + 8) & ~7u;             // level-2 LDS entries reserved after level 1
     const dim3 grid_t(max_tiles, (u32)nblocks), grid_b((u32)nblocks);
-    hipLaunchKernelGGL(sfd_sync, grid_t, dim3(DEC_THREADS), lds_sync, st, dblk, R, ws + o_cfn, ws + o_tilefn);
-    hipLaunchKernelGGL(sfd_tiles, grid_b, dim3(DEC_THREADS), lds_tiles, st, dblk, R, (const u8 *)(ws + o_tilefn),
-                       ws + o_tent);
-    hipLaunchKernelGGL(sfd_count, grid_t, dim3(DEC_THREADS), lds_count, st, dblk, R, (const u8 *)(ws + o_cfn),
-                       (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt), (u32 *)(ws + o_tcnt));
+    if (packed) {
+        const size_t lds_sync16 = lds_data + (1u << LEN_MAXK) + DEC_THREADS * 8 + 64;
+        const size_t lds_count16 = lds_data + DEC_THREADS * 8 + lds_lut + 32 + DEC_THREADS + 64;
+        hipLaunchKernelGGL(sfd_sync16, grid_t, dim3(DEC_THREADS), lds_sync16, st, dblk, (u64 *)(ws + o_cfn),
+                           (u64 *)(ws + o_tilefn));
+        hipLaunchKernelGGL(sfd_tiles16, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u64 *)(ws + o_tilefn),
+                           ws + o_tent);
+        hipLaunchKernelGGL(sfd_count<true>, grid_t, dim3(DEC_THREADS), lds_count16, st, dblk, R, l2cap,
+                           (const u8 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
+                           (u32 *)(ws + o_tcnt));
+    } else {
+        hipLaunchKernelGGL(sfd_sync, grid_t, dim3(DEC_THREADS), lds_sync, st, dblk, R, l2cap, ws + o_cfn, ws + o_tilefn);
+        hipLaunchKernelGGL(sfd_tiles, grid_b, dim3(DEC_THREADS), lds_tiles, st, dblk, R, (const u8 *)(ws + o_tilefn),
+                           ws + o_tent);
+        hipLaunchKernelGGL(sfd_count<false>, grid_t, dim3(DEC_THREADS), lds_count, st, dblk, R, l2cap,
+                           (const u8 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
+                           (u32 *)(ws + o_tcnt));
+    }
     hipLaunchKernelGGL(sfd_offsets, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u32 *)(ws + o_tcnt),
                        (u64 *)(ws + o_toff));
-    hipLaunchKernelGGL(sfd_write, grid_t, dim3(DEC_THREADS), lds_write, st, dblk, (const u8 *)(ws + o_cent),
+    hipLaunchKernelGGL(sfd_write, grid_t, dim3(DEC_THREADS), lds_write, st, dblk, l2cap, (const u8 *)(ws + o_cent),
                        (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff));
     HIP_TRY(hipGetLastError());
     return SHAFA_SUCCESS;
