@@ -1,0 +1,489 @@
+/*
+ * modules.c — the five module entry points of the reference (f.h:16, t.h:11, c.h:11, d.h:14,22),
+ * same names, arguments, path ownership and error numbers, with every per-block computation sent
+ * to the GPU through the C-ABI of libshafa_hip.so:
+ *
+ *     reference call site                     here
+ *     f.c:248  block_compression          ->  shafa_hip_rle_encode   (+ fused make_freq, f.c:310)
+ *     f.c:325  make_freq                  ->  shafa_hip_hist256
+ *     c.c:411  compress_to_buffer         ->  shafa_hip_sf_encode
+ *     d.c:735  process_shafa_decomp       ->  shafa_hip_sf_decode (+ shafa_hip_rle_decode)
+ *     d.c:342  rle_block_decompressor     ->  shafa_hip_rle_decode
+ *
+ * The host keeps what the reference's drivers do around those calls: block splitting, the block-0
+ * RLE decision, the '@'-framed text files, ordered writes.  There is no CPU implementation of the
+ * kernels here: without a GPU every module returns SHAFA_DEVICE_ERROR.
+ */
+#include "shafa_host.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+bool NO_MULTITHREAD = false;
+bool SHAFA_VERBOSE = true;
+
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec / 1e6;
+}
+
+/* ------------------------------------------------------------------ tiny reader for '@' framed text */
+
+typedef struct { char *buf; size_t len, pos; } text_t;
+
+static int slurp(const char *path, text_t *t)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return SHAFA_FILE_INACCESSIBLE;
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz < 0) { fclose(f); return SHAFA_FILE_STREAM_FAILED; }
+    t->buf = malloc((size_t)sz + 1);
+    if (!t->buf) { fclose(f); return SHAFA_LACK_OF_MEMORY; }
+    t->len = fread(t->buf, 1, (size_t)sz, f);
+    t->buf[t->len] = '\0';
+    t->pos = 0;
+    fclose(f);
+    return SHAFA_SUCCESS;
+}
+
+static bool eat(text_t *t, char c)
+{
+    if (t->pos < t->len && t->buf[t->pos] == c) { ++t->pos; return true; }
+    return false;
+}
+
+static bool read_u64(text_t *t, uint64_t *v)
+{
+    size_t p = t->pos;
+    uint64_t x = 0;
+    while (p < t->len && t->buf[p] >= '0' && t->buf[p] <= '9') x = x * 10 + (uint64_t)(t->buf[p++] - '0');
+    if (p == t->pos) return false;
+    *v = x;
+    t->pos = p;
+    return true;
+}
+
+/* "@<R|N>@<n>" (f.c:289,294; t.c:302) */
+static bool read_header(text_t *t, char *mode, uint64_t *n)
+{
+    if (!eat(t, '@') || t->pos >= t->len) return false;
+    *mode = t->buf[t->pos++];
+    return eat(t, '@') && read_u64(t, n);
+}
+
+/* "@<size>@<payload up to the next '@'>" : payload is NUL-terminated in place, *next = char it replaced */
+static bool read_block(text_t *t, uint64_t *size, char **payload, size_t max_payload)
+{
+    if (!eat(t, '@') || !read_u64(t, size) || !eat(t, '@')) return false;
+    size_t e = t->pos;
+    while (e < t->len && t->buf[e] != '@') ++e;
+    if (e == t->pos || e - t->pos > max_payload || e >= t->len) return false;   /* needs a following '@' */
+    *payload = t->buf + t->pos;
+    t->pos = e;
+    return true;
+}
+
+/* ------------------------------------------------------------------ Module F (f.c:180-412) */
+
+static void f_summary(uint64_t n_blocks, const uint64_t *sizes, uint64_t size_f, const uint64_t *rle_sizes,
+                      double ms, const char *p_rle, const char *p_freq, const char *p_rle_freq)
+{
+    if (!SHAFA_VERBOSE) return;
+    printf("Module: f (calculation of symbol frequencies)\nNumber of blocks: %lu\n", (unsigned long)n_blocks);
+    printf("Size of blocks analyzed in the original file: ");
+    for (uint64_t i = 0; i < n_blocks; ++i) printf(i + 1 == n_blocks ? "%lu\n" : "%lu/", (unsigned long)sizes[i]);
+    if (p_rle) {
+        uint64_t total = 0;
+        for (uint64_t i = 0; i < n_blocks; ++i) total += rle_sizes[i];
+        const float ratio = (float)((long)size_f - (long)total) / (float)size_f * 100.0f;
+        printf("RLE Compression: %s (%f%% compression)\n", p_rle, ratio);
+        printf("Size of blocks analyzed in the RLE file: ");
+        for (uint64_t i = 0; i < n_blocks; ++i)
+            printf(i + 1 == n_blocks ? "%lu bytes\n" : "%lu/", (unsigned long)rle_sizes[i]);
+    }
+    printf("Module runtime (milliseconds): %f\nGenerated files: ", ms);
+    if (p_freq && p_rle_freq) printf("%s, %s\n", p_freq, p_rle_freq);
+    else if (p_freq) printf("%s\n", p_freq);
+    else if (p_rle_freq) printf("%s\n", p_rle_freq);
+}
+
+static int put_freq_block(FILE *f, uint64_t size, const uint64_t freq[256], bool last)
+{
+    char text[SHAFA_FREQ_BLOCK_MAX + 1];
+    const size_t n = shafa_freq_format(freq, text);
+    if (fprintf(f, "@%lu@", (unsigned long)size) < 2) return SHAFA_FILE_STREAM_FAILED;
+    if (fwrite(text, 1, n, f) != n) return SHAFA_FILE_STREAM_FAILED;
+    if (last && fputs("@0", f) < 0) return SHAFA_FILE_STREAM_FAILED;          /* f.c:112-116 */
+    return SHAFA_SUCCESS;
+}
+
+_modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, unsigned long block_size)
+{
+    const double t0 = now_ms();
+    int err = SHAFA_SUCCESS;
+    FILE *in = fopen(*path, "rb");
+    if (!in) return SHAFA_FILE_INACCESSIBLE;
+    fseek(in, 0, SEEK_END);
+    const long fsz = ftell(in);
+    fseek(in, 0, SEEK_SET);
+    uint64_t bs = block_size, last = 0;
+    const uint64_t size_f = fsz > 0 ? (uint64_t)fsz : 0;
+    const uint64_t n_blocks = shafa_block_count(size_f, &bs, &last);
+    if (size_f < SHAFA_1KiB) { fclose(in); return SHAFA_FILE_TOO_SMALL; }      /* f.c:220,366 */
+
+    char *p_rle = shafa_add_ext(*path, SHAFA_RLE_EXT);
+    char *p_rle_freq = p_rle ? shafa_add_ext(p_rle, SHAFA_FREQ_EXT) : NULL;
+    char *p_freq = shafa_add_ext(*path, SHAFA_FREQ_EXT);
+    uint64_t *sizes = malloc(n_blocks * sizeof(uint64_t)), *rle_sizes = malloc(n_blocks * sizeof(uint64_t));
+    uint8_t *buf = malloc(bs), *rle = malloc(2 * bs + 3);
+    FILE *f_rle = NULL, *f_rle_freq = NULL, *f_freq = NULL;
+    bool use_rle = true;
+    if (!p_rle || !p_rle_freq || !p_freq || !sizes || !rle_sizes || !buf || !rle) err = SHAFA_LACK_OF_MEMORY;
+
+    for (uint64_t b = 0; b < n_blocks && !err; ++b) {
+        const uint64_t n = (b + 1 == n_blocks) ? last : bs;
+        sizes[b] = n;
+        if (fread(buf, 1, n, in) != n) { err = SHAFA_FILE_STREAM_FAILED; break; }
+        uint64_t freq[256];
+        size_t rle_n = 0;
+        if (use_rle) {
+            /* block_compression + make_freq of the RLE bytes, one GPU pass (f.c:248,310) */
+            err = shafa_hip_rle_encode(buf, n, rle, 2 * n + 3, &rle_n, freq);
+            if (err) break;
+            if (b == 0) use_rle = shafa_rle_worthwhile(n, rle_n, force_rle);   /* f.c:250-258 */
+        }
+        if (b == 0) {                                                           /* f.c:262-295 */
+            if (use_rle) {
+                f_rle = fopen(p_rle, "wb");
+                f_rle_freq = fopen(p_rle_freq, "wb");
+                if (!f_rle || !f_rle_freq) { err = SHAFA_FILE_INACCESSIBLE; break; }
+                if (fprintf(f_rle_freq, "@R@%lu", (unsigned long)n_blocks) < 4) { err = SHAFA_FILE_STREAM_FAILED; break; }
+            }
+            if (!use_rle || force_freq) {
+                f_freq = fopen(p_freq, "wb");
+                if (!f_freq) { err = SHAFA_FILE_INACCESSIBLE; break; }
+                if (fprintf(f_freq, "@N@%lu", (unsigned long)n_blocks) < 4) { err = SHAFA_FILE_STREAM_FAILED; break; }
+            }
+        }
+        if (use_rle) {
+            rle_sizes[b] = rle_n;
+            if (fwrite(rle, 1, rle_n, f_rle) != rle_n) { err = SHAFA_FILE_STREAM_FAILED; break; }
+            err = put_freq_block(f_rle_freq, rle_n, freq, b + 1 == n_blocks);
+            if (err) break;
+        }
+        if (!use_rle || force_freq) {
+            err = shafa_hip_hist256(buf, n, freq);                              /* make_freq, f.c:325 */
+            if (err) break;
+            err = put_freq_block(f_freq, n, freq, b + 1 == n_blocks);
+        }
+    }
+    if (f_rle) fclose(f_rle);
+    if (f_rle_freq) fclose(f_rle_freq);
+    if (f_freq) fclose(f_freq);
+    fclose(in);
+
+    if (!err) {
+        const bool wrote_freq = !use_rle || force_freq;
+        f_summary(n_blocks, sizes, size_f, rle_sizes, now_ms() - t0, use_rle ? p_rle : NULL,
+                  wrote_freq ? p_freq : NULL, use_rle ? p_rle_freq : NULL);
+        if (use_rle) {                                                           /* f.c:396-399 */
+            free(*path);
+            *path = p_rle;
+            p_rle = NULL;
+        }
+    }
+    free(p_rle); free(p_rle_freq); free(p_freq); free(sizes); free(rle_sizes); free(buf); free(rle);
+    return (_modules_error)err;
+}
+
+/* ------------------------------------------------------------------ Module T (t.c:246-445) */
+
+_modules_error get_shafa_codes(const char *path)
+{
+    const double t0 = now_ms();
+    char *p_freq = shafa_add_ext(path, SHAFA_FREQ_EXT);
+    if (!p_freq) return SHAFA_LACK_OF_MEMORY;
+    text_t t = {0};
+    int err = slurp(p_freq, &t);
+    free(p_freq);
+    if (err) return (_modules_error)err;
+
+    char mode = 0;
+    uint64_t n_blocks = 0;
+    if (!read_header(&t, &mode, &n_blocks) || (mode != 'R' && mode != 'N')) { free(t.buf); return SHAFA_FILE_UNRECOGNIZABLE; }
+    char *p_cod = shafa_add_ext(path, SHAFA_CODES_EXT);
+    uint64_t *sizes = malloc((n_blocks ? n_blocks : 1) * sizeof(uint64_t));
+    FILE *out = p_cod ? fopen(p_cod, "wb") : NULL;
+    if (!p_cod || !sizes) err = SHAFA_LACK_OF_MEMORY;
+    else if (!out) err = SHAFA_FILE_INACCESSIBLE;
+    else if (fprintf(out, "@%c@%lu", mode, (unsigned long)n_blocks) < 3) err = SHAFA_FILE_STREAM_FAILED;
+
+    char *cod = malloc(SHAFA_COD_BLOCK_MAX + 2);
+    if (!cod && !err) err = SHAFA_LACK_OF_MEMORY;
+    for (uint64_t b = 0; b < n_blocks && !err; ++b) {
+        uint64_t size = 0;
+        char *fields = NULL;
+        if (!read_block(&t, &size, &fields, SHAFA_FREQ_BLOCK_MAX)) { err = SHAFA_FILE_STREAM_FAILED; break; }
+        sizes[b] = size;
+        const char keep = t.buf[t.pos];
+        t.buf[t.pos] = '\0';
+        uint64_t freq[256];
+        err = shafa_freq_parse(fields, freq);
+        t.buf[t.pos] = keep;
+        if (err) break;
+        shafa_code_table tab;
+        shafa_sf_build_codes(freq, &tab);
+        const size_t n = shafa_cod_format(&tab, cod);
+        if (fprintf(out, "@%lu@", (unsigned long)size) < 2 || fwrite(cod, 1, n, out) != n) err = SHAFA_FILE_STREAM_FAILED;
+    }
+    if (!err && out) fputs("@0", out);                                          /* t.c:395-396 */
+    if (out) fclose(out);
+    if (!err && SHAFA_VERBOSE) {
+        printf("Module:T (Calculation of symbol codes)\nNumber of blocks: %lu\n"
+               "Size of blocks analyzed in the symbol file: ", (unsigned long)n_blocks);
+        for (uint64_t i = 0; i + 1 < n_blocks; ++i) printf("%lu/", (unsigned long)sizes[i]);
+        if (n_blocks) printf("%lu bytes\n", (unsigned long)sizes[n_blocks - 1]);
+        printf("Module runtime (milliseconds): %f\nGenerated file %s\n", now_ms() - t0, p_cod);
+    }
+    free(cod); free(sizes); free(p_cod); free(t.buf);
+    return (_modules_error)err;
+}
+
+/* ------------------------------------------------------------------ Module C (c.c:306-472) */
+
+_modules_error shafa_compress(char **path)
+{
+    const double t0 = now_ms();
+    char *p_cod = shafa_add_ext(*path, SHAFA_CODES_EXT);
+    if (!p_cod) return SHAFA_LACK_OF_MEMORY;
+    text_t t = {0};
+    int err = slurp(p_cod, &t);
+    free(p_cod);
+    if (err) return (_modules_error)err;
+    char mode = 0;
+    uint64_t n_blocks = 0;
+    if (!read_header(&t, &mode, &n_blocks)) { free(t.buf); return SHAFA_FILE_UNRECOGNIZABLE; }   /* c.c:333,447 */
+
+    FILE *in = fopen(*path, "rb");
+    if (!in) { free(t.buf); return SHAFA_FILE_INACCESSIBLE; }
+    char *p_shaf = shafa_add_ext(*path, SHAFA_SHAFA_EXT);
+    FILE *out = p_shaf ? fopen(p_shaf, "wb") : NULL;
+    uint64_t *in_sizes = malloc((n_blocks ? n_blocks : 1) * 2 * sizeof(uint64_t));
+    uint64_t *out_sizes = in_sizes ? in_sizes + n_blocks : NULL;
+    if (!p_shaf || !in_sizes) err = SHAFA_LACK_OF_MEMORY;
+    else if (!out) err = SHAFA_FILE_INACCESSIBLE;
+    else if (fprintf(out, "@%lu", (unsigned long)n_blocks) < 2) err = SHAFA_FILE_STREAM_FAILED;
+
+    uint8_t *buf = NULL, *enc = NULL;
+    size_t buf_cap = 0, enc_cap = 0;
+    for (uint64_t b = 0; b < n_blocks && !err; ++b) {
+        uint64_t size = 0;
+        char *codes = NULL;
+        if (!read_block(&t, &size, &codes, SHAFA_COD_BLOCK_MAX)) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* c.c:369 */
+        const char keep = t.buf[t.pos];
+        t.buf[t.pos] = '\0';
+        shafa_code_table tab;
+        err = shafa_cod_parse(codes, &tab);                                      /* c.c:115-177 */
+        t.buf[t.pos] = keep;
+        if (err) break;
+        if (size > buf_cap) {
+            free(buf);
+            buf = malloc(size ? size : 1);
+            buf_cap = size;
+            if (!buf) { err = SHAFA_LACK_OF_MEMORY; break; }
+        }
+        if (fread(buf, 1, size, in) != size) { err = SHAFA_FILE_STREAM_FAILED; break; }          /* c.c:392 */
+        unsigned lmax = 0;
+        for (int s = 0; s < 256; ++s) lmax = tab.len[s] > lmax ? tab.len[s] : lmax;
+        const size_t need = (size_t)((size * (uint64_t)lmax + 7) / 8) + 16;      /* exact upper bound, not 1.05 n (c.c:58) */
+        if (need > enc_cap) {
+            free(enc);
+            enc = malloc(need);
+            enc_cap = need;
+            if (!enc) { err = SHAFA_LACK_OF_MEMORY; break; }
+        }
+        size_t out_n = 0;
+        err = shafa_hip_sf_encode(buf, size, &tab, enc, enc_cap, &out_n);        /* binary_coding on the GPU */
+        if (err) break;
+        in_sizes[b] = size;
+        out_sizes[b] = out_n;
+        if (fprintf(out, "@%lu@", (unsigned long)out_n) < 2 || fwrite(enc, 1, out_n, out) != out_n)
+            err = SHAFA_FILE_STREAM_FAILED;                                      /* c.c:256-258 */
+    }
+    if (out) fclose(out);
+    fclose(in);
+    if (!err) {
+        if (SHAFA_VERBOSE) {
+            printf("Module: C (Symbol codes' codification)\nNumber of blocks: %lu\n", (unsigned long)n_blocks);
+            for (uint64_t i = 0; i < n_blocks; ++i)
+                printf("Size before/after & compression rate (Block %lu): %lu/%lu -> %d%%\n", (unsigned long)i,
+                       (unsigned long)in_sizes[i], (unsigned long)out_sizes[i],
+                       (int)(((float)out_sizes[i] / in_sizes[i]) * 100));
+            printf("Module runtime (milliseconds): %f\nGenerated file %s\n", now_ms() - t0, p_shaf);
+        }
+        free(*path);
+        *path = p_shaf;
+        p_shaf = NULL;
+    }
+    free(p_shaf); free(in_sizes); free(buf); free(enc); free(t.buf);
+    return (_modules_error)err;
+}
+
+/* ------------------------------------------------------------------ Module D (d.c:232-388, 628-834) */
+
+static void d_summary(double ms, const uint64_t *before, const uint64_t *after, uint64_t n, const char *path, int algo)
+{
+    if (!SHAFA_VERBOSE) return;
+    printf(algo == 0 ? "Module: D (RLE decoding)\n" : algo == 1 ? "Module: D (SHAFA decoding)\n"
+                                                               : "Module: D (SHAFA & RLE decoding)\n");
+    for (uint64_t i = 0; i < n; ++i)
+        printf("Size before/after generating file (block %lu): %lu/%lu\n", (unsigned long)(i + 1),
+               (unsigned long)before[i], (unsigned long)after[i]);
+    printf("Module runtime (in milliseconds): %f\nGenerated file %s\n", ms, path);
+}
+
+_modules_error rle_decompress(char **path)
+{
+    const double t0 = now_ms();
+    FILE *in = fopen(*path, "rb");
+    if (!in) return SHAFA_FILE_INACCESSIBLE;
+    char *p_out = shafa_rm_ext(*path);
+    FILE *out = p_out ? fopen(p_out, "wb") : NULL;                               /* d.c:256 */
+    char *p_freq = shafa_add_ext(*path, SHAFA_FREQ_EXT);
+    int err = (!p_out || !p_freq) ? SHAFA_LACK_OF_MEMORY : (!out ? SHAFA_FILE_INACCESSIBLE : SHAFA_SUCCESS);
+    text_t t = {0};
+    if (!err) err = slurp(p_freq, &t);
+    char mode = 0;
+    uint64_t n_blocks = 0;
+    if (!err && !read_header(&t, &mode, &n_blocks)) err = SHAFA_FILE_STREAM_FAILED;   /* d.c:268,296 */
+    if (!err && mode != 'R') err = SHAFA_FILE_UNRECOGNIZABLE;                          /* d.c:270,292 */
+    uint64_t *sizes = !err ? malloc((n_blocks ? n_blocks : 1) * 2 * sizeof(uint64_t)) : NULL;
+    uint64_t *finals = sizes ? sizes + n_blocks : NULL;
+    if (!err && !sizes) err = SHAFA_LACK_OF_MEMORY;
+    for (uint64_t b = 0; b < n_blocks && !err; ++b) {                                  /* d.c:277-281 */
+        char *skip = NULL;
+        if (!read_block(&t, &sizes[b], &skip, SHAFA_FREQ_BLOCK_MAX)) err = SHAFA_FILE_STREAM_FAILED;
+    }
+    uint8_t *buf = NULL, *dec = malloc(SHAFA_RLE_DECODE_MAX);
+    size_t buf_cap = 0;
+    if (!err && !dec) err = SHAFA_LACK_OF_MEMORY;
+    for (uint64_t b = 0; b < n_blocks && !err; ++b) {
+        if (sizes[b] > buf_cap) {
+            free(buf);
+            buf = malloc(sizes[b] ? sizes[b] : 1);
+            buf_cap = sizes[b];
+            if (!buf) { err = SHAFA_LACK_OF_MEMORY; break; }
+        }
+        if (fread(buf, 1, sizes[b], in) != sizes[b]) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* d.c:84 */
+        size_t n = 0;
+        err = shafa_hip_rle_decode(buf, sizes[b], dec, SHAFA_RLE_DECODE_MAX, &n);      /* rle_block_decompressor */
+        if (err) break;
+        finals[b] = n;
+        if (fwrite(dec, 1, n, out) != n) err = SHAFA_FILE_STREAM_FAILED;
+    }
+    if (out) fclose(out);
+    fclose(in);
+    if (!err) {
+        d_summary(now_ms() - t0, sizes, finals, n_blocks, p_out, 0);
+        free(*path);
+        *path = p_out;
+        p_out = NULL;
+    }
+    free(p_out); free(p_freq); free(sizes); free(buf); free(dec); free(t.buf);
+    return (_modules_error)err;
+}
+
+/* "@<n>" then "@<size>@" + size raw bytes per block, from a binary stream (c.c:351,256) */
+static bool shaf_read_u64(FILE *f, char lead, uint64_t *v, bool trailing_at)
+{
+    if (fgetc(f) != lead) return false;
+    int c, digits = 0;
+    uint64_t x = 0;
+    while ((c = fgetc(f)) >= '0' && c <= '9') { x = x * 10 + (uint64_t)(c - '0'); ++digits; }
+    if (!digits) return false;
+    if (trailing_at) { if (c != '@') return false; }
+    else if (c != EOF) ungetc(c, f);
+    *v = x;
+    return true;
+}
+
+_modules_error shafa_decompress(char **path, bool decompress_rle)
+{
+    const double t0 = now_ms();
+    FILE *in = fopen(*path, "rb");
+    if (!in) return SHAFA_FILE_INACCESSIBLE;
+    int err = SHAFA_SUCCESS;
+    char *p_tmp = shafa_rm_ext(*path);                                                /* X[.rle] */
+    char *p_out = p_tmp ? (decompress_rle ? shafa_rm_ext(p_tmp) : shafa_add_ext(p_tmp, "")) : NULL;
+    char *p_cod = p_tmp ? shafa_add_ext(p_tmp, SHAFA_CODES_EXT) : NULL;
+    if (!p_tmp || !p_out || !p_cod) err = SHAFA_LACK_OF_MEMORY;
+    FILE *out = !err ? fopen(p_out, "wb") : NULL;                                     /* d.c:663 (before any check) */
+    if (!err && !out) err = SHAFA_FILE_INACCESSIBLE;
+    text_t t = {0};
+    if (!err) err = slurp(p_cod, &t);
+    uint64_t n_shaf = 0, n_blocks = 0;
+    char mode = 0;
+    if (!err && !shaf_read_u64(in, '@', &n_shaf, false)) err = SHAFA_FILE_STREAM_FAILED;          /* d.c:673 */
+    if (!err && !read_header(&t, &mode, &n_blocks)) err = SHAFA_FILE_STREAM_FAILED;               /* d.c:676: .cod's count wins */
+    if (!err && !((mode == 'N' && !decompress_rle) || mode == 'R')) err = SHAFA_FILE_UNRECOGNIZABLE;   /* d.c:678 */
+
+    uint64_t *sf_sizes = !err ? malloc((n_blocks ? n_blocks : 1) * 3 * sizeof(uint64_t)) : NULL;
+    uint64_t *sizes = sf_sizes ? sf_sizes + n_blocks : NULL, *finals = sf_sizes ? sf_sizes + 2 * n_blocks : NULL;
+    if (!err && !sf_sizes) err = SHAFA_LACK_OF_MEMORY;
+    uint8_t *payload = NULL, *sym = NULL, *dec = decompress_rle ? malloc(SHAFA_RLE_DECODE_MAX) : NULL;
+    size_t pay_cap = 0, sym_cap = 0;
+    if (!err && decompress_rle && !dec) err = SHAFA_LACK_OF_MEMORY;
+    for (uint64_t b = 0; b < n_blocks && !err; ++b) {
+        uint64_t sf_n = 0, n_sym = 0;
+        if (!shaf_read_u64(in, '@', &sf_n, true)) { err = SHAFA_FILE_STREAM_FAILED; break; }     /* d.c:697 */
+        if (sf_n > pay_cap) {
+            free(payload);
+            payload = malloc(sf_n ? sf_n : 1);
+            pay_cap = sf_n;
+            if (!payload) { err = SHAFA_LACK_OF_MEMORY; break; }
+        }
+        if (fread(payload, 1, sf_n, in) != sf_n) { err = SHAFA_FILE_STREAM_FAILED; break; }       /* d.c:706 */
+        char *codes = NULL;
+        if (!read_block(&t, &n_sym, &codes, SHAFA_COD_BLOCK_MAX)) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* d.c:709,716 */
+        const char keep = t.buf[t.pos];
+        t.buf[t.pos] = '\0';
+        shafa_code_table tab;
+        err = shafa_cod_parse(codes, &tab);
+        t.buf[t.pos] = keep;
+        if (err) break;
+        if (n_sym > sym_cap) {
+            free(sym);
+            sym = malloc(n_sym ? n_sym : 1);
+            sym_cap = n_sym;
+            if (!sym) { err = SHAFA_LACK_OF_MEMORY; break; }
+        }
+        err = shafa_hip_sf_decode(payload, sf_n, &tab, sym, n_sym);                   /* shafa_block_decompressor */
+        if (err) break;
+        sf_sizes[b] = sf_n;
+        sizes[b] = n_sym;
+        const uint8_t *wr = sym;
+        size_t wr_n = n_sym;
+        if (decompress_rle) {                                                          /* d.c:574-586 */
+            err = shafa_hip_rle_decode(sym, n_sym, dec, SHAFA_RLE_DECODE_MAX, &wr_n);
+            if (err) break;
+            wr = dec;
+            finals[b] = wr_n;
+        }
+        if (fwrite(wr, 1, wr_n, out) != wr_n) err = SHAFA_FILE_STREAM_FAILED;
+    }
+    if (out) fclose(out);
+    fclose(in);
+    if (!err) {
+        d_summary(now_ms() - t0, sf_sizes, decompress_rle ? finals : sizes, n_blocks, p_out, decompress_rle ? 2 : 1);
+        free(*path);
+        *path = p_out;
+        p_out = NULL;
+    }
+    free(p_out); free(p_tmp); free(p_cod); free(sf_sizes); free(payload); free(sym); free(dec); free(t.buf);
+    return (_modules_error)err;
+}

@@ -1,0 +1,115 @@
+"""The C host CLI (shafa-cd_amd/bin/shafa) against the reference CLI's recorded behaviour
+(tests/golden/*/manifest.json: argv, exit code, stderr, every produced file's size + SHA-256).
+
+CPU part: argv errors and the loud failure without a GPU.  GPU part (-m gpu): every golden case is
+replayed with our binary and every file it writes must be byte-identical to the reference's."""
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+CLI = os.path.join(ROOT, "shafa-cd_amd", "bin", "shafa")
+
+
+def sha(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()
+
+
+def run(argv, cwd):
+    r = subprocess.run([CLI] + argv, cwd=cwd, capture_output=True, timeout=600)
+    return r.returncode, r.stderr.decode("utf-8", "replace"), r.stdout.decode("utf-8", "replace")
+
+
+def manifest(case):
+    with open(os.path.join(GOLD, case, "manifest.json")) as f:
+        return json.load(f)
+
+
+def test_cli_binary_is_built():
+    assert os.path.exists(CLI), "run __graft_entry__.build()"
+
+
+def test_cli_argv_errors_match_reference(tmp_path):
+    man = manifest("cli_errors")
+    shutil.copyfile(os.path.join(GOLD, "cli_errors", "z"), tmp_path / "z")
+    checked = 0
+    for cmd in man["cmds"]:
+        argv = cmd["argv"]
+        if argv[:3] == ["z", "-m", "f"]:
+            continue                       # runs Module F: GPU part below
+        rc, err, _ = run(argv, tmp_path)
+        assert (rc, err) == (cmd["rc"], cmd["stderr"]), argv
+        checked += 1
+    assert checked == 4
+    rc, err, _ = run([], tmp_path)
+    assert rc == 1 and err == "No file input\n"
+    rc, err, _ = run(["-m", "f"], tmp_path)
+    assert rc == 1 and err == "No file input\n"
+    rc, err, _ = run(["z", "-b", "X"], tmp_path)
+    assert rc == 1 and err == "Wrong Options' syntax\n"
+    rc, err, _ = run(["z.freq", "-m", "t"], tmp_path)          # .freq missing: file can't be accessed
+    assert rc == 1 and err.startswith("Module t: Something went wrong...\nFile can't be accessed")
+    rc, err, _ = run(["z", "-m", "t"], tmp_path)
+    assert rc == 1 and err == "Module t: Wrong extension... Should end in .freq\n"
+
+
+def test_cli_fails_loudly_without_gpu(tmp_path, shafa):
+    if shafa.lib().shafa_hip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    shutil.copyfile(os.path.join(GOLD, "cli_errors", "z"), tmp_path / "z")
+    rc, err, _ = run(["z"], tmp_path)
+    assert rc == 1 and "GPU device error" in err
+    assert not os.path.exists(tmp_path / "z.rle") and not os.path.exists(tmp_path / "z.freq")
+
+
+def test_cli_module_t_alone_on_cpu(tmp_path):
+    """Module T is host-only (256 symbols per block): it runs without a GPU and must reproduce h.cod."""
+    shutil.copyfile(os.path.join(GOLD, "t_handmade", "h.freq"), tmp_path / "h.freq")
+    rc, err, out = run(["h.freq", "-m", "t"], tmp_path)
+    assert rc == 0, err
+    assert sha(tmp_path / "h.cod") == manifest("t_handmade")["files"]["h.cod"]["sha256"]
+    assert "Module:T (Calculation of symbol codes)" in out and "Number of blocks: 5" in out
+
+
+GPU_CASES = ["runs_default", "edges_forced_rle", "uniform_no_rle", "uniform_forced_both", "runs_force_freq",
+             "textlike_m", "tiny_1024", "tiny_1023", "cli_errors", "cfg0_K_runs", "cfg0_K_uniform"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GPU_CASES)
+def test_cli_replays_reference_session(case, tmp_path):
+    man = manifest(case)
+    for fn in man["inputs"]:
+        src = os.path.join(GOLD, case, fn)
+        if os.path.exists(src):
+            shutil.copyfile(src, tmp_path / fn)
+        else:                                           # big inputs are regenerated from their seed
+            import golden.make_golden as mg
+            zt = mg.zipf_table(1.2)
+            data = mg.runs_stream(7, 655360, zt) if case == "cfg0_K_runs" else mg.gen_bytes(8, 655360)
+            data.tofile(tmp_path / fn)
+            assert sha(tmp_path / fn) == man["files"][fn]["sha256"]
+    for cmd in man["cmds"]:
+        if isinstance(cmd, list):
+            if cmd[0] == "__copy__":
+                shutil.copyfile(tmp_path / cmd[1], tmp_path / cmd[2])
+            elif cmd[0] == "__rm__":
+                os.remove(tmp_path / cmd[1])
+            continue
+        rc, err, out = run(cmd["argv"], tmp_path)
+        assert rc == cmd["rc"], f"{case} {cmd['argv']}: rc {rc} stderr {err!r}"
+        assert err == cmd["stderr"], f"{case} {cmd['argv']}"
+    produced = sorted(os.listdir(tmp_path))
+    assert produced == sorted(man["files"]), f"{case}: file set differs"
+    for fn, meta in man["files"].items():
+        p = tmp_path / fn
+        assert os.path.getsize(p) == meta["size"], f"{case}/{fn}: size {os.path.getsize(p)} != {meta['size']}"
+        assert sha(p) == meta["sha256"], f"{case}/{fn}: content differs from the reference's file"
