@@ -17,3 +17,10 @@ def load():
     sys.modules["shafa_cd_amd"] = mod
     spec.loader.exec_module(mod)
     return mod
+
+
+def load_submodule(name):
+    """shafa_cd_amd.<name> (e.g. sharding) without importing torch-free parts twice."""
+    import importlib
+    load()
+    return importlib.import_module("shafa_cd_amd." + name)
