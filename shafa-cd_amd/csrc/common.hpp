@@ -74,6 +74,52 @@ __device__ __forceinline__ u32 funnel_r(u32 hi, u32 lo, u32 sh)
     return __builtin_amdgcn_alignbit(hi, lo, sh);
 }
 
+// Pointers that reach a kernel inside a parameter record are "generic" to the compiler, which then
+// emits flat_load/flat_store: those count on BOTH vmcnt and lgkmcnt and retire out of order, so every
+// later LDS wait also waits for the HBM access (no prefetch overlap).  These helpers state the global
+// address space explicitly (global_load/global_store, vmcnt only).
+#define GLOBAL_AS __attribute__((address_space(1)))
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ T gload(const void *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const GLOBAL_AS T *)(unsigned long long)p;
+#else
+    return *(const T *)p;
+#endif
+}
+template <>
+__device__ __forceinline__ uint4 gload<uint4>(const void *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32x4_t v = *(const GLOBAL_AS u32x4_t *)(unsigned long long)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *(const uint4 *)p;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void gstore(void *p, T v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    *(GLOBAL_AS T *)(unsigned long long)p = v;
+#else
+    *(T *)p = v;
+#endif
+}
+template <>
+__device__ __forceinline__ void gstore<uint4>(void *p, uint4 v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32x4_t x;
+    x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w;
+    *(GLOBAL_AS u32x4_t *)(unsigned long long)p = x;
+#else
+    *(uint4 *)p = v;
+#endif
+}
+
 // first error wins per block (codes are small positive ints; keep the first non-zero)
 __device__ __forceinline__ void set_error(int *err, int code)
 {
@@ -84,7 +130,10 @@ __device__ __forceinline__ void set_error(int *err, int code)
 // look-back over one block's tile descriptors; wave 0 only, all 64 lanes.  Returns the exclusive
 // prefix (sum of the aggregates of tiles 0..k-1).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 lookback_sum(const u64 *desc, int k, int *err)
+// `first` (optional): the descriptors of tiles k-1-lane, loaded earlier by the caller so that the
+// round trip overlaps other work; used for the first window instead of a fresh load.
+__device__ __forceinline__ u64 lookback_sum(const u64 *desc, int k, int *err, bool have_first = false,
+                                            u64 first = 0)
 {
     const int lane = lane_id();
     u64 excl = 0;
@@ -94,7 +143,9 @@ __device__ __forceinline__ u64 lookback_sum(const u64 *desc, int k, int *err)
         u64 d = 0;
         u32 spins = 0;
         for (;;) {
-            d = (idx >= 0) ? desc_load(desc + idx) : (DESC_PREFIX << 62);
+            if (have_first) d = first;
+            else d = (idx >= 0) ? desc_load(desc + idx) : (DESC_PREFIX << 62);
+            have_first = false;
             if (__all((d >> 62) != DESC_EMPTY)) break;
             if (++spins > SPIN_LIMIT) {          // lost predecessor: flag instead of hanging
                 if (lane == 0) set_error(err, SHAFA_DEVICE_ERROR);

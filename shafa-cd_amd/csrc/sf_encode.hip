@@ -20,6 +20,8 @@
 #include "common.hpp"
 #include "internal.hpp"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int ENC_THREADS = 256;
@@ -47,7 +49,7 @@ __device__ __forceinline__ void emit_group(u32 *stage, u32 wlo, u32 wcount, u64 
 template <int G> struct Ent;
 template <> struct Ent<4> {                       // Lmax <= 16: code | len << 16
     typedef u32 type;
-    static __device__ __forceinline__ u32 len(u32 e) { return e >> 16; }
+    static __device__ __forceinline__ u32 len(u32 e) { return (e >> 16) & 31u; }   // bit 31 = symbol absent
     static __device__ __forceinline__ u32 code(u32 e) { return e & 0xFFFFu; }
 };
 template <> struct Ent<2> {                       // Lmax <= 32: code | len << 32
@@ -69,9 +71,11 @@ struct EncShared {
     u64 prefix;
 };
 
+// dbg bits (timing experiments only, output is wrong when set; SHAFA_ENC_DBG env var):
+// 1 = no ticket, 2 = no look-back, 4 = no emission, 8 = no copy-out
 template <typename EmitFn, typename LeadFn>
 __device__ __forceinline__ void encode_tail(EncShared &sh, const EncBlk &blk, u64 *desc, int k,
-                                            u32 tile_bits, EmitFn emit, LeadFn lead_bits)
+                                            u32 tile_bits, EmitFn emit, LeadFn lead_bits, u32 dbg = 0)
 {
     const int tid = threadIdx.x;
     u64 *bdesc = desc + blk.desc_base;
@@ -79,10 +83,11 @@ __device__ __forceinline__ void encode_tail(EncShared &sh, const EncBlk &blk, u6
 
     if (wave_id() == 0) {
         u64 B = 0;
-        if (k > 0) {
+        if (k > 0 && !(dbg & 2)) {
             if (tid == 0) desc_store(bdesc + k, DESC_AGG, tile_bits);
             B = lookback_sum(bdesc, k, blk.err);
         }
+        if (dbg & 2) B = (u64)k * 87001ull;
         if (tid == 0) {
             desc_store(bdesc + k, DESC_PREFIX, B + tile_bits);
             sh.prefix = B;
@@ -114,9 +119,10 @@ __device__ __forceinline__ void encode_tail(EncShared &sh, const EncBlk &blk, u6
             if (tid == 0) sh.stage[0] = carry;
             __syncthreads();
         }
-        emit(sh.stage + 1, r0, (u32)ENC_STAGE_WORDS);
+        if (!(dbg & 4)) emit(sh.stage + 1, r0, (u32)ENC_STAGE_WORDS);
         __syncthreads();
-        const u32 jend = (OW < r0 + ENC_STAGE_WORDS) ? OW : r0 + ENC_STAGE_WORDS;
+        u32 jend = (OW < r0 + ENC_STAGE_WORDS) ? OW : r0 + ENC_STAGE_WORDS;
+        if (dbg & 8) jend = 0;
         for (u32 j = r0 + tid; j < jend; j += ENC_THREADS) {
             const u32 li = j - r0;
             const u32 w = funnel_r(sh.stage[li], sh.stage[li + 1], s);
@@ -137,9 +143,9 @@ __device__ __forceinline__ void encode_tail(EncShared &sh, const EncBlk &blk, u6
 // ------------------------------------------------------------------------------------------------
 // fast kernel: Lmax <= 16 (G = 4, 16 KiB tiles) or Lmax <= 32 (G = 2, 8 KiB tiles)
 // ------------------------------------------------------------------------------------------------
-template <int G>
-__global__ __launch_bounds__(ENC_THREADS) void sf_encode_fast(const EncBlk *__restrict__ blks, int nblk,
-                                                              u64 *desc, u32 *tickets)
+template <int G, int OCC>
+__global__ __launch_bounds__(ENC_THREADS, OCC) void sf_encode_fast(const EncBlk *__restrict__ blks, int nblk,
+                                                              u64 *desc, u32 *tickets, u32 dbg)
 {
     typedef typename Ent<G>::type ent_t;
     constexpr int ITEMS = G;                 // 16-byte items per thread
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(ENC_THREADS) void sf_encode_fast(const EncBlk *__re
     const EncBlk blk = blks[b];
     if ((u32)(blockIdx.x / nblk) >= blk.n_tiles) return;
 
-    if (tid == 0) sh.tile = atomicAdd(tickets + blk.ticket, 1u);
+    if (tid == 0) sh.tile = (dbg & 1) ? (u32)(blockIdx.x / nblk) : atomicAdd(tickets + blk.ticket, 1u);
     lut[tid] = ((const ent_t *)blk.lut)[tid];
     __syncthreads();
     const int k = (int)sh.tile;
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(ENC_THREADS) void sf_encode_fast(const EncBlk *__re
         }
         return (u32)acc & ((1u << need) - 1u);
     };
-    encode_tail(sh, blk, desc, k, tile_bits, emit, lead);
+    encode_tail(sh, blk, desc, k, tile_bits, emit, lead, dbg);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -345,6 +351,9 @@ __global__ __launch_bounds__(ENC_THREADS) void sf_encode_generic(const EncBlk *_
 // ------------------------------------------------------------------------------------------------
 // host launcher
 // ------------------------------------------------------------------------------------------------
+void sfenc2_launch(hipStream_t st, const EncBlk *dblk, int count, u32 total_tiles, u64 *ddesc, u32 *dtick);
+void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 *d_tile_bits, u64 *d_tile_off);
+
 int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                  const u64 *h_in_n, const shafa_code_table *h_tables, u8 *d_out, const u64 *h_out_off,
                  const u64 *h_out_cap, u64 *d_out_n)
@@ -357,7 +366,10 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     std::vector<int> cls(nblocks);
     u64 total_tiles[4] = {0, 0, 0, 0};
     u32 max_tiles[4] = {0, 0, 0, 0};
-    static const u64 tile_syms[4] = {1, 256 * 16 * 4, 256 * 16 * 2, GEN_TILE};
+    const char *v_env0 = getenv("SHAFA_ENC_V");
+    const int enc_v = v_env0 ? atoi(v_env0) : 3;           // 1 = one tile per workgroup, 2 = persistent, 3 = three kernels
+    const bool use_v1 = enc_v == 1;
+    const u64 tile_syms[4] = {1, enc_v == 1 ? 256u * 16 * 4 : 256u * 16 * 2, 256 * 16 * 2, GEN_TILE};
     for (int b = 0; b < nblocks; ++b) {
         if ((h_in_off[b] & 15) || (h_out_off[b] & 15)) return SHAFA_OUTSIDE_MODULE;
         const u64 n = h_in_n[b];
@@ -379,6 +391,7 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const size_t o_desc = off; off += ndesc * 8;
     const size_t o_tick = off; off += (size_t)nblocks * 4; off = (off + 15) & ~(size_t)15;
     const size_t o_zero_end = off;
+    const size_t o_tbits = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;      // v3: tile bit totals
     const size_t o_blk = off; off += (size_t)nblocks * sizeof(EncBlk); off = (off + 15) & ~(size_t)15;
     const size_t o_tab = off;
     size_t tab_bytes = 0;
@@ -423,7 +436,7 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
                 for (int s = 0; s < 256; ++s) {
                     u32 code = 0;
                     for (int q = 0; q < t.len[s]; ++q) code = (code << 1) | ((t.bits[s][q >> 3] >> (7 - (q & 7))) & 1u);
-                    l[s] = code | ((u32)t.len[s] << 16);
+                    l[s] = t.len[s] ? (code | ((u32)t.len[s] << 16)) : 0x80000000u;
                 }
                 tpos += 1024;
             } else if (c == 2) {
@@ -441,20 +454,33 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
             ++pos;
         }
     }
-    if (o_zero_end) HIP_TRY(hipMemsetAsync(ws, 0, o_zero_end, st));
+    const bool need_desc = cls_count[2] || cls_count[3] || (cls_count[1] && enc_v != 3);
+    if (o_zero_end && need_desc) HIP_TRY(hipMemsetAsync(ws, 0, o_zero_end, st));
     HIP_TRY(hipMemcpyAsync(ws + o_blk, hs, stage_bytes, hipMemcpyHostToDevice, st));
     for (int b = 0; b < nblocks; ++b)
         if (cls[b] == 0) HIP_TRY(hipMemsetAsync(d_out_n + b, 0, 8, st));
 
+    const char *dbg_env = getenv("SHAFA_ENC_DBG");
+    const u32 dbg = dbg_env ? (u32)atoi(dbg_env) : 0u;
     const EncBlk *dblk = (const EncBlk *)(ws + o_blk);
     u64 *ddesc = (u64 *)(ws + o_desc);
     u32 *dtick = (u32 *)(ws + o_tick);
-    if (cls_count[1])
-        hipLaunchKernelGGL(sf_encode_fast<4>, dim3(max_tiles[1] * cls_count[1]), dim3(ENC_THREADS), 0, st,
-                           dblk + cls_first[1], cls_count[1], ddesc, dtick);
-    if (cls_count[2])
-        hipLaunchKernelGGL(sf_encode_fast<2>, dim3(max_tiles[2] * cls_count[2]), dim3(ENC_THREADS), 0, st,
-                           dblk + cls_first[2], cls_count[2], ddesc, dtick);
+    const char *occ_env = getenv("SHAFA_ENC_OCC");
+    const int occ = occ_env ? atoi(occ_env) : 1;
+#define LAUNCH_FAST(G, C)                                                                                     \
+    do {                                                                                                      \
+        const dim3 grid(max_tiles[C] * cls_count[C]);                                                         \
+        if (occ >= 6) hipLaunchKernelGGL((sf_encode_fast<G, 6>), grid, dim3(ENC_THREADS), 0, st, dblk + cls_first[C], cls_count[C], ddesc, dtick, dbg); \
+        else if (occ == 5) hipLaunchKernelGGL((sf_encode_fast<G, 5>), grid, dim3(ENC_THREADS), 0, st, dblk + cls_first[C], cls_count[C], ddesc, dtick, dbg); \
+        else if (occ == 4) hipLaunchKernelGGL((sf_encode_fast<G, 4>), grid, dim3(ENC_THREADS), 0, st, dblk + cls_first[C], cls_count[C], ddesc, dtick, dbg); \
+        else hipLaunchKernelGGL((sf_encode_fast<G, 1>), grid, dim3(ENC_THREADS), 0, st, dblk + cls_first[C], cls_count[C], ddesc, dtick, dbg); \
+    } while (0)
+    if (cls_count[1]) {
+        if (use_v1) LAUNCH_FAST(4, 1);
+        else if (enc_v == 2) sfenc2_launch(st, dblk + cls_first[1], cls_count[1], (u32)total_tiles[1], ddesc, dtick);
+        else sfenc3_launch(st, dblk + cls_first[1], cls_count[1], max_tiles[1], (u32 *)(ws + o_tbits), ddesc);
+    }
+    if (cls_count[2]) LAUNCH_FAST(2, 2);
     if (cls_count[3])
         hipLaunchKernelGGL(sf_encode_generic, dim3(max_tiles[3] * cls_count[3]), dim3(ENC_THREADS), 0, st,
                            dblk + cls_first[3], cls_count[3], ddesc, dtick);

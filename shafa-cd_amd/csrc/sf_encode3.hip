@@ -1,0 +1,303 @@
+// sf_encode3.hip — Shannon-Fano bit-pack encoder for codes <= 16 bits as three dependency-free kernels.
+//
+// Same output as sf_encode_fast<4> (sf_encode.hip).  The single-pass chained-scan versions spend
+// most of their time waiting (ticket -> load -> look-back chain per workgroup, or a serial resolve
+// step per tile at 4 waves/SIMD); a calibration kernel that only loads, looks up and groups runs at
+// 4.5-5.3 TB/s of input on the same data (tools/microbench.py).  So the prefix problem is split off:
+//
+//   sfe3_count : per tile, sum of code lengths                    (reads n; byte LUT, no grouping)
+//   sfe3_scan  : per block, exclusive scan of the tile totals     (4096 tiles per 64 MiB block)
+//   sfe3_pack  : per tile, look up + group + merge into an LDS bit-stream + aligned stores
+//
+// No tickets, no descriptors, no inter-workgroup waiting; every workgroup is independent, which is
+// what lets the hardware run 6-8 of them per CU.  The price is a second read of the input (n more
+// bytes of traffic; it is served from the 256 MiB Infinity Cache when the launch covers <= ~2 blocks).
+#include "common.hpp"
+#include "internal.hpp"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+namespace {
+
+constexpr int E3_THREADS = 256;
+constexpr int E3_ITEMS = 2;                            // 16-byte items per lane and tile
+constexpr int E3_TILE = E3_THREADS * 16 * E3_ITEMS;    // 8 KiB of symbols
+constexpr int E3_SW64 = 1280;                          // LDS bit-stream window: 10 KiB; tiles that expand more take two rounds
+
+__device__ __forceinline__ u32 dpp_scan(u32 v)
+{
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// count: tile_bits[tile] = sum of code lengths; grid = (tiles, blocks)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(E3_THREADS) void sfe3_count(const EncBlk *__restrict__ blks, u32 *__restrict__ tile_bits)
+{
+    __shared__ u32 lut[256];
+    __shared__ u32 wsum[4];
+    const EncBlk blk = blks[blockIdx.y];
+    const u32 tile = blockIdx.x;
+    if (tile >= blk.n_tiles) return;
+    const int tid = threadIdx.x;
+    lut[tid] = gload<u32>((const u32 *)blk.lut + tid);
+    __syncthreads();
+    const u64 base = (u64)tile * E3_TILE;
+    u32 tot = 0, flags = 0;
+    if (base + E3_TILE <= blk.n) {
+        uint4 v[E3_ITEMS];
+#pragma unroll
+        for (int it = 0; it < E3_ITEMS; ++it) v[it] = gload<uint4>(blk.in + base + (u64)it * (E3_THREADS * 16) + (u64)tid * 16);
+#pragma unroll
+        for (int it = 0; it < E3_ITEMS; ++it) {
+            const u32 w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const u32 x = lut[(w[j >> 2] >> (8 * (j & 3))) & 0xFFu];
+                flags |= x;
+                tot += (x >> 16) & 31u;
+            }
+        }
+    } else {                                           // ragged last tile of the block
+        for (int it = 0; it < E3_ITEMS; ++it) {
+            const u64 idx = base + (u64)it * (E3_THREADS * 16) + (u64)tid * 16;
+            for (int j = 0; j < 16; ++j) {
+                if (idx + j < blk.n) {
+                    const u32 x = lut[gload<u8>(blk.in + idx + j)];
+                    flags |= x;
+                    tot += (x >> 16) & 31u;
+                }
+            }
+        }
+    }
+    if (flags & 0x80000000u) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
+    const u32 s = dpp_scan(tot);
+    if ((tid & 63) == 63) wsum[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) tile_bits[blk.desc_base + tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// scan: per block, tile_off[tile] = bits before the tile; out_n[b] = ceil(total / 8)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(E3_THREADS) void sfe3_scan(const EncBlk *__restrict__ blks, const u32 *__restrict__ tile_bits,
+                                                        u64 *__restrict__ tile_off)
+{
+    __shared__ u64 wtot[4];
+    __shared__ u64 carry;
+    const EncBlk blk = blks[blockIdx.x];
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (u32 t0 = 0; t0 < blk.n_tiles; t0 += E3_THREADS) {
+        const u32 t = t0 + tid;
+        const u64 c = t < blk.n_tiles ? (u64)tile_bits[blk.desc_base + t] : 0ull;
+        const u64 incl = wave_incl_scan_add<u64>(c);
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        u64 base = carry;
+        for (u32 w = 0; w < wv; ++w) base += wtot[w];
+        if (t < blk.n_tiles) tile_off[blk.desc_base + t] = base + incl - c;
+        __syncthreads();
+        if (tid == 0) carry += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+    }
+    if (tid == 0) gstore<u64>(blk.out_n, (carry + 7) >> 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack: the tile's groups are OR-ed into a zeroed LDS window of 64-bit words that is ALREADY aligned to
+// the global output (bit offset = tile-local offset + (B mod 64)), so storing is a straight copy.  A tile
+// owns every output u64 that begins inside it; the (B mod 64) leading bits of its first word belong
+// to the previous tile and are re-encoded from the 64 input bytes before the tile.
+// ------------------------------------------------------------------------------------------------
+struct Pack3Shared {
+    u64 stage[E3_SW64 + 2];
+    u32 lut[256];                // code | len << 16
+    u32 wtot[4 * E3_ITEMS];
+    u32 prev[16];
+};
+
+__device__ __forceinline__ u64 bswap64(u64 x)
+{
+    return ((u64)bswap32((u32)x) << 32) | bswap32((u32)(x >> 32));
+}
+
+__global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict__ blks, const u32 *__restrict__ tile_bits,
+                                                        const u64 *__restrict__ tile_off, u32 dbg)
+{
+    __shared__ __attribute__((aligned(16))) Pack3Shared sh;
+    const EncBlk blk = blks[blockIdx.y];
+    const u32 tile = blockIdx.x;
+    if (tile >= blk.n_tiles) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u64 base = (u64)tile * E3_TILE;
+    const bool full = base + E3_TILE <= blk.n;
+
+    // everything this tile needs from memory is requested up front, nothing depends on anything else
+    const u64 B = tile_off[blk.desc_base + tile];
+    uint4 cur[E3_ITEMS];
+#pragma unroll
+    for (int it = 0; it < E3_ITEMS; ++it) {
+        const u64 idx = base + (u64)it * (E3_THREADS * 16) + (u64)tid * 16;
+        if (full) cur[it] = gload<uint4>(blk.in + idx);
+        else {
+            u32 w[4] = {0, 0, 0, 0};
+            if (idx < blk.n) {
+                const int nv = blk.n - idx >= 16 ? 16 : (int)(blk.n - idx);
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (q < nv) w[q >> 2] |= (u32)gload<u8>(blk.in + idx + q) << (8 * (q & 3));
+            }
+            cur[it] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    u32 pv = 0;
+    if (tid < 16 && tile > 0) pv = gload<u32>(blk.in + base - 64 + 4 * tid);
+    {
+        const u32 x = gload<u32>((const u32 *)blk.lut + tid) & 0x7FFFFFFFu;     // absent symbols: count flagged them
+        sh.lut[tid] = x;
+    }
+    if (!(dbg & 32)) for (int i = tid; i < E3_SW64 + 2; i += E3_THREADS) sh.stage[i] = 0;
+    if (tid < 16) sh.prev[tid] = pv;
+    __syncthreads();                                                                           // 1
+
+    // ---- look up + group (4 symbols -> one group of <= 64 bits) ---------------------------------------
+    u64 grp[E3_ITEMS][4];
+    u32 glen[E3_ITEMS];
+    u32 itot[E3_ITEMS];
+#pragma unroll
+    for (int it = 0; it < E3_ITEMS; ++it) {
+        const u64 idx = base + (u64)it * (E3_THREADS * 16) + (u64)tid * 16;
+        const u32 wds[4] = {cur[it].x, cur[it].y, cur[it].z, cur[it].w};
+        u32 tot = 0, packed = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32 e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32 x = sh.lut[(wds[g] >> (8 * j)) & 0xFFu];
+                if (!full && idx + 4 * g + j >= blk.n) x = 0;
+                e[j] = x;
+            }
+            const u32 l0 = e[0] >> 16, l1 = e[1] >> 16, l2 = e[2] >> 16, l3 = e[3] >> 16;
+            const u32 a = ((e[0] & 0xFFFFu) << l1) | (e[1] & 0xFFFFu);
+            const u32 c = ((e[2] & 0xFFFFu) << l3) | (e[3] & 0xFFFFu);
+            const u32 L = l0 + l1 + l2 + l3;
+            grp[it][g] = ((u64)a << (l2 + l3)) | c;
+            packed |= L << (8 * g);
+            tot += L;
+        }
+        glen[it] = packed;
+        itot[it] = tot;
+    }
+    u32 incl[E3_ITEMS];
+#pragma unroll
+    for (int it = 0; it < E3_ITEMS; ++it) incl[it] = dpp_scan(itot[it]);
+    if (lane == 63) {
+#pragma unroll
+        for (int it = 0; it < E3_ITEMS; ++it) sh.wtot[it * 4 + wv] = incl[it];
+    }
+    __syncthreads();                                                                           // 2
+    const u32 s = (u32)B & 63;                         // bit phase of the tile inside its first output u64
+    u32 ioff[E3_ITEMS];
+    u32 run = 0;
+#pragma unroll
+    for (int it = 0; it < E3_ITEMS; ++it) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w == wv) ioff[it] = s + run + incl[it] - itot[it];
+            run += sh.wtot[it * 4 + w];
+        }
+    }
+    const u32 T = run;                                 // tile bit total (== tile_bits[tile])
+    const bool last = (tile == blk.n_tiles - 1);
+    const u64 g64 = B >> 6;                            // first output u64 owned by the tile
+    const u64 E = B + T;
+    const u32 nfull = (u32)((E >> 6) - g64);           // whole output words owned
+    const u64 total_bytes = (E + 7) >> 3;              // block size when this is the last tile
+    const u32 ntail = last ? (u32)(total_bytes - 8 * (E >> 6)) : 0u;     // 0..7 bytes of a final partial word
+    const u32 nwords = nfull + (ntail ? 1u : 0u);
+
+    if (tid == 255 && s) {                             // lead bits: the last s bits before the tile
+        u64 acc = 0;
+        u32 got = 0;
+        const u8 *pb = (const u8 *)sh.prev;
+        for (int p = 63; p >= 0 && got < s; --p) {     // >= 1 bit per symbol: 63 symbols suffice
+            const u32 x = sh.lut[pb[p]];
+            acc |= (got < 64 ? (u64)(x & 0xFFFFu) << got : 0ull);
+            got += (x >> 16) & 31u;
+        }
+        acc &= (~0ull) >> (64 - s);
+        atomicOr((unsigned long long *)&sh.stage[0], (unsigned long long)(acc << (64 - s)));
+    }
+
+    // ---- merge into the window(s), store --------------------------------------------------------------------
+    u64 *out64 = (u64 *)blk.out + g64;
+    const u64 cap64 = blk.out_cap >> 3;
+    for (u32 r0 = 0; r0 < (nwords ? nwords : 1u); r0 += E3_SW64) {
+        if (r0) {                                      // tile expands past one window (codes near 16 bits)
+            __syncthreads();
+            for (int i = tid; i < E3_SW64 + 2; i += E3_THREADS) sh.stage[i] = 0;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int it = 0; it < E3_ITEMS; ++it) {
+            u32 q = ioff[it];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const u32 L = (glen[it] >> (8 * g)) & 0xFFu;
+                if (L && !(dbg & 4)) {                 // a group of <= 64 bits touches at most two 64-bit words
+                    const u64 Gl = grp[it][g] << (64 - L);          // left-aligned
+                    const u32 sft = q & 63, i = (q >> 6) - r0;
+                    const u64 hi = Gl >> sft;
+                    const u64 lo = sft ? (Gl << (64 - sft)) : 0ull;
+                    if (i < (u32)E3_SW64) atomicOr((unsigned long long *)&sh.stage[i], (unsigned long long)hi);
+                    if (lo && i + 1 < (u32)E3_SW64) atomicOr((unsigned long long *)&sh.stage[i + 1], (unsigned long long)lo);
+                }
+                q += L;
+            }
+        }
+        __syncthreads();                                                                       // 3
+        if (dbg & 8) { if (sh.stage[tid] == 0x123456789ull) gstore<u32>(blk.out, 1u); continue; }
+        // straight copy of the owned words of this window: two u64 (16 bytes) per lane
+        const u32 wend = (nfull < r0 + E3_SW64) ? nfull : r0 + E3_SW64;
+        if (g64 + wend > cap64) {
+            if (tid == 0) set_error(blk.err, SHAFA_LACK_OF_MEMORY);
+        } else {
+            for (u32 i = r0 + 2 * (u32)tid; i < wend; i += 2 * E3_THREADS) {
+                const u64 a = bswap64(sh.stage[i - r0]);
+                if (i + 1 < wend) {
+                    const u64 c = bswap64(sh.stage[i - r0 + 1]);
+                    gstore<uint4>(out64 + i, make_uint4((u32)a, (u32)(a >> 32), (u32)c, (u32)(c >> 32)));
+                } else gstore<u64>(out64 + i, a);
+            }
+        }
+        if (ntail && tid == 0 && nfull >= r0 && nfull < r0 + E3_SW64) {     // the block's final partial word
+            const u64 w = sh.stage[nfull - r0];
+            if (total_bytes <= blk.out_cap) {
+                for (u32 q = 0; q < ntail; ++q) gstore<u8>(blk.out + 8 * (g64 + nfull) + q, (u8)(w >> (56 - 8 * q)));
+            } else set_error(blk.err, SHAFA_LACK_OF_MEMORY);
+        }
+    }
+}
+
+}  // namespace
+
+// launched from sfenc_launch (sf_encode.hip) for the Lmax <= 16 class; ws3 = [tile_bits u32 * tiles][tile_off u64 * tiles]
+void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 *d_tile_bits, u64 *d_tile_off)
+{
+    const dim3 grid(max_tiles, (u32)count);
+    hipLaunchKernelGGL(sfe3_count, grid, dim3(E3_THREADS), 0, st, dblk, d_tile_bits);
+    hipLaunchKernelGGL(sfe3_scan, dim3((u32)count), dim3(E3_THREADS), 0, st, dblk, (const u32 *)d_tile_bits, d_tile_off);
+    const char *dbg_env = getenv("SHAFA_ENC_DBG");
+    hipLaunchKernelGGL(sfe3_pack, grid, dim3(E3_THREADS), 0, st, dblk, (const u32 *)d_tile_bits, (const u64 *)d_tile_off,
+                       dbg_env ? (u32)atoi(dbg_env) : 0u);
+}
