@@ -26,6 +26,8 @@
 #include "common.hpp"
 #include "internal.hpp"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int DEC_THREADS = 256;
@@ -48,6 +50,7 @@ struct DecBlk {
                            //   group (next nb bits index lut2[base..]) ; 0 = go to the trie
     const u16 *lut2;       // level 2 (codes of K+1 .. K+8 bits): sym | len << 8 ; 0 = go to the trie
     const u8 *lenlut;      // 2^K1 entries: len only (DP of the packed path); 0 = longer than K1 bits
+    const u16 *lut13;      // 2^K1 entries: sym | len << 8, single level (only when Lmax <= 13), else NULL
     const u32 *trie;       // pairs {child0, child1}: 0x80000000|sym = leaf, 0xFFFFFFFF = missing
     u32 K;
     u32 K1;
@@ -63,12 +66,13 @@ __device__ __forceinline__ u32 widx(u32 w) { return w + (w >> 3); }
 struct Code { u32 len; u32 sym; bool ok; };
 
 // length (and symbol) of the code that starts at tile-local bit position p
-__device__ __forceinline__ Code code_at(const u32 *data, const u16 *lut, const u32 *trie, u32 K, u32 p)
+__device__ __forceinline__ Code code_at(const u32 *data, const u16 *lut, const u32 *trie, u32 K, u32 p,
+                                        bool trie_only = false)
 {
     const u32 w = p >> 5, r = p & 31;
     const u64 two = ((u64)data[widx(w)] << 32) | data[widx(w + 1)];
     const u32 win = (u32)((two << r) >> 32);
-    u32 e = lut[win >> (32 - K)];
+    u32 e = trie_only ? 0u : lut[win >> (32 - K)];
     Code c;
     if (e & 0x8000u) {                              // codes of K+1..K+8 bits: one more table
         const u32 nb = ((e >> 12) & 7u) + 1;
@@ -96,13 +100,13 @@ __device__ __forceinline__ void load_tile(u32 *data, const DecBlk &blk, u32 tile
         const u64 off = base + (u64)i * 16;
         u32 w[4] = {0, 0, 0, 0};
         if (off + 16 <= blk.in_n) {
-            const uint4 v = *(const uint4 *)(blk.in + off);
+            const uint4 v = gload<uint4>(blk.in + off);
             w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
         } else if (off < blk.in_n) {
             const int nv = (int)(blk.in_n - off);
 #pragma unroll
             for (int q = 0; q < 16; ++q)
-                if (q < nv) w[q >> 2] |= (u32)blk.in[off + q] << (8 * (q & 3));
+                if (q < nv) w[q >> 2] |= (u32)gload<u8>(blk.in + off + q) << (8 * (q & 3));
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) data[widx(4 * i + q)] = bswap32(w[q]);
@@ -113,9 +117,9 @@ __device__ __forceinline__ void load_lut(u16 *lut, const DecBlk &blk)
 {
     const u32 n32 = (1u << blk.K) / 2;            // K >= 1
     for (u32 i = threadIdx.x; i < (n32 ? n32 : 1); i += DEC_THREADS)
-        ((u32 *)lut)[i] = ((const u32 *)blk.lut)[i];
+        ((u32 *)lut)[i] = gload<u32>((const u32 *)blk.lut + i);
     u32 *l2 = (u32 *)(lut + (1u << LUT_MAXK));
-    for (u32 i = threadIdx.x; i < (blk.n_l2 + 1) / 2; i += DEC_THREADS) l2[i] = ((const u32 *)blk.lut2)[i];
+    for (u32 i = threadIdx.x; i < (blk.n_l2 + 1) / 2; i += DEC_THREADS) l2[i] = gload<u32>((const u32 *)blk.lut2 + i);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_sync16(const DecBlk *__restri
 
     load_tile(data, blk, tile);
     for (u32 i = tid; i < (1u << K1) / 4 + 1; i += DEC_THREADS)
-        if (i < ((1u << K1) + 3) / 4) ((u32 *)lenlut)[i] = ((const u32 *)blk.lenlut)[i];
+        if (i < ((1u << K1) + 3) / 4) ((u32 *)lenlut)[i] = gload<u32>((const u32 *)blk.lenlut + i);
     __syncthreads();
 
     // backward DP; nibble j of `ring` = exit(p + 1 + j).  Positions 256..271 (the next chunk's first
@@ -317,15 +321,46 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tiles16(const DecBlk *__restr
 // last byte must not be counted, or a truncated stream would go unnoticed.
 template <typename Sink>
 __device__ __forceinline__ u32 decode_chunk(const u32 *data, const u16 *lut, const DecBlk &blk, u32 cbase,
-                                            u32 entry, u32 limit, Sink sink)
+                                            u32 entry, u32 limit, u32 max_syms, Sink sink)
 {
+    // 64-bit bit buffer, next stream bit at the MSB, >= 32 valid bits before every look-up
     u32 p = entry, cnt = 0;
-    while (p < (u32)CH_BITS) {
-        const Code c = code_at(data, lut, blk.trie, blk.K, cbase + p);
-        if (cbase + p + c.len > limit) break;
-        sink(c.sym, c.ok);
-        p += c.len;
+    u32 pos = cbase + p;
+    u32 wnext = (pos >> 5) + 2;
+    u64 buf = ((((u64)data[widx(pos >> 5)]) << 32) | data[widx((pos >> 5) + 1)]) << (pos & 31);
+    int avail = 64 - (int)(pos & 31);
+    const u32 K = blk.K;
+    while (p < (u32)CH_BITS && cnt < max_syms) {
+        const u32 win = (u32)(buf >> 32);
+        u32 e = lut[win >> (32 - K)];
+        if (e & 0x8000u) {                              // codes of K+1..K+8 bits: one more table
+            const u32 nb = ((e >> 12) & 7u) + 1;
+            e = lut[(1u << LUT_MAXK) + (e & 0xFFFu) + ((win << K) >> (32 - nb))];
+        }
+        u32 len = e >> 8, sym = e & 0xFF;
+        bool ok = true;
+        if (__builtin_expect(e == 0, 0)) {              // longer code or missing branch: trie walk
+            const Code c = code_at(data, lut, blk.trie, K, cbase + p);
+            len = c.len; sym = c.sym; ok = c.ok;
+        }
+        if (cbase + p + len > limit) break;
+        sink(sym, ok);
+        p += len;
         ++cnt;
+        if (__builtin_expect(len > 31, 0)) {            // rebuild the buffer after a very long code
+            pos = cbase + p;
+            wnext = (pos >> 5) + 2;
+            buf = ((((u64)data[widx(pos >> 5)]) << 32) | data[widx((pos >> 5) + 1)]) << (pos & 31);
+            avail = 64 - (int)(pos & 31);
+        } else {
+            buf <<= len;
+            avail -= (int)len;
+            if (avail < 32) {
+                buf |= (u64)data[widx(wnext)] << (32 - avail);
+                avail += 32;
+                ++wnext;
+            }
+        }
     }
     return cnt;
 }
@@ -415,13 +450,177 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_count(const DecBlk *__restric
     __syncthreads();
 
     const u32 entry = ent[tid];
-    const u32 cnt = decode_chunk(data, lut, blk, tid * CH_BITS, entry, tile_bit_limit(blk, tile), [](u32, bool) {});
+    const u32 cnt = decode_chunk(data, lut, blk, tid * CH_BITS, entry, tile_bit_limit(blk, tile), 0xFFFFFFFFu, [](u32, bool) {});
     chunk_entry[gt * DEC_THREADS + tid] = (u8)entry;
     chunk_cnt[gt * DEC_THREADS + tid] = (u16)cnt;
     const u32 tot = wave_reduce_add<u32>(cnt);
     if (lane == 0) wsum[wv] = tot;
     __syncthreads();
     if (tid == 0) tile_cnt[gt] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ================================================================================================
+// Fast symbol passes (every block of the launch has Lmax <= 13): one LUT level, and an inner loop with
+// a single rare branch.  The generic loops above spend ~150 issue slots per symbol on divergent
+// control flow (level-2 test, trie fallback, end-of-stream test, refill); these spend ~25.
+// ================================================================================================
+
+// bit reader over the staged tile: 64-bit buffer, next stream bit at the MSB, >= 32 valid bits
+struct BitBuf {
+    u64 buf;
+    int avail;
+    u32 wnext;
+    __device__ __forceinline__ void init(const u32 *data, u32 pos)
+    {
+        wnext = (pos >> 5) + 2;
+        buf = ((((u64)data[widx(pos >> 5)]) << 32) | data[widx((pos >> 5) + 1)]) << (pos & 31);
+        avail = 64 - (int)(pos & 31);
+    }
+    __device__ __forceinline__ u32 peek32() const { return (u32)(buf >> 32); }
+    __device__ __forceinline__ void skip(const u32 *data, u32 len)        // len <= 31
+    {
+        buf <<= len;
+        avail -= (int)len;
+        if (avail < 32) {
+            buf |= (u64)data[widx(wnext)] << (32 - avail);
+            avail += 32;
+            ++wnext;
+        }
+    }
+};
+
+// sfd_count13: dynamic LDS: data | cmap[256] u64 | lenlut[2^13] u8 | wmap[4] u64 | ent[256] u8 | wsum[4]
+template <bool LAST>
+__device__ __forceinline__ u32 count13_loop(const u32 *data, const u8 *lenlut, u32 sh, const u32 *trie, u32 cbase,
+                                            u32 entry, u32 limit)
+{
+    u32 p = entry, cnt = 0;
+    BitBuf bb;
+    bb.init(data, cbase + p);
+    while (p < (u32)CH_BITS) {
+        u32 len = lenlut[bb.peek32() >> sh];
+        if (__builtin_expect(len == 0, 0)) len = slow_len(data, trie, cbase + p);      // incomplete table only
+        if (LAST && cbase + p + len > limit) break;
+        p += len;
+        ++cnt;
+        if (__builtin_expect(len > 31, 0)) bb.init(data, cbase + p); else bb.skip(data, len);
+    }
+    return cnt;
+}
+
+__global__ __launch_bounds__(DEC_THREADS) void sfd_count13(const DecBlk *__restrict__ blks,
+                                                           const u64 *__restrict__ chunkfn,
+                                                           const u8 *__restrict__ tile_entry,
+                                                           u8 *__restrict__ chunk_entry, u16 *__restrict__ chunk_cnt,
+                                                           u32 *__restrict__ tile_cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const DecBlk blk = blks[blockIdx.y];
+    const u32 tile = blockIdx.x;
+    if (tile >= blk.n_tiles) return;
+    u32 *data = (u32 *)smem;
+    u64 *cm = (u64 *)(smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4);
+    u8 *lenlut = (u8 *)(cm + DEC_THREADS);
+    u64 *wm = (u64 *)(lenlut + (1u << LEN_MAXK));
+    u8 *ent = (u8 *)(wm + 4);
+    u32 *wsum = (u32 *)(ent + DEC_THREADS);
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t gt = (size_t)blk.tile_base + tile;
+    const u32 K1 = blk.K1;
+
+    load_tile(data, blk, tile);
+    for (u32 i = tid; i < ((1u << K1) + 3) / 4; i += DEC_THREADS) ((u32 *)lenlut)[i] = gload<u32>((const u32 *)blk.lenlut + i);
+    cm[tid] = chunkfn[gt * DEC_THREADS + tid];
+    __syncthreads();
+    if (lane < 16) {                                   // wave maps
+        u32 v = lane;
+        for (u32 c = 0; c < 64; ++c) v = nib(cm[wv * 64 + c], v);
+        u64 m = (u64)v << (4 * lane);
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) m |= __shfl_xor(m, d, 64);
+        if (lane == 0) wm[wv] = m;
+    }
+    __syncthreads();
+    if (lane == 0) {                                   // every chunk's entry
+        u32 v = tile_entry[gt];
+        for (u32 w = 0; w < wv; ++w) v = nib(wm[w], v);
+        for (u32 c = 0; c < 64; ++c) {
+            ent[wv * 64 + c] = (u8)v;
+            v = nib(cm[wv * 64 + c], v);
+        }
+    }
+    __syncthreads();
+    const u32 entry = ent[tid];
+    const u32 limit = tile_bit_limit(blk, tile);
+    const bool last = limit < (u32)(DTILE + HALO_WORDS * 4) * 8;          // the stream ends inside this window
+    const u32 cnt = last ? count13_loop<true>(data, lenlut, 32 - K1, blk.trie, tid * CH_BITS, entry, limit)
+                         : count13_loop<false>(data, lenlut, 32 - K1, blk.trie, tid * CH_BITS, entry, limit);
+    chunk_entry[gt * DEC_THREADS + tid] = (u8)entry;
+    chunk_cnt[gt * DEC_THREADS + tid] = (u16)cnt;
+    const u32 tot = wave_reduce_add<u32>(cnt);
+    if (lane == 0) wsum[wv] = tot;
+    __syncthreads();
+    if (tid == 0) tile_cnt[gt] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// sfd_write13: dynamic LDS: data | lut13[2^13] u16 | wsum[4]
+__global__ __launch_bounds__(DEC_THREADS) void sfd_write13(const DecBlk *__restrict__ blks,
+                                                           const u8 *__restrict__ chunk_entry,
+                                                           const u16 *__restrict__ chunk_cnt,
+                                                           const u64 *__restrict__ tile_off)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const DecBlk blk = blks[blockIdx.y];
+    const u32 tile = blockIdx.x;
+    if (tile >= blk.n_tiles) return;
+    u32 *data = (u32 *)smem;
+    u16 *lut = (u16 *)(smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4);
+    u32 *wsum = (u32 *)(lut + (1u << LEN_MAXK));
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t gt = (size_t)blk.tile_base + tile;
+    const u64 toff = tile_off[gt];
+    if (toff >= blk.n_sym) return;                      // the whole tile is padding / past the end
+    const u32 K1 = blk.K1;
+
+    load_tile(data, blk, tile);
+    for (u32 i = tid; i < (1u << K1) / 2 + 1; i += DEC_THREADS)
+        if (i < ((1u << K1) + 1) / 2) ((u32 *)lut)[i] = gload<u32>((const u32 *)blk.lut13 + i);
+    const u32 entry = chunk_entry[gt * DEC_THREADS + tid];
+    const u32 cnt = chunk_cnt[gt * DEC_THREADS + tid];
+    const u32 incl = wave_incl_scan_add<u32>(cnt);
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    u32 base = 0;
+    for (u32 w = 0; w < wv; ++w) base += wsum[w];
+    const u64 first = toff + base + incl - cnt;         // global index of this chunk's first symbol
+    const u64 nsym = blk.n_sym;
+    u32 want = first >= nsym ? 0u : (nsym - first < (u64)cnt ? (u32)(nsym - first) : cnt);
+    u8 *op = blk.out + first;
+    const u32 cbase = tid * CH_BITS, sh = 32 - K1;
+    u32 p = entry, acc = 0, na = 0;
+    bool bad = false;
+    BitBuf bb;
+    bb.init(data, cbase + p);
+    while (want) {                                      // exactly the symbols counted by sfd_count13
+        const u32 e = lut[bb.peek32() >> sh];
+        u32 len = e >> 8, sym = e & 0xFF;
+        if (__builtin_expect(e == 0, 0)) {              // incomplete table only
+            const Code c = code_at(data, lut, blk.trie, 0, cbase + p, true);
+            len = c.len; sym = c.sym; bad |= !c.ok;
+        }
+        p += len;
+        --want;
+        acc |= sym << (8 * na);
+        if (++na == 4) {                                // four symbols per store (any byte alignment)
+            gstore<u32>(op, acc);
+            op += 4;
+            acc = 0;
+            na = 0;
+        }
+        if (__builtin_expect(len > 31, 0)) bb.init(data, cbase + p); else bb.skip(data, len);
+    }
+    for (u32 q = 0; q < na; ++q) gstore<u8>(op + q, (u8)(acc >> (8 * q)));
+    if (bad) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -484,27 +683,23 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_write(const DecBlk *__restric
     for (u32 w = 0; w < wv; ++w) base += wsum[w];
     const u64 first = toff + base + incl - cnt;         // global index of this chunk's first symbol
 
-    u64 gi = first;
-    u32 acc = 0;
-    bool bad = false;
+    // symbols of this chunk that fall inside the block (the stream's padding decodes to extra ones)
     const u64 nsym = blk.n_sym;
-    u8 *out = blk.out;
-    decode_chunk(data, lut, blk, tid * CH_BITS, entry, tile_bit_limit(blk, tile), [&](u32 sym, bool ok) {
-        if (gi < nsym) {
-            if (!ok) bad = true;
-            acc |= sym << (8 * ((u32)gi & 3));
-            ++gi;
-            if (((u32)gi & 3) == 0) {                   // a 4-byte group is complete
-                if (gi - 4 >= first) *(u32 *)(out + gi - 4) = acc;
-                else for (u64 q = first; q < gi; ++q) out[q] = (u8)(acc >> (8 * ((u32)q & 3)));
-                acc = 0;
-            }
+    const u32 want = first >= nsym ? 0u : (nsym - first < (u64)cnt ? (u32)(nsym - first) : cnt);
+    u8 *op = blk.out + first;
+    u32 acc = 0, na = 0;
+    bool bad = false;
+    decode_chunk(data, lut, blk, tid * CH_BITS, entry, tile_bit_limit(blk, tile), want, [&](u32 sym, bool ok) {
+        bad |= !ok;
+        acc |= sym << (8 * na);
+        if (++na == 4) {                                // four symbols per store (any byte alignment)
+            gstore<u32>(op, acc);
+            op += 4;
+            acc = 0;
+            na = 0;
         }
     });
-    if ((u32)gi & 3) {                                  // trailing partial group
-        const u64 g0 = gi & ~3ull;
-        for (u64 q = (g0 > first ? g0 : first); q < gi; ++q) out[q] = (u8)(acc >> (8 * ((u32)q & 3)));
-    }
+    for (u32 q = 0; q < na; ++q) gstore<u8>(op + q, (u8)(acc >> (8 * q)));
     if (bad) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
 }
 
@@ -516,7 +711,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_write(const DecBlk *__restric
 namespace {
 struct HostTab {
     std::vector<u32> trie;     // pairs
-    std::vector<u16> lut, lut2;
+    std::vector<u16> lut, lut2, lut13;
     std::vector<u8> lenlut;
     u32 K, K1, lmax;
     bool ok, empty;
@@ -533,6 +728,7 @@ void build_host_tab(const shafa_code_table &t, HostTab &h)
     h.lut.assign((size_t)1 << h.K, 0);
     h.K1 = h.lmax < (u32)LEN_MAXK ? (h.lmax ? h.lmax : 1) : (u32)LEN_MAXK;
     h.lenlut.assign(((size_t)1 << h.K1) + 4, 0);
+    if (h.lmax <= (u32)LEN_MAXK) h.lut13.assign(((size_t)1 << h.K1) + 2, 0);
     auto code_of = [&](int s) {
         u64 code = 0;       // only the first 32 bits are ever needed here
         const u32 L = t.len[s] < 32 ? t.len[s] : 32;
@@ -567,6 +763,8 @@ void build_host_tab(const shafa_code_table &t, HostTab &h)
             const u32 code = code_of(s);
             const u32 lo = code << (h.K1 - L), cnt = 1u << (h.K1 - L);
             memset(h.lenlut.data() + lo, (int)L, cnt);
+            if (!h.lut13.empty())
+                for (u32 i = 0; i < cnt; ++i) h.lut13[lo + i] = (u16)(s | (L << 8));
         }
     }
     if (!h.ok) return;
@@ -627,7 +825,8 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         if (ntiles[b] > max_tiles) max_tiles = ntiles[b];
         if (h.lmax > lmax_all) lmax_all = h.lmax;
         tab_bytes += ((h.lut.size() * 2 + 15) & ~(size_t)15) + ((h.trie.size() * 4 + 15) & ~(size_t)15) +
-                     ((h.lenlut.size() + 15) & ~(size_t)15) + ((h.lut2.size() * 2 + 16 + 15) & ~(size_t)15);
+                     ((h.lenlut.size() + 15) & ~(size_t)15) + ((h.lut2.size() * 2 + 16 + 15) & ~(size_t)15) +
+                     ((h.lut13.size() * 2 + 15) & ~(size_t)15);
         if (h.lut2.size() > max_l2) max_l2 = (u32)h.lut2.size();
     }
     if (!total_tiles) return SHAFA_SUCCESS;
@@ -646,6 +845,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const size_t o_cent = off; off += (size_t)total_tiles * DEC_THREADS; off = (off + 15) & ~(size_t)15;
     const size_t o_ccnt = off; off += (size_t)total_tiles * DEC_THREADS * 2; off = (off + 15) & ~(size_t)15;
     const bool packed = (R == 16);
+    const bool fast13 = lmax_all <= (u32)LEN_MAXK && !getenv("SHAFA_DEC_GENERIC");   // single-level LUT symbol passes
     const size_t o_cfn = off; off += packed ? (size_t)total_tiles * DEC_THREADS * 8 : (size_t)total_tiles * R * DEC_THREADS;
     int rc = batch_reserve(bt, off);
     if (rc) return rc;
@@ -676,6 +876,9 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         e.n_l2 = (u32)h.lut2.size();
         if (h.lut2.size()) memcpy(hs + tpos, h.lut2.data(), h.lut2.size() * 2);
         tpos += (h.lut2.size() * 2 + 16 + 15) & ~(size_t)15;
+        e.lut13 = h.lut13.empty() ? nullptr : (const u16 *)(ws + tpos);
+        if (!h.lut13.empty()) memcpy(hs + tpos, h.lut13.data(), h.lut13.size() * 2);
+        tpos += (h.lut13.size() * 2 + 15) & ~(size_t)15;
         e.lenlut = ws + tpos;
         memcpy(hs + tpos, h.lenlut.data(), h.lenlut.size());
         tpos += (h.lenlut.size() + 15) & ~(size_t)15;
@@ -709,9 +912,15 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
                            (u64 *)(ws + o_tilefn));
         hipLaunchKernelGGL(sfd_tiles16, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u64 *)(ws + o_tilefn),
                            ws + o_tent);
-        hipLaunchKernelGGL(sfd_count<true>, grid_t, dim3(DEC_THREADS), lds_count16, st, dblk, R, l2cap,
-                           (const u8 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
-                           (u32 *)(ws + o_tcnt));
+        if (fast13) {
+            const size_t lds_count13 = lds_data + DEC_THREADS * 8 + (1u << LEN_MAXK) + 32 + DEC_THREADS + 64;
+            hipLaunchKernelGGL(sfd_count13, grid_t, dim3(DEC_THREADS), lds_count13, st, dblk, (const u64 *)(ws + o_cfn),
+                               (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt), (u32 *)(ws + o_tcnt));
+        } else {
+            hipLaunchKernelGGL(sfd_count<true>, grid_t, dim3(DEC_THREADS), lds_count16, st, dblk, R, l2cap,
+                               (const u8 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
+                               (u32 *)(ws + o_tcnt));
+        }
     } else {
         hipLaunchKernelGGL(sfd_sync, grid_t, dim3(DEC_THREADS), lds_sync, st, dblk, R, l2cap, ws + o_cfn, ws + o_tilefn);
         hipLaunchKernelGGL(sfd_tiles, grid_b, dim3(DEC_THREADS), lds_tiles, st, dblk, R, (const u8 *)(ws + o_tilefn),
@@ -722,8 +931,14 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     }
     hipLaunchKernelGGL(sfd_offsets, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u32 *)(ws + o_tcnt),
                        (u64 *)(ws + o_toff));
-    hipLaunchKernelGGL(sfd_write, grid_t, dim3(DEC_THREADS), lds_write, st, dblk, l2cap, (const u8 *)(ws + o_cent),
-                       (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff));
+    if (fast13) {
+        const size_t lds_write13 = lds_data + (size_t)(1u << LEN_MAXK) * 2 + 64;
+        hipLaunchKernelGGL(sfd_write13, grid_t, dim3(DEC_THREADS), lds_write13, st, dblk, (const u8 *)(ws + o_cent),
+                           (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff));
+    } else {
+        hipLaunchKernelGGL(sfd_write, grid_t, dim3(DEC_THREADS), lds_write, st, dblk, l2cap, (const u8 *)(ws + o_cent),
+                           (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff));
+    }
     HIP_TRY(hipGetLastError());
     return SHAFA_SUCCESS;
 }
