@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument("--block-mib", type=int, default=64)
     ap.add_argument("--dist", default="zipf", choices=["zipf", "uniform"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-sample-blocks", type=int, default=4)
+    ap.add_argument("--cpu-sample-blocks", type=int, default=16)
     ap.add_argument("--encode-only", action="store_true")
     return ap.parse_args()
 

@@ -597,7 +597,8 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_write13(const DecBlk *__restr
     u32 want = first >= nsym ? 0u : (nsym - first < (u64)cnt ? (u32)(nsym - first) : cnt);
     u8 *op = blk.out + first;
     const u32 cbase = tid * CH_BITS, sh = 32 - K1;
-    u32 p = entry, acc = 0, na = 0;
+    u32 p = entry, na = 0;
+    u64 acc = 0;
     bool bad = false;
     BitBuf bb;
     bb.init(data, cbase + p);
@@ -610,15 +611,17 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_write13(const DecBlk *__restr
         }
         p += len;
         --want;
-        acc |= sym << (8 * na);
-        if (++na == 4) {                                // four symbols per store (any byte alignment)
-            gstore<u32>(op, acc);
-            op += 4;
+        acc |= (u64)sym << na;
+        na += 8;
+        if (na == 64) {                                 // eight symbols per store (any byte alignment)
+            gstore<u64>(op, acc);
+            op += 8;
             acc = 0;
             na = 0;
         }
         if (__builtin_expect(len > 31, 0)) bb.init(data, cbase + p); else bb.skip(data, len);
     }
+    na >>= 3;
     for (u32 q = 0; q < na; ++q) gstore<u8>(op + q, (u8)(acc >> (8 * q)));
     if (bad) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
 }
