@@ -50,6 +50,9 @@ struct DecBlk {
                            //   group (next nb bits index lut2[base..]) ; 0 = go to the trie
     const u16 *lut2;       // level 2 (codes of K+1 .. K+8 bits): sym | len << 8 ; 0 = go to the trie
     const u8 *lenlut;      // 2^K1 entries: len only (DP of the packed path); 0 = longer than K1 bits
+    u16 *cnt3;             // 2^K1 entries: up to three codes per window: total bits | len0 << 4 | n << 12
+    u32 *sym3;             // 2^K1 entries: sym0 | sym1 << 8 | sym2 << 16 | total bits << 24 | n << 28
+    u8 *pairlut;           // 2^(K1+1) entries: (len(p)-1) | (len(p+1)-1) << 4 from a K1+1-bit window (complete codes)
     const u16 *lut13;      // 2^K1 entries: sym | len << 8, single level (only when Lmax <= 13), else NULL
     const u32 *trie;       // pairs {child0, child1}: 0x80000000|sym = leaf, 0xFFFFFFFF = missing
     u32 K;
@@ -227,71 +230,156 @@ __device__ __noinline__ u32 slow_len(const u32 *data, const u32 *trie, u32 p)
 
 __device__ __forceinline__ u32 nib(u64 m, u32 v) { return (u32)(m >> (4 * v)) & 15u; }
 
-// sfd_sync16: dynamic LDS: data | lenlut[2^13] u8 | cmap[256] u64 | wmap[4] u64
+// packed 16-entry maps: (a then b)[d] = b[a[d]]
+__device__ __forceinline__ u64 map_compose(u64 a, u64 b)
+{
+    u64 r = 0;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) r |= (u64)nib(b, nib(a, (u32)d)) << (4 * d);
+    return r;
+}
+
+// Quarter chase over one wave's 64 chunk maps (LDS, wave-private slice `cmw`): lane (q = lane >> 4, d = lane & 15)
+// follows entry d through the 16 chunks of quarter q.  Returns Q_q[d]; when HIST, *hist gets the entry seen at each
+// of the 16 chunks (nibble c).  16 dependent LDS reads instead of 64, all 64 lanes busy.
+template <bool HIST>
+__device__ __forceinline__ u32 quarter_chase(const u64 *cmw, u64 *hist)
+{
+    const u32 lane = lane_id();
+    const u64 *src = cmw + (lane >> 4) * 16;
+    u32 v = lane & 15u, hlo = 0, hhi = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        if (HIST) { if (c < 8) hlo |= v << (4 * c); else hhi |= v << (4 * (c - 8)); }
+        v = nib(src[c], v);
+    }
+    if (HIST) *hist = ((u64)hhi << 32) | hlo;
+    return v;
+}
+// wave map from the four quarter maps held one value per lane (lanes d < 16 return W[d])
+__device__ __forceinline__ u32 wave_map_of(u32 qv)
+{
+    u32 v = lane_id() & 15u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v = __shfl(qv, q * 16 + (int)v, 64);
+    return v;
+}
+
+// copy a device table (16-byte aligned, padded to 16 bytes in the workspace) into LDS
+__device__ __forceinline__ void fill_lds16(void *dst, const void *src, u32 bytes)
+{
+    for (u32 i = threadIdx.x; i < (bytes + 15) / 16; i += DEC_THREADS)
+        ((uint4 *)dst)[i] = gload<uint4>((const uint4 *)src + i);
+}
+
+// sfd_tables: one workgroup per block expands the host tables (complete codes, Lmax <= 13) into
+//   pairlut: the two-positions-per-lookup length table of the DP, and
+//   cnt3 / sym3: up to three whole codes per K1-bit window for the symbol passes.
+__global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restrict__ blks)
+{
+    const DecBlk blk = blks[blockIdx.x];
+    if (!blk.n_tiles) return;
+    const u32 K1 = blk.K1, mask = (1u << K1) - 1;
+    for (u32 i = threadIdx.x; i < (2u << K1); i += DEC_THREADS)
+        blk.pairlut[i] = (u8)((blk.lenlut[i >> 1] - 1u) | ((blk.lenlut[i & mask] - 1u) << 4));
+    for (u32 i = threadIdx.x; i <= mask; i += DEC_THREADS) {
+        u32 pos = 0, n = 0, syms = 0, l0 = 0;
+        for (; n < 3; ++n) {
+            const u32 e = blk.lut13[(i << pos) & mask];          // window shifted left, zero filled
+            const u32 L = e >> 8;
+            if (L > K1 - pos) break;                             // would use bits outside the window
+            if (n == 0) l0 = L;
+            syms |= (e & 0xFFu) << (8 * n);
+            pos += L;
+        }
+        blk.cnt3[i] = (u16)(pos | (l0 << 4) | (n << 12));
+        blk.sym3[i] = syms | (pos << 24) | (n << 28);
+    }
+}
+
+// sfd_sync16: dynamic LDS: data | lenlut[2^13] u8 (PAIR: pairlut[2^14]) | cmap[256] u64 | wmb[64] u8
+template <bool PAIR>
 __global__ __launch_bounds__(DEC_THREADS) void sfd_sync16(const DecBlk *__restrict__ blks,
-                                                          u64 *__restrict__ chunkfn, u64 *__restrict__ tilefn)
+                                                          u64 *__restrict__ chunkfn, u64 *__restrict__ tilefn, u32 tpw)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const DecBlk blk = blks[blockIdx.y];
-    const u32 tile = blockIdx.x;
-    if (tile >= blk.n_tiles) return;
+    if (blockIdx.x * tpw >= blk.n_tiles) return;
     u32 *data = (u32 *)smem;
     u8 *lenlut = smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
-    u64 *cmap = (u64 *)(lenlut + (1u << LEN_MAXK));
-    u64 *wmap = cmap + DEC_THREADS;
+    u64 *cmap = (u64 *)(lenlut + (PAIR ? 2u : 1u) * (1u << LEN_MAXK));
+    u8 *wmb = (u8 *)(cmap + DEC_THREADS);
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 K1 = blk.K1;
 
+    fill_lds16(lenlut, PAIR ? (const void *)blk.pairlut : (const void *)blk.lenlut, PAIR ? (2u << K1) : (1u << K1));
+    const u32 tile_end = (blockIdx.x + 1) * tpw < blk.n_tiles ? (blockIdx.x + 1) * tpw : blk.n_tiles;
+    for (u32 tile = blockIdx.x * tpw; tile < tile_end; ++tile) {      // one table load serves tpw tiles
+    __syncthreads();                                   // previous tile's LDS reads are done
     load_tile(data, blk, tile);
-    for (u32 i = tid; i < (1u << K1) / 4 + 1; i += DEC_THREADS)
-        if (i < ((1u << K1) + 3) / 4) ((u32 *)lenlut)[i] = gload<u32>((const u32 *)blk.lenlut + i);
     __syncthreads();
 
     // backward DP; nibble j of `ring` = exit(p + 1 + j).  Positions 256..271 (the next chunk's first
     // bits) have exit = their offset, which is the initial ring.
     u64 ring = 0xFEDCBA9876543210ull;
     const u32 cw = tid * (CH_BITS / 32);
-    const u32 sh = 32 - K1;
     u32 w1 = data[widx(cw + 8)];
-    for (int wi = 7; wi >= 0; --wi) {
-        const u32 w0 = data[widx(cw + wi)];
-        u32 len[32];
+    if (PAIR) {
+        const u32 sh = 31 - K1;                        // K1+1-bit window: positions r and r+1
+        for (int wi = 7; wi >= 0; --wi) {
+            const u32 w0 = data[widx(cw + wi)];
+            u32 e[16];
 #pragma unroll
-        for (int r = 31; r >= 0; --r) {
-            const u32 win = r ? __builtin_amdgcn_alignbit(w0, w1, 32 - r) : w0;
-            len[r] = lenlut[win >> sh];
-        }
+            for (int q = 15; q >= 0; --q) {
+                const u32 win = q ? __builtin_amdgcn_alignbit(w0, w1, 32 - 2 * q) : w0;
+                e[q] = lenlut[win >> sh];
+            }
 #pragma unroll
-        for (int r = 31; r >= 0; --r) {
-            u32 l = len[r];
-            if (__builtin_expect(l == 0, 0)) l = slow_len(data, blk.trie, (cw + wi) * 32 + r);
-            const u32 x = nib(ring, l - 1);
-            ring = (ring << 4) | x;
+            for (int q = 15; q >= 0; --q) {
+                const u32 x1 = nib(ring, e[q] >> 4);          // position 2q+1
+                ring = (ring << 4) | x1;
+                const u32 x0 = nib(ring, e[q] & 15u);         // position 2q
+                ring = (ring << 4) | x0;
+            }
+            w1 = w0;
         }
-        w1 = w0;
+    } else {
+        const u32 sh = 32 - K1;
+        for (int wi = 7; wi >= 0; --wi) {
+            const u32 w0 = data[widx(cw + wi)];
+            u32 len[32];
+#pragma unroll
+            for (int r = 31; r >= 0; --r) {
+                const u32 win = r ? __builtin_amdgcn_alignbit(w0, w1, 32 - r) : w0;
+                len[r] = lenlut[win >> sh];
+            }
+#pragma unroll
+            for (int r = 31; r >= 0; --r) {
+                u32 l = len[r];
+                if (__builtin_expect(l == 0, 0)) l = slow_len(data, blk.trie, (cw + wi) * 32 + r);
+                const u32 x = nib(ring, l - 1);
+                ring = (ring << 4) | x;
+            }
+            w1 = w0;
+        }
     }
     // ring nibble d = exit(d) = this chunk's map
     chunkfn[((size_t)blk.tile_base + tile) * DEC_THREADS + tid] = ring;
-    cmap[tid] = ring;
-    __syncthreads();
-    // wave map: lane d (< 16) chases entry d through the wave's 64 chunks
-    if (lane < 16) {
-        u32 v = lane;
-        for (u32 c = 0; c < 64; ++c) v = nib(cmap[wv * 64 + c], v);
-        u64 m = (u64)v << (4 * lane);
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) m |= __shfl_xor(m, d, 64);
-        if (lane == 0) wmap[wv] = m;
+    cmap[tid] = ring;                                  // wave-private slice: no barrier needed before the chase
+    {
+        const u32 w = wave_map_of(quarter_chase<false>(cmap + wv * 64, nullptr));
+        if (lane < 16) wmb[wv * 16 + lane] = (u8)w;
     }
     __syncthreads();
     if (tid < 16) {
         u32 v = tid;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) v = nib(wmap[w], v);
+        for (int w = 0; w < 4; ++w) v = wmb[w * 16 + v];
         u64 m = (u64)v << (4 * tid);
 #pragma unroll
         for (int d = 1; d < 16; d <<= 1) m |= __shfl_xor(m, d, 64);
         if (tid == 0) tilefn[(size_t)blk.tile_base + tile] = m;
+    }
     }
 }
 
@@ -489,7 +577,28 @@ struct BitBuf {
     }
 };
 
-// sfd_count13: dynamic LDS: data | cmap[256] u64 | lenlut[2^13] u8 | wmap[4] u64 | ent[256] u8 | wsum[4]
+// entry offset of every chunk of the tile: quarter chase with history, wave maps through LDS, then each lane
+// picks its nibble.  cm = the tile's 256 chunk maps (LDS), hist = 256 u64 (LDS), wmb = 64 bytes (LDS).
+__device__ __forceinline__ u32 chunk_entry_of(const u64 *cm, u64 *hist, u8 *wmb, u32 tile_entry_v)
+{
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, q = lane >> 4;
+    u64 h;
+    const u32 qv = quarter_chase<true>(cm + wv * 64, &h);
+    hist[tid] = h;                                              // tid == wv*64 + q*16 + d
+    const u32 w = wave_map_of(qv);
+    if (lane < 16) wmb[wv * 16 + lane] = (u8)w;
+    __syncthreads();
+    u32 e = tile_entry_v;
+    for (u32 w2 = 0; w2 < wv; ++w2) e = wmb[w2 * 16 + e];       // entry of this wave
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {                               // entry of this lane's quarter
+        const u32 nx = __shfl(qv, k * 16 + (int)e, 64);
+        if ((u32)k < q) e = nx;
+    }
+    return nib(hist[wv * 64 + q * 16 + e], lane & 15u);
+}
+
+// sfd_count13: dynamic LDS: data | cmap[256] u64 | lenlut[2^13] u8 | hist[256] u64 | wmb[64] u8 | wsum[4]
 template <bool LAST>
 __device__ __forceinline__ u32 count13_loop(const u32 *data, const u8 *lenlut, u32 sh, const u32 *trie, u32 cbase,
                                             u32 entry, u32 limit)
@@ -508,83 +617,105 @@ __device__ __forceinline__ u32 count13_loop(const u32 *data, const u8 *lenlut, u
     return cnt;
 }
 
+// up to three codes per lookup (complete tables); the chunk tail and the last tile step one code at a time
+template <bool LAST>
+__device__ __forceinline__ u32 count3_loop(const u32 *data, const u16 *tab, u32 K1, u32 cbase, u32 entry, u32 limit)
+{
+    u32 p = entry, cnt = 0;
+    const u32 sh = 32 - K1;
+    BitBuf bb;
+    bb.init(data, cbase + p);
+    if (!LAST) {
+        const u32 stop = (u32)CH_BITS - K1;       // a window at p <= stop holds only codes that start inside the chunk
+        while (p <= stop) {
+            const u32 e = tab[bb.peek32() >> sh];
+            const u32 tot = e & 15u;
+            cnt += e >> 12;
+            p += tot;
+            bb.skip(data, tot);
+        }
+    }
+    while (p < (u32)CH_BITS) {
+        const u32 l0 = (tab[bb.peek32() >> sh] >> 4) & 15u;
+        if (LAST && cbase + p + l0 > limit) break;
+        p += l0;
+        ++cnt;
+        bb.skip(data, l0);
+    }
+    return cnt;
+}
+
+template <bool MULTI>
 __global__ __launch_bounds__(DEC_THREADS) void sfd_count13(const DecBlk *__restrict__ blks,
                                                            const u64 *__restrict__ chunkfn,
                                                            const u8 *__restrict__ tile_entry,
                                                            u8 *__restrict__ chunk_entry, u16 *__restrict__ chunk_cnt,
-                                                           u32 *__restrict__ tile_cnt)
+                                                           u32 *__restrict__ tile_cnt, u32 tpw)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const DecBlk blk = blks[blockIdx.y];
-    const u32 tile = blockIdx.x;
-    if (tile >= blk.n_tiles) return;
+    if (blockIdx.x * tpw >= blk.n_tiles) return;
     u32 *data = (u32 *)smem;
     u64 *cm = (u64 *)(smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4);
     u8 *lenlut = (u8 *)(cm + DEC_THREADS);
-    u64 *wm = (u64 *)(lenlut + (1u << LEN_MAXK));
-    u8 *ent = (u8 *)(wm + 4);
-    u32 *wsum = (u32 *)(ent + DEC_THREADS);
+    u64 *hist = (u64 *)(lenlut + (MULTI ? 2u : 1u) * (1u << LEN_MAXK));
+    u8 *wmb = (u8 *)(hist + DEC_THREADS);
+    u32 *wsum = (u32 *)(wmb + 64);
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const size_t gt = (size_t)blk.tile_base + tile;
     const u32 K1 = blk.K1;
 
+    fill_lds16(lenlut, MULTI ? (const void *)blk.cnt3 : (const void *)blk.lenlut, MULTI ? (2u << K1) : (1u << K1));
+    const u32 tile_end = (blockIdx.x + 1) * tpw < blk.n_tiles ? (blockIdx.x + 1) * tpw : blk.n_tiles;
+    for (u32 tile = blockIdx.x * tpw; tile < tile_end; ++tile) {
+    const size_t gt = (size_t)blk.tile_base + tile;
+    __syncthreads();                                   // previous tile's LDS reads are done
     load_tile(data, blk, tile);
-    for (u32 i = tid; i < ((1u << K1) + 3) / 4; i += DEC_THREADS) ((u32 *)lenlut)[i] = gload<u32>((const u32 *)blk.lenlut + i);
     cm[tid] = chunkfn[gt * DEC_THREADS + tid];
     __syncthreads();
-    if (lane < 16) {                                   // wave maps
-        u32 v = lane;
-        for (u32 c = 0; c < 64; ++c) v = nib(cm[wv * 64 + c], v);
-        u64 m = (u64)v << (4 * lane);
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) m |= __shfl_xor(m, d, 64);
-        if (lane == 0) wm[wv] = m;
-    }
-    __syncthreads();
-    if (lane == 0) {                                   // every chunk's entry
-        u32 v = tile_entry[gt];
-        for (u32 w = 0; w < wv; ++w) v = nib(wm[w], v);
-        for (u32 c = 0; c < 64; ++c) {
-            ent[wv * 64 + c] = (u8)v;
-            v = nib(cm[wv * 64 + c], v);
-        }
-    }
-    __syncthreads();
-    const u32 entry = ent[tid];
+    const u32 entry = chunk_entry_of(cm, hist, wmb, tile_entry[gt]);
     const u32 limit = tile_bit_limit(blk, tile);
     const bool last = limit < (u32)(DTILE + HALO_WORDS * 4) * 8;          // the stream ends inside this window
-    const u32 cnt = last ? count13_loop<true>(data, lenlut, 32 - K1, blk.trie, tid * CH_BITS, entry, limit)
-                         : count13_loop<false>(data, lenlut, 32 - K1, blk.trie, tid * CH_BITS, entry, limit);
+    u32 cnt;
+    if (MULTI)
+        cnt = last ? count3_loop<true>(data, (const u16 *)lenlut, K1, tid * CH_BITS, entry, limit)
+                   : count3_loop<false>(data, (const u16 *)lenlut, K1, tid * CH_BITS, entry, limit);
+    else
+        cnt = last ? count13_loop<true>(data, lenlut, 32 - K1, blk.trie, tid * CH_BITS, entry, limit)
+                   : count13_loop<false>(data, lenlut, 32 - K1, blk.trie, tid * CH_BITS, entry, limit);
     chunk_entry[gt * DEC_THREADS + tid] = (u8)entry;
     chunk_cnt[gt * DEC_THREADS + tid] = (u16)cnt;
     const u32 tot = wave_reduce_add<u32>(cnt);
     if (lane == 0) wsum[wv] = tot;
     __syncthreads();
     if (tid == 0) tile_cnt[gt] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
 }
 
-// sfd_write13: dynamic LDS: data | lut13[2^13] u16 | wsum[4]
+// sfd_write13: dynamic LDS: data | lut13[2^13] u16 (MULTI: sym3[2^13] u32) | wsum[4]
+template <bool MULTI>
 __global__ __launch_bounds__(DEC_THREADS) void sfd_write13(const DecBlk *__restrict__ blks,
                                                            const u8 *__restrict__ chunk_entry,
                                                            const u16 *__restrict__ chunk_cnt,
-                                                           const u64 *__restrict__ tile_off)
+                                                           const u64 *__restrict__ tile_off, u32 tpw, u32 dbg)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const DecBlk blk = blks[blockIdx.y];
-    const u32 tile = blockIdx.x;
-    if (tile >= blk.n_tiles) return;
+    if (blockIdx.x * tpw >= blk.n_tiles) return;
     u32 *data = (u32 *)smem;
     u16 *lut = (u16 *)(smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4);
-    u32 *wsum = (u32 *)(lut + (1u << LEN_MAXK));
+    u32 *wsum = (u32 *)(lut + (MULTI ? 2u : 1u) * (1u << LEN_MAXK));
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 K1 = blk.K1;
+    if (tile_off[(size_t)blk.tile_base + blockIdx.x * tpw] >= blk.n_sym) return;   // all padding / past the end
+    fill_lds16(lut, MULTI ? (const void *)blk.sym3 : (const void *)blk.lut13, MULTI ? (4u << K1) : (2u << K1));
+    bool bad = false;
+    const u32 tile_end = (blockIdx.x + 1) * tpw < blk.n_tiles ? (blockIdx.x + 1) * tpw : blk.n_tiles;
+    for (u32 tile = blockIdx.x * tpw; tile < tile_end; ++tile) {
     const size_t gt = (size_t)blk.tile_base + tile;
     const u64 toff = tile_off[gt];
-    if (toff >= blk.n_sym) return;                      // the whole tile is padding / past the end
-    const u32 K1 = blk.K1;
-
+    if (toff >= blk.n_sym) break;                       // uniform: the rest is padding / past the end
+    __syncthreads();                                    // previous tile's LDS reads are done
     load_tile(data, blk, tile);
-    for (u32 i = tid; i < (1u << K1) / 2 + 1; i += DEC_THREADS)
-        if (i < ((1u << K1) + 1) / 2) ((u32 *)lut)[i] = gload<u32>((const u32 *)blk.lut13 + i);
     const u32 entry = chunk_entry[gt * DEC_THREADS + tid];
     const u32 cnt = chunk_cnt[gt * DEC_THREADS + tid];
     const u32 incl = wave_incl_scan_add<u32>(cnt);
@@ -599,9 +730,28 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_write13(const DecBlk *__restr
     const u32 cbase = tid * CH_BITS, sh = 32 - K1;
     u32 p = entry, na = 0;
     u64 acc = 0;
-    bool bad = false;
     BitBuf bb;
     bb.init(data, cbase + p);
+    if (MULTI) {
+        const u32 *tab = (const u32 *)lut;
+        u32 nb = 0;                                     // bytes waiting in acc (< 4 between iterations)
+        while (want) {                                  // up to three symbols per lookup; stops on the count
+            const u32 e = tab[bb.peek32() >> sh];
+            const u32 n = (e >> 28) & 3u, take = n < want ? n : want;
+            acc |= (u64)(e & 0xFFFFFFu) << (8 * nb);
+            nb += take;
+            want -= take;
+            if (nb >= 4) {
+                if (!(dbg & 1) || acc == 0x123456789ull) gstore<u32>(op, (u32)acc);
+                op += 4;
+                acc >>= 32;
+                nb -= 4;
+            }
+            bb.skip(data, (e >> 24) & 15u);
+        }
+        for (u32 q = 0; q < nb; ++q) gstore<u8>(op + q, (u8)(acc >> (8 * q)));
+        continue;
+    }
     while (want) {                                      // exactly the symbols counted by sfd_count13
         const u32 e = lut[bb.peek32() >> sh];
         u32 len = e >> 8, sym = e & 0xFF;
@@ -623,6 +773,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_write13(const DecBlk *__restr
     }
     na >>= 3;
     for (u32 q = 0; q < na; ++q) gstore<u8>(op + q, (u8)(acc >> (8 * q)));
+    }
     if (bad) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
 }
 
@@ -717,13 +868,14 @@ struct HostTab {
     std::vector<u16> lut, lut2, lut13;
     std::vector<u8> lenlut;
     u32 K, K1, lmax;
-    bool ok, empty;
+    bool ok, empty, complete;
 };
 
 void build_host_tab(const shafa_code_table &t, HostTab &h)
 {
     h.trie.assign(2, 0xFFFFFFFFu);
     h.ok = true;
+    h.complete = false;
     h.lmax = 0;
     for (int s = 0; s < 256; ++s) h.lmax = t.len[s] > h.lmax ? t.len[s] : h.lmax;
     h.empty = h.lmax == 0;
@@ -771,6 +923,8 @@ void build_host_tab(const shafa_code_table &t, HostTab &h)
         }
     }
     if (!h.ok) return;
+    h.complete = h.lmax <= (u32)LEN_MAXK;               // every K1-bit window starts a code: pair table usable
+    for (size_t i = 0; h.complete && i < ((size_t)1 << h.K1); ++i) h.complete = h.lenlut[i] != 0;
     // level 2: group the codes of K+1..K+8 bits by their first K bits
     for (int s = 0; s < 256; ++s) {
         const u32 L = t.len[s];
@@ -812,6 +966,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     u64 total_tiles = 0;
     size_t tab_bytes = 0;
     std::vector<u32> ntiles(nblocks, 0);
+    bool pair_all = !getenv("SHAFA_DEC_NOPAIR");
     for (int b = 0; b < nblocks; ++b) {
         if ((h_in_off[b] & 15) || (h_out_off[b] & 15)) return SHAFA_OUTSIDE_MODULE;
         build_host_tab(h_tables[b], tabs[b]);
@@ -831,6 +986,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
                      ((h.lenlut.size() + 15) & ~(size_t)15) + ((h.lut2.size() * 2 + 16 + 15) & ~(size_t)15) +
                      ((h.lut13.size() * 2 + 15) & ~(size_t)15);
         if (h.lut2.size() > max_l2) max_l2 = (u32)h.lut2.size();
+        pair_all = pair_all && h.complete;
     }
     if (!total_tiles) return SHAFA_SUCCESS;
     u32 R = 16;
@@ -849,6 +1005,10 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const size_t o_ccnt = off; off += (size_t)total_tiles * DEC_THREADS * 2; off = (off + 15) & ~(size_t)15;
     const bool packed = (R == 16);
     const bool fast13 = lmax_all <= (u32)LEN_MAXK && !getenv("SHAFA_DEC_GENERIC");   // single-level LUT symbol passes
+    const bool multi = fast13 && pair_all && !getenv("SHAFA_DEC_NOMULTI");            // three codes per lookup
+    const size_t o_pair = off; off += pair_all ? (size_t)nblocks * (2u << LEN_MAXK) : 0;
+    const size_t o_cnt3 = off; off += pair_all ? (size_t)nblocks * (2u << LEN_MAXK) : 0;
+    const size_t o_sym3 = off; off += pair_all ? (size_t)nblocks * (4u << LEN_MAXK) : 0;
     const size_t o_cfn = off; off += packed ? (size_t)total_tiles * DEC_THREADS * 8 : (size_t)total_tiles * R * DEC_THREADS;
     int rc = batch_reserve(bt, off);
     if (rc) return rc;
@@ -869,6 +1029,9 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         e.err = bt->d_err + b;
         e.n_tiles = ntiles[b];
         e.tile_base = tbase;
+        e.pairlut = pair_all ? ws + o_pair + (size_t)b * (2u << LEN_MAXK) : nullptr;
+        e.cnt3 = pair_all ? (u16 *)(ws + o_cnt3 + (size_t)b * (2u << LEN_MAXK)) : nullptr;
+        e.sym3 = pair_all ? (u32 *)(ws + o_sym3 + (size_t)b * (4u << LEN_MAXK)) : nullptr;
         tbase += ntiles[b];
         if (!ntiles[b]) continue;
         HostTab &h = tabs[b];
@@ -908,17 +1071,33 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     }
     const u32 l2cap = (max_l2 + 8) & ~7u;             // level-2 LDS entries reserved after level 1
     const dim3 grid_t(max_tiles, (u32)nblocks), grid_b((u32)nblocks);
+    u32 tpw = 4;                                       // tiles per workgroup of the fast kernels (one table load)
+    if (const char *e = getenv("SHAFA_DEC_TPW")) tpw = (u32)atoi(e) > 0 ? (u32)atoi(e) : 1u;
+    while (tpw > 1 && (u64)ceil_div_u64(max_tiles, tpw) * nblocks < 2048) tpw >>= 1;     // keep the chip full
+    const dim3 grid_f((u32)ceil_div_u64(max_tiles, tpw), (u32)nblocks);
+    const u32 dbg = getenv("SHAFA_DEC_DBG") ? (u32)atoi(getenv("SHAFA_DEC_DBG")) : 0u;
     if (packed) {
-        const size_t lds_sync16 = lds_data + (1u << LEN_MAXK) + DEC_THREADS * 8 + 64;
         const size_t lds_count16 = lds_data + DEC_THREADS * 8 + lds_lut + 32 + DEC_THREADS + 64;
-        hipLaunchKernelGGL(sfd_sync16, grid_t, dim3(DEC_THREADS), lds_sync16, st, dblk, (u64 *)(ws + o_cfn),
-                           (u64 *)(ws + o_tilefn));
+        if (pair_all) {
+            hipLaunchKernelGGL(sfd_tables, grid_b, dim3(DEC_THREADS), 0, st, dblk);
+            hipLaunchKernelGGL(sfd_sync16<true>, grid_f, dim3(DEC_THREADS), lds_data + (2u << LEN_MAXK) + DEC_THREADS * 8 + 64, st, dblk,
+                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw);
+        } else {
+            hipLaunchKernelGGL(sfd_sync16<false>, grid_f, dim3(DEC_THREADS), lds_data + (1u << LEN_MAXK) + DEC_THREADS * 8 + 64, st, dblk,
+                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw);
+        }
         hipLaunchKernelGGL(sfd_tiles16, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u64 *)(ws + o_tilefn),
                            ws + o_tent);
         if (fast13) {
-            const size_t lds_count13 = lds_data + DEC_THREADS * 8 + (1u << LEN_MAXK) + 32 + DEC_THREADS + 64;
-            hipLaunchKernelGGL(sfd_count13, grid_t, dim3(DEC_THREADS), lds_count13, st, dblk, (const u64 *)(ws + o_cfn),
-                               (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt), (u32 *)(ws + o_tcnt));
+            const size_t lds_count13 = lds_data + DEC_THREADS * 16 + (multi ? 2u : 1u) * (1u << LEN_MAXK) + 64 + 16 + 64;
+            if (multi)
+                hipLaunchKernelGGL(sfd_count13<true>, grid_f, dim3(DEC_THREADS), lds_count13, st, dblk,
+                                   (const u64 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
+                                   (u32 *)(ws + o_tcnt), tpw);
+            else
+                hipLaunchKernelGGL(sfd_count13<false>, grid_f, dim3(DEC_THREADS), lds_count13, st, dblk,
+                                   (const u64 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
+                                   (u32 *)(ws + o_tcnt), tpw);
         } else {
             hipLaunchKernelGGL(sfd_count<true>, grid_t, dim3(DEC_THREADS), lds_count16, st, dblk, R, l2cap,
                                (const u8 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
@@ -935,9 +1114,13 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     hipLaunchKernelGGL(sfd_offsets, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u32 *)(ws + o_tcnt),
                        (u64 *)(ws + o_toff));
     if (fast13) {
-        const size_t lds_write13 = lds_data + (size_t)(1u << LEN_MAXK) * 2 + 64;
-        hipLaunchKernelGGL(sfd_write13, grid_t, dim3(DEC_THREADS), lds_write13, st, dblk, (const u8 *)(ws + o_cent),
-                           (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff));
+        const size_t lds_write13 = lds_data + (size_t)(1u << LEN_MAXK) * (multi ? 4 : 2) + 64;
+        if (multi)
+            hipLaunchKernelGGL(sfd_write13<true>, grid_f, dim3(DEC_THREADS), lds_write13, st, dblk,
+                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, dbg);
+        else
+            hipLaunchKernelGGL(sfd_write13<false>, grid_f, dim3(DEC_THREADS), lds_write13, st, dblk,
+                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, dbg);
     } else {
         hipLaunchKernelGGL(sfd_write, grid_t, dim3(DEC_THREADS), lds_write, st, dblk, l2cap, (const u8 *)(ws + o_cent),
                            (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff));
