@@ -38,6 +38,8 @@ constexpr int HALO_WORDS = 16;                     // 64 bytes past the tile (wi
 constexpr int DATA_WORDS = DTILE / 4 + HALO_WORDS;
 constexpr int LUT_MAXK = 11;
 constexpr int LUT2_MAX = 4096;                     // level-2 entries kept in LDS (8 KiB)
+constexpr int SYM3_MAXK = 12;                      // window of the three-codes table of sfd_write13: 16 KiB
+constexpr int LDS_DATA = (DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
 constexpr int LEN_MAXK = 13;                       // length-only LUT of the packed DP: 8 KiB
 
 struct DecBlk {
@@ -230,6 +232,16 @@ __device__ __noinline__ u32 slow_len(const u32 *data, const u32 *trie, u32 p)
 
 __device__ __forceinline__ u32 nib(u64 m, u32 v) { return (u32)(m >> (4 * v)) & 15u; }
 
+// ring = (ring << 4) | nibble (sh4 >> 2) of ring; only bits 2..5 of sh4 matter.  v_bfi merges the and + or.
+__device__ __forceinline__ u64 ring_push(u64 ring, u32 sh4)
+{
+    const u32 x = (u32)(ring >> (sh4 & 60u));
+    const u64 up = ring << 4;
+    u32 lo;
+    asm("v_bfi_b32 %0, 15, %1, %2" : "=v"(lo) : "v"(x), "v"((u32)up));
+    return (up & 0xFFFFFFFF00000000ull) | lo;
+}
+
 // packed 16-entry maps: (a then b)[d] = b[a[d]]
 __device__ __forceinline__ u64 map_compose(u64 a, u64 b)
 {
@@ -282,17 +294,26 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
     const u32 K1 = blk.K1, mask = (1u << K1) - 1;
     for (u32 i = threadIdx.x; i < (2u << K1); i += DEC_THREADS)
         blk.pairlut[i] = (u8)((blk.lenlut[i >> 1] - 1u) | ((blk.lenlut[i & mask] - 1u) << 4));
+    const u32 K3 = K1 < (u32)SYM3_MAXK ? K1 : (u32)SYM3_MAXK;
     for (u32 i = threadIdx.x; i <= mask; i += DEC_THREADS) {
-        u32 pos = 0, n = 0, syms = 0, l0 = 0;
+        u32 pos = 0, n = 0, l0 = 0;
         for (; n < 3; ++n) {
-            const u32 e = blk.lut13[(i << pos) & mask];          // window shifted left, zero filled
-            const u32 L = e >> 8;
+            const u32 L = blk.lut13[(i << pos) & mask] >> 8;     // window shifted left, zero filled
             if (L > K1 - pos) break;                             // would use bits outside the window
             if (n == 0) l0 = L;
-            syms |= (e & 0xFFu) << (8 * n);
             pos += L;
         }
         blk.cnt3[i] = (u16)(pos | (l0 << 4) | (n << 12));
+    }
+    for (u32 i = threadIdx.x; i < (1u << K3); i += DEC_THREADS) {   // K3-bit window; n = 0: first code is longer
+        u32 pos = 0, n = 0, syms = 0;
+        for (; n < 3; ++n) {
+            const u32 e = blk.lut13[((i << (K1 - K3)) << pos) & mask];
+            const u32 L = e >> 8;
+            if (L > K3 - pos) break;
+            syms |= (e & 0xFFu) << (8 * n);
+            pos += L;
+        }
         blk.sym3[i] = syms | (pos << 24) | (n << 28);
     }
 }
@@ -302,11 +323,12 @@ template <bool PAIR>
 __global__ __launch_bounds__(DEC_THREADS) void sfd_sync16(const DecBlk *__restrict__ blks,
                                                           u64 *__restrict__ chunkfn, u64 *__restrict__ tilefn, u32 tpw)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    // static LDS: constant addresses fold into the ds_read offset field (no per-lookup address add)
+    __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + (PAIR ? 2 : 1) * (1 << LEN_MAXK) + DEC_THREADS * 8 + 64];
     const DecBlk blk = blks[blockIdx.y];
     if (blockIdx.x * tpw >= blk.n_tiles) return;
     u32 *data = (u32 *)smem;
-    u8 *lenlut = smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
+    u8 *lenlut = smem + LDS_DATA;
     u64 *cmap = (u64 *)(lenlut + (PAIR ? 2u : 1u) * (1u << LEN_MAXK));
     u8 *wmb = (u8 *)(cmap + DEC_THREADS);
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -336,10 +358,8 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_sync16(const DecBlk *__restri
             }
 #pragma unroll
             for (int q = 15; q >= 0; --q) {
-                const u32 x1 = nib(ring, e[q] >> 4);          // position 2q+1
-                ring = (ring << 4) | x1;
-                const u32 x0 = nib(ring, e[q] & 15u);         // position 2q
-                ring = (ring << 4) | x0;
+                ring = ring_push(ring, e[q] >> 2);            // position 2q+1 (shift = 4 * high nibble)
+                ring = ring_push(ring, e[q] << 2);            // position 2q   (shift = 4 * low nibble)
             }
             w1 = w0;
         }
@@ -652,11 +672,11 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_count13(const DecBlk *__restr
                                                            u8 *__restrict__ chunk_entry, u16 *__restrict__ chunk_cnt,
                                                            u32 *__restrict__ tile_cnt, u32 tpw)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + DEC_THREADS * 16 + (MULTI ? 2 : 1) * (1 << LEN_MAXK) + 64 + 16 + 64];
     const DecBlk blk = blks[blockIdx.y];
     if (blockIdx.x * tpw >= blk.n_tiles) return;
     u32 *data = (u32 *)smem;
-    u64 *cm = (u64 *)(smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4);
+    u64 *cm = (u64 *)(smem + LDS_DATA);
     u8 *lenlut = (u8 *)(cm + DEC_THREADS);
     u64 *hist = (u64 *)(lenlut + (MULTI ? 2u : 1u) * (1u << LEN_MAXK));
     u8 *wmb = (u8 *)(hist + DEC_THREADS);
@@ -698,16 +718,17 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_write13(const DecBlk *__restr
                                                            const u16 *__restrict__ chunk_cnt,
                                                            const u64 *__restrict__ tile_off, u32 tpw, u32 dbg)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + (MULTI ? (4 << SYM3_MAXK) : (2 << LEN_MAXK)) + 64];
     const DecBlk blk = blks[blockIdx.y];
     if (blockIdx.x * tpw >= blk.n_tiles) return;
     u32 *data = (u32 *)smem;
-    u16 *lut = (u16 *)(smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4);
-    u32 *wsum = (u32 *)(lut + (MULTI ? 2u : 1u) * (1u << LEN_MAXK));
+    u16 *lut = (u16 *)(smem + LDS_DATA);
+    u32 *wsum = (u32 *)(smem + LDS_DATA + (MULTI ? (4 << SYM3_MAXK) : (2 << LEN_MAXK)));
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 K1 = blk.K1;
     if (tile_off[(size_t)blk.tile_base + blockIdx.x * tpw] >= blk.n_sym) return;   // all padding / past the end
-    fill_lds16(lut, MULTI ? (const void *)blk.sym3 : (const void *)blk.lut13, MULTI ? (4u << K1) : (2u << K1));
+    const u32 K3 = K1 < (u32)SYM3_MAXK ? K1 : (u32)SYM3_MAXK;
+    fill_lds16(lut, MULTI ? (const void *)blk.sym3 : (const void *)blk.lut13, MULTI ? (4u << K3) : (2u << K1));
     bool bad = false;
     const u32 tile_end = (blockIdx.x + 1) * tpw < blk.n_tiles ? (blockIdx.x + 1) * tpw : blk.n_tiles;
     for (u32 tile = blockIdx.x * tpw; tile < tile_end; ++tile) {
@@ -734,21 +755,35 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_write13(const DecBlk *__restr
     bb.init(data, cbase + p);
     if (MULTI) {
         const u32 *tab = (const u32 *)lut;
-        u32 nb = 0;                                     // bytes waiting in acc (< 4 between iterations)
+        const u32 sh3 = 32 - K3;
+        u32 nb = 0;                                     // bytes waiting in acc (< 8 between iterations)
+        u64 pend = 0;                                   // a full first half waiting for its second half
+        bool have_pend = false;
         while (want) {                                  // up to three symbols per lookup; stops on the count
-            const u32 e = tab[bb.peek32() >> sh];
-            const u32 n = (e >> 28) & 3u, take = n < want ? n : want;
-            acc |= (u64)(e & 0xFFFFFFu) << (8 * nb);
+            u32 e = tab[bb.peek32() >> sh3];
+            if (__builtin_expect((e >> 28) == 0, 0)) {  // first code longer than the window: one code from lut13
+                const u32 e1 = gload<u16>(blk.lut13 + (bb.peek32() >> sh));
+                e = (e1 & 0xFFu) | ((e1 >> 8) << 24) | (1u << 28);
+            }
+            const u32 n = e >> 28, take = n < want ? n : want, syms = e & 0xFFFFFFu;
+            acc |= (u64)syms << (8 * nb);
+            const u32 room = 8 - nb;                    // bytes of `syms` that fitted
             nb += take;
             want -= take;
-            if (nb >= 4) {
-                if (!(dbg & 1) || acc == 0x123456789ull) gstore<u32>(op, (u32)acc);
-                op += 4;
-                acc >>= 32;
-                nb -= 4;
+            if (nb >= 8) {                              // sixteen symbols per store (any byte alignment)
+                if (have_pend) {
+                    if (!(dbg & 1) || acc == 0x123456789ull) gstore<uint4>(op, make_uint4((u32)pend, (u32)(pend >> 32), (u32)acc, (u32)(acc >> 32)));
+                    op += 16;
+                } else {
+                    pend = acc;
+                }
+                have_pend = !have_pend;
+                nb -= 8;
+                acc = room < 3 ? (u64)(syms >> (8 * room)) : 0ull;
             }
             bb.skip(data, (e >> 24) & 15u);
         }
+        if (have_pend) { gstore<u64>(op, pend); op += 8; }
         for (u32 q = 0; q < nb; ++q) gstore<u8>(op + q, (u8)(acc >> (8 * q)));
         continue;
     }
@@ -1080,22 +1115,21 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         const size_t lds_count16 = lds_data + DEC_THREADS * 8 + lds_lut + 32 + DEC_THREADS + 64;
         if (pair_all) {
             hipLaunchKernelGGL(sfd_tables, grid_b, dim3(DEC_THREADS), 0, st, dblk);
-            hipLaunchKernelGGL(sfd_sync16<true>, grid_f, dim3(DEC_THREADS), lds_data + (2u << LEN_MAXK) + DEC_THREADS * 8 + 64, st, dblk,
+            hipLaunchKernelGGL(sfd_sync16<true>, grid_f, dim3(DEC_THREADS), 0, st, dblk,
                                (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw);
         } else {
-            hipLaunchKernelGGL(sfd_sync16<false>, grid_f, dim3(DEC_THREADS), lds_data + (1u << LEN_MAXK) + DEC_THREADS * 8 + 64, st, dblk,
+            hipLaunchKernelGGL(sfd_sync16<false>, grid_f, dim3(DEC_THREADS), 0, st, dblk,
                                (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw);
         }
         hipLaunchKernelGGL(sfd_tiles16, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u64 *)(ws + o_tilefn),
                            ws + o_tent);
         if (fast13) {
-            const size_t lds_count13 = lds_data + DEC_THREADS * 16 + (multi ? 2u : 1u) * (1u << LEN_MAXK) + 64 + 16 + 64;
             if (multi)
-                hipLaunchKernelGGL(sfd_count13<true>, grid_f, dim3(DEC_THREADS), lds_count13, st, dblk,
+                hipLaunchKernelGGL(sfd_count13<true>, grid_f, dim3(DEC_THREADS), 0, st, dblk,
                                    (const u64 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
                                    (u32 *)(ws + o_tcnt), tpw);
             else
-                hipLaunchKernelGGL(sfd_count13<false>, grid_f, dim3(DEC_THREADS), lds_count13, st, dblk,
+                hipLaunchKernelGGL(sfd_count13<false>, grid_f, dim3(DEC_THREADS), 0, st, dblk,
                                    (const u64 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
                                    (u32 *)(ws + o_tcnt), tpw);
         } else {
@@ -1114,12 +1148,11 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     hipLaunchKernelGGL(sfd_offsets, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u32 *)(ws + o_tcnt),
                        (u64 *)(ws + o_toff));
     if (fast13) {
-        const size_t lds_write13 = lds_data + (size_t)(1u << LEN_MAXK) * (multi ? 4 : 2) + 64;
         if (multi)
-            hipLaunchKernelGGL(sfd_write13<true>, grid_f, dim3(DEC_THREADS), lds_write13, st, dblk,
+            hipLaunchKernelGGL(sfd_write13<true>, grid_f, dim3(DEC_THREADS), 0, st, dblk,
                                (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, dbg);
         else
-            hipLaunchKernelGGL(sfd_write13<false>, grid_f, dim3(DEC_THREADS), lds_write13, st, dblk,
+            hipLaunchKernelGGL(sfd_write13<false>, grid_f, dim3(DEC_THREADS), 0, st, dblk,
                                (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, dbg);
     } else {
         hipLaunchKernelGGL(sfd_write, grid_t, dim3(DEC_THREADS), lds_write, st, dblk, l2cap, (const u8 *)(ws + o_cent),
