@@ -403,23 +403,44 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_sync16(const DecBlk *__restri
     }
 }
 
-// sfd_tiles16: per block, chase the packed tile maps
+// sfd_tiles16: per block, the entry offset of every tile.  Batches of 4096 tile maps in LDS; thread (s, d)
+// follows entry d through segment s (1/16 of the batch), thread 0 links the 16 segments, then one thread per
+// segment walks it again from its real entry: 2 * 256 + 16 dependent LDS reads per batch instead of 4096.
+constexpr int TB = 4096;
 __global__ __launch_bounds__(DEC_THREADS) void sfd_tiles16(const DecBlk *__restrict__ blks,
                                                            const u64 *__restrict__ tilefn, u8 *__restrict__ tile_entry)
 {
-    __shared__ u64 maps[DEC_THREADS];
-    __shared__ u8 ent[DEC_THREADS];
+    __shared__ u64 maps[TB];
+    __shared__ u8 ent[TB];
+    __shared__ u8 segmap[16 * 16], segent[16];
+    __shared__ u32 carry;
     const DecBlk blk = blks[blockIdx.x];
-    const u32 tid = threadIdx.x;
-    u32 v = 0;
-    for (u32 t0 = 0; t0 < blk.n_tiles; t0 += DEC_THREADS) {
-        const u32 nt = (blk.n_tiles - t0 < (u32)DEC_THREADS) ? blk.n_tiles - t0 : (u32)DEC_THREADS;
-        if (tid < nt) maps[tid] = tilefn[(size_t)blk.tile_base + t0 + tid];
+    const u32 tid = threadIdx.x, sg = tid >> 4, d = tid & 15u;
+    if (tid == 0) carry = 0;
+    for (u32 t0 = 0; t0 < blk.n_tiles; t0 += TB) {
+        const u32 nt = (blk.n_tiles - t0 < (u32)TB) ? blk.n_tiles - t0 : (u32)TB;
+        const u32 seg = (nt + 15) / 16;
+        for (u32 i = tid; i < nt; i += DEC_THREADS) maps[i] = tilefn[(size_t)blk.tile_base + t0 + i];
         __syncthreads();
-        if (tid == 0)
-            for (u32 t = 0; t < nt; ++t) { ent[t] = (u8)v; v = nib(maps[t], v); }
+        const u32 lo = sg * seg < nt ? sg * seg : nt, hi = lo + seg < nt ? lo + seg : nt;
+        {
+            u32 v = d;
+            for (u32 i = lo; i < hi; ++i) v = nib(maps[i], v);
+            segmap[sg * 16 + d] = (u8)v;
+        }
         __syncthreads();
-        if (tid < nt) tile_entry[blk.tile_base + t0 + tid] = ent[tid];
+        if (tid == 0) {
+            u32 e = carry;
+            for (u32 q = 0; q < 16; ++q) { segent[q] = (u8)e; e = segmap[q * 16 + e]; }
+            carry = e;
+        }
+        __syncthreads();
+        if (d == 0) {
+            u32 v = segent[sg];
+            for (u32 i = lo; i < hi; ++i) { ent[i] = (u8)v; v = nib(maps[i], v); }
+        }
+        __syncthreads();
+        for (u32 i = tid; i < nt; i += DEC_THREADS) tile_entry[blk.tile_base + t0 + i] = ent[i];
         __syncthreads();
     }
 }

@@ -159,13 +159,14 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
             cur[it] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
+    u32 dropmask[E3_ITEMS] = {};
     u32 pv = 0;
     if (tid < 16 && tile > 0) pv = gload<u32>(blk.in + base - 64 + 4 * tid);
     {
         const u32 x = gload<u32>((const u32 *)blk.lut + tid) & 0x7FFFFFFFu;     // absent symbols: count flagged them
         sh.lut[tid] = x;
     }
-    if (!(dbg & 32)) for (int i = tid; i < E3_SW64 + 2; i += E3_THREADS) sh.stage[i] = 0;
+    for (int i = tid; i < E3_SW64 + 2; i += E3_THREADS) sh.stage[i] = 0;
     if (tid < 16) sh.prev[tid] = pv;
     __syncthreads();                                                                           // 1
 
@@ -173,19 +174,27 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
     u64 grp[E3_ITEMS][4];
     u32 glen[E3_ITEMS];
     u32 itot[E3_ITEMS];
+    if (!full) {                                       // ragged last tile: symbols past the block encode as nothing
+#pragma unroll
+        for (int it = 0; it < E3_ITEMS; ++it) {
+            const u64 idx = base + (u64)it * (E3_THREADS * 16) + (u64)tid * 16;
+            const u32 keep = idx >= blk.n ? 0u : (blk.n - idx >= 16 ? 16u : (u32)(blk.n - idx));
+            dropmask[it] = keep >= 16 ? 0u : (0xFFFFu << keep) & 0xFFFFu;      // bytes past the block (loaded as 0)
+        }
+    }
 #pragma unroll
     for (int it = 0; it < E3_ITEMS; ++it) {
-        const u64 idx = base + (u64)it * (E3_THREADS * 16) + (u64)tid * 16;
         const u32 wds[4] = {cur[it].x, cur[it].y, cur[it].z, cur[it].w};
+        const u32 dm = dropmask[it];
         u32 tot = 0, packed = 0;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             u32 e[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                u32 x = sh.lut[(wds[g] >> (8 * j)) & 0xFFu];
-                if (!full && idx + 4 * g + j >= blk.n) x = 0;
-                e[j] = x;
+            for (int j = 0; j < 4; ++j) e[j] = sh.lut[(wds[g] >> (8 * j)) & 0xFFu];
+            if (__builtin_expect(dm != 0, 0)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if ((dm >> (4 * g + j)) & 1u) e[j] = 0;
             }
             const u32 l0 = e[0] >> 16, l1 = e[1] >> 16, l2 = e[2] >> 16, l3 = e[3] >> 16;
             const u32 a = ((e[0] & 0xFFFFu) << l1) | (e[1] & 0xFFFFu);
@@ -254,19 +263,17 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const u32 L = (glen[it] >> (8 * g)) & 0xFFu;
-                if (L && !(dbg & 4)) {                 // a group of <= 64 bits touches at most two 64-bit words
-                    const u64 Gl = grp[it][g] << (64 - L);          // left-aligned
-                    const u32 sft = q & 63, i = (q >> 6) - r0;
-                    const u64 hi = Gl >> sft;
-                    const u64 lo = sft ? (Gl << (64 - sft)) : 0ull;
-                    if (i < (u32)E3_SW64) atomicOr((unsigned long long *)&sh.stage[i], (unsigned long long)hi);
-                    if (lo && i + 1 < (u32)E3_SW64) atomicOr((unsigned long long *)&sh.stage[i + 1], (unsigned long long)lo);
-                }
+                // a group of <= 64 bits touches at most two 64-bit words; L == 0 ORs nothing
+                const u64 Gl = L ? grp[it][g] << (64 - L) : 0ull;   // left-aligned
+                const u32 sft = q & 63, i = (q >> 6) - r0;          // i == -1: only the low part is in this window
+                const u64 hi = Gl >> sft;
+                const u64 lo = (Gl << 1) << (63 - sft);             // == Gl << (64 - sft), 0 when sft == 0
+                if (i < (u32)E3_SW64) atomicOr((unsigned long long *)&sh.stage[i], (unsigned long long)hi);
+                if (lo && i + 1 < (u32)E3_SW64) atomicOr((unsigned long long *)&sh.stage[i + 1], (unsigned long long)lo);
                 q += L;
             }
         }
         __syncthreads();                                                                       // 3
-        if (dbg & 8) { if (sh.stage[tid] == 0x123456789ull) gstore<u32>(blk.out, 1u); continue; }
         // straight copy of the owned words of this window: two u64 (16 bytes) per lane
         const u32 wend = (nfull < r0 + E3_SW64) ? nfull : r0 + E3_SW64;
         if (g64 + wend > cap64) {
