@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SHAFA_HIP_ABI_VERSION 1
+#define SHAFA_HIP_ABI_VERSION 2
 
 /* utils/errors.h:5-16 (_modules_error), same numbers */
 enum shafa_error {
@@ -140,6 +140,55 @@ int shafa_hipd_finish(shafa_hipd_batch *b, void *stream, int nblocks, int *h_blo
  * orc_gen_bytes): byte i = map[r16(seed, first_index + i)] or r16 >> 8 when d_map65536 == NULL. */
 int shafa_hipd_gen_bytes(void *stream, uint64_t seed, uint64_t first_index,
                          const uint8_t *d_map65536, uint8_t *d_out, size_t n);
+
+/* =================================================================================================
+ * Layer 3 — bounded in-order block pipeline (host buffers, asynchronous).
+ *
+ * Stands where the reference's drivers start one thread per block and join them in order
+ * (multithread.c:126-194 create, :70-87 ordered write chain; callers f.c:231-356, c.c:383-411,
+ * d.c:330-345, d.c:690-740).  A pipe owns n_slots slots; each slot has a HIP stream, pinned host
+ * input/output buffers and device buffers.  Usage per block: fill shafa_pipe_in(slot), submit, and
+ * later wait on the slots in submission order.  Blocks in different slots overlap: host read,
+ * H2D copy, kernels, D2H copy and host write of neighbouring blocks run concurrently, with at
+ * most n_slots blocks in flight (the reference's read-ahead is unbounded, c.c:383).
+ * ================================================================================================= */
+typedef struct shafa_pipe shafa_pipe;
+
+enum shafa_pipe_op {
+    SHAFA_OP_HIST = 1,           /* make_freq of the input (f.c:325)                                  */
+    SHAFA_OP_RLE_ENCODE = 2,     /* block_compression + make_freq of the RLE bytes (f.c:248,310)      */
+    SHAFA_OP_SF_ENCODE = 3,      /* compress_to_buffer (c.c:91-237)                                   */
+    SHAFA_OP_SF_DECODE = 4,      /* create_tree + shafa_block_decompressor (d.c:565-569)              */
+    SHAFA_OP_RLE_DECODE = 5,     /* rle_block_decompressor (d.c:116-197)                              */
+    SHAFA_OP_SF_RLE_DECODE = 6   /* process_shafa_decomp with RLE (d.c:558-590), fused on the device  */
+};
+#define SHAFA_PIPE_INPUT_HIST 1  /* with SHAFA_OP_RLE_ENCODE: also the histogram of the input (-c f)  */
+
+typedef struct shafa_pipe_result {
+    const uint8_t *out;          /* the slot's pinned result buffer (valid until the slot is reused)  */
+    size_t out_n;                /* result bytes                                                      */
+    size_t mid_n;                /* SF_RLE_DECODE: bytes after the SF stage                           */
+    uint64_t freq[256];          /* HIST: of the input; RLE_ENCODE: of the RLE bytes                  */
+    uint64_t freq_in[256];       /* RLE_ENCODE with SHAFA_PIPE_INPUT_HIST: of the input               */
+} shafa_pipe_result;
+
+int shafa_pipe_create(int n_slots, shafa_pipe **out);
+void shafa_pipe_destroy(shafa_pipe *p);
+int shafa_pipe_slots(const shafa_pipe *p);
+
+/* Pinned input buffer of an idle slot, grown to hold `bytes`; NULL if the slot is busy or on failure. */
+uint8_t *shafa_pipe_in(shafa_pipe *p, int slot, size_t bytes);
+
+/* Enqueue `op` on the first in_n bytes of the slot's input buffer and return without waiting.
+ * table: SF ops; n_symbols: SF decodes; out_cap: SF_ENCODE result capacity (the other ops size
+ * their own results: 2n+3 for RLE_ENCODE, 64 MiB + 1 KiB for RLE decodes).  Errors of the block,
+ * including malformed tables, are reported by shafa_pipe_wait so that they surface in block order. */
+int shafa_pipe_submit(shafa_pipe *p, int slot, int op, size_t in_n, const shafa_code_table *table,
+                      size_t n_symbols, size_t out_cap, int flags);
+
+/* Wait for the slot's block, fetch its result into the pinned output buffer, mark the slot idle.
+ * Returns the block's _modules_error number. */
+int shafa_pipe_wait(shafa_pipe *p, int slot, shafa_pipe_result *res);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,16 @@ class CodeTable(C.Structure):
         return t
 
 
+class PipeResult(C.Structure):
+    """shafa_pipe_result (include/shafa_hip.h, layer 3)."""
+    _fields_ = [("out", C.c_void_p), ("out_n", C.c_size_t), ("mid_n", C.c_size_t),
+                ("freq", C.c_uint64 * 256), ("freq_in", C.c_uint64 * 256)]
+
+
+OP_HIST, OP_RLE_ENCODE, OP_SF_ENCODE, OP_SF_DECODE, OP_RLE_DECODE, OP_SF_RLE_DECODE = 1, 2, 3, 4, 5, 6
+PIPE_INPUT_HIST = 1
+
+
 class ShafaError(RuntimeError):
     def __init__(self, code, what=""):
         self.code = code
@@ -89,6 +99,16 @@ def lib():
     L.shafa_hipd_rle_decode.argtypes = [vp, vp, C.c_int, u8p, u64p, u64p, u8p, u64p, u64p, vp]
     L.shafa_hipd_finish.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.shafa_hipd_gen_bytes.argtypes = [vp, C.c_uint64, C.c_uint64, u8p, u8p, C.c_size_t]
+    L.shafa_pipe_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.shafa_pipe_destroy.argtypes = [vp]
+    L.shafa_pipe_destroy.restype = None
+    L.shafa_pipe_slots.argtypes = [vp]
+    L.shafa_pipe_in.argtypes = [vp, C.c_int, C.c_size_t]
+    L.shafa_pipe_in.restype = C.c_void_p
+    L.shafa_pipe_submit.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, tp, C.c_size_t, C.c_size_t, C.c_int]
+    L.shafa_pipe_wait.argtypes = [vp, C.c_int, C.POINTER(PipeResult)]
+    for name in ("shafa_pipe_create", "shafa_pipe_slots", "shafa_pipe_submit", "shafa_pipe_wait"):
+        getattr(L, name).restype = C.c_int
     for name in ("shafa_hip_init", "shafa_hip_hist256", "shafa_hip_rle_encode", "shafa_hip_sf_encode",
                  "shafa_hip_sf_decode", "shafa_hip_rle_decode", "shafa_hipd_batch_create",
                  "shafa_hipd_hist256", "shafa_hipd_rle_encode", "shafa_hipd_sf_encode",
@@ -238,6 +258,44 @@ class Batch:
         if raise_on_error:
             _check(rc, "hipd_finish")
         return rc, list(errs)[:nblocks]
+
+
+class Pipe:
+    """Layer 3: bounded in-order block pipeline over host buffers (shafa_pipe_*)."""
+
+    def __init__(self, n_slots):
+        self._h = C.c_void_p()
+        _check(lib().shafa_pipe_create(n_slots, C.byref(self._h)), "pipe_create")
+        self.n_slots = lib().shafa_pipe_slots(self._h)
+
+    def close(self):
+        if self._h:
+            lib().shafa_pipe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, slot, op, data, table=None, n_symbols=0, out_cap=0, flags=0):
+        a = _np_u8(data)
+        p = lib().shafa_pipe_in(self._h, slot, a.size)
+        if not p:
+            raise ShafaError(LACK_OF_MEMORY, "pipe_in (slot busy?)")
+        C.memmove(p, a.ctypes.data, a.size)
+        _check(lib().shafa_pipe_submit(self._h, slot, op, a.size, C.byref(table) if table is not None else None,
+                                       n_symbols, out_cap, flags), "pipe_submit")
+
+    def wait(self, slot, raw_rc=False):
+        """-> (rc, result bytes, PipeResult)"""
+        r = PipeResult()
+        rc = lib().shafa_pipe_wait(self._h, slot, C.byref(r))
+        if rc and not raw_rc:
+            _check(rc, "pipe_wait")
+        out = C.string_at(r.out, r.out_n) if rc == 0 and r.out_n else b""
+        return rc, out, r
 
 
 def gen_bytes(stream, seed, first_index, d_out, n, d_map=None):

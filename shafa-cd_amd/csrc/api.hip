@@ -238,6 +238,7 @@ void shafa_hip_shutdown(void)
 }
 
 static int lazy_init(void) { return g.ready ? SHAFA_SUCCESS : shafa_hip_init(0); }
+int shafa_hip_lazy_init(void) { return lazy_init(); }     /* layer 3 (pipe.hip) */
 
 static int upload(const uint8_t *in, size_t n)
 {

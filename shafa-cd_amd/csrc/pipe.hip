@@ -1,0 +1,246 @@
+// pipe.hip — layer 3 of the C-ABI: a bounded, in-order block pipeline.
+//
+// The reference starts one host thread per block and lets the reader run ahead without bound
+// (multithread.c:126-194; c.c:383-411 keeps every block's input and output resident).  Here a fixed
+// number of slots, each with its own HIP stream, pinned host buffers and device buffers, gives
+//     fread(block b+2)  ‖  H2D(block b+1)  ‖  kernels(block b)  ‖  D2H(block b-1)  ‖  fwrite(block b-2)
+// with at most n_slots blocks in flight.  The caller fills shafa_pipe_in(slot), submits, and retires
+// slots in submission order, which is the reference's ordered-write chain (multithread.c:75-86).
+#include "common.hpp"
+#include "internal.hpp"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+int shafa_set_hip_error(hipError_t e, const char *what);
+extern "C" int shafa_hip_lazy_init(void);
+
+namespace {
+
+struct Slot {
+    hipStream_t st;
+    Batch *batch;
+    u8 *h_in, *h_out;          // pinned
+    size_t h_in_cap, h_out_cap;
+    u8 *d_in, *d_out, *d_mid;  // device: input, result, SF-decoded bytes of the fused decode
+    size_t d_in_cap, d_out_cap, d_mid_cap;
+    u64 *d_small;              // [0..255] hist of the result / input, [256..511] hist of the input (-c f), [512] size, [513] mid size
+    u64 *h_small;              // pinned mirror
+    int op;
+    bool busy, want_in_hist;
+    size_t in_n, out_cap, n_symbols;
+    int rc;                    // error found while submitting
+};
+
+}  // namespace
+
+struct shafa_pipe {
+    int n_slots;
+    Slot *slots;
+};
+
+namespace {
+
+int grow_pinned(u8 **p, size_t *cap, size_t need)
+{
+    if (need <= *cap) return SHAFA_SUCCESS;
+    if (*p) { HIP_TRY(hipHostFree(*p)); *p = nullptr; *cap = 0; }
+    const size_t want = (need + 4095) & ~(size_t)4095;
+    HIP_TRY(hipHostMalloc((void **)p, want, hipHostMallocDefault));
+    *cap = want;
+    return SHAFA_SUCCESS;
+}
+
+int grow_dev(u8 **p, size_t *cap, size_t need)
+{
+    if (need <= *cap) return SHAFA_SUCCESS;
+    if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; *cap = 0; }
+    const size_t want = (need + 64 + 255) & ~(size_t)255;
+    HIP_TRY(hipMalloc((void **)p, want));
+    *cap = want;
+    return SHAFA_SUCCESS;
+}
+
+int slot_submit(Slot &s, const shafa_code_table *table)
+{
+    int rc;
+    const u64 off0[1] = {0}, in_n[1] = {s.in_n};
+    if ((rc = grow_dev(&s.d_in, &s.d_in_cap, s.in_n))) return rc;
+    if (s.in_n) HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, s.in_n, hipMemcpyHostToDevice, s.st));
+    u64 *d_size = s.d_small + 512;
+    switch (s.op) {
+    case SHAFA_OP_HIST:
+        if ((rc = hist_launch(s.batch, s.st, 1, s.d_in, off0, in_n, s.d_small))) return rc;
+        HIP_TRY(hipMemcpyAsync(s.h_small, s.d_small, 256 * sizeof(u64), hipMemcpyDeviceToHost, s.st));
+        break;
+    case SHAFA_OP_RLE_ENCODE: {
+        const size_t cap = (2 * s.in_n + 3 + 15) & ~(size_t)15;                 // f.c:244 worst case
+        if ((rc = grow_dev(&s.d_out, &s.d_out_cap, cap))) return rc;
+        if ((rc = grow_pinned(&s.h_out, &s.h_out_cap, cap))) return rc;
+        if (s.want_in_hist && (rc = hist_launch(s.batch, s.st, 1, s.d_in, off0, in_n, s.d_small + 256))) return rc;
+        const u64 ocap[1] = {cap};
+        if ((rc = rleenc_launch(s.batch, s.st, 1, s.d_in, off0, in_n, s.d_out, off0, ocap, d_size, s.d_small))) return rc;
+        HIP_TRY(hipMemcpyAsync(s.h_small, s.d_small, 514 * sizeof(u64), hipMemcpyDeviceToHost, s.st));
+        break;
+    }
+    case SHAFA_OP_SF_ENCODE: {
+        if (!table) return SHAFA_OUTSIDE_MODULE;
+        if ((rc = grow_dev(&s.d_out, &s.d_out_cap, s.out_cap + 16))) return rc;
+        if ((rc = grow_pinned(&s.h_out, &s.h_out_cap, s.out_cap))) return rc;
+        const u64 ocap[1] = {s.out_cap};
+        if ((rc = sfenc_launch(s.batch, s.st, 1, s.d_in, off0, in_n, table, s.d_out, off0, ocap, d_size))) return rc;
+        HIP_TRY(hipMemcpyAsync(s.h_small + 512, d_size, sizeof(u64), hipMemcpyDeviceToHost, s.st));
+        break;
+    }
+    case SHAFA_OP_SF_DECODE: {
+        if (!table) return SHAFA_OUTSIDE_MODULE;
+        if ((rc = grow_dev(&s.d_out, &s.d_out_cap, s.n_symbols))) return rc;
+        if ((rc = grow_pinned(&s.h_out, &s.h_out_cap, s.n_symbols))) return rc;
+        const u64 ns[1] = {s.n_symbols};
+        if ((rc = sfdec_launch(s.batch, s.st, 1, s.d_in, off0, in_n, table, ns, s.d_out, off0))) return rc;
+        if (s.n_symbols) HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, s.n_symbols, hipMemcpyDeviceToHost, s.st));
+        break;
+    }
+    case SHAFA_OP_RLE_DECODE:
+    case SHAFA_OP_SF_RLE_DECODE: {
+        const u8 *rle_in = s.d_in;
+        u64 rle_n[1] = {s.in_n};
+        if (s.op == SHAFA_OP_SF_RLE_DECODE) {                                   // d.c:565-586, fused on the device
+            if (!table) return SHAFA_OUTSIDE_MODULE;
+            if ((rc = grow_dev(&s.d_mid, &s.d_mid_cap, s.n_symbols))) return rc;
+            const u64 ns[1] = {s.n_symbols};
+            if ((rc = sfdec_launch(s.batch, s.st, 1, s.d_in, off0, in_n, table, ns, s.d_mid, off0))) return rc;
+            rle_in = s.d_mid;
+            rle_n[0] = s.n_symbols;
+        }
+        const size_t cap = SHAFA_RLE_DECODE_MAX;                                 // d.c:129-169
+        if ((rc = grow_dev(&s.d_out, &s.d_out_cap, cap))) return rc;
+        if ((rc = grow_pinned(&s.h_out, &s.h_out_cap, cap))) return rc;
+        const u64 ocap[1] = {cap};
+        if ((rc = rledec_launch(s.batch, s.st, 1, rle_in, off0, rle_n, s.d_out, off0, ocap, d_size))) return rc;
+        HIP_TRY(hipMemcpyAsync(s.h_small + 512, d_size, sizeof(u64), hipMemcpyDeviceToHost, s.st));
+        break;
+    }
+    default:
+        return SHAFA_OUTSIDE_MODULE;
+    }
+    return SHAFA_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" {
+
+int shafa_pipe_create(int n_slots, shafa_pipe **out)
+{
+    if (!out || n_slots <= 0 || n_slots > 64) return SHAFA_OUTSIDE_MODULE;
+    int rc = shafa_hip_lazy_init();
+    if (rc) return rc;
+    shafa_pipe *p = (shafa_pipe *)calloc(1, sizeof(shafa_pipe));
+    if (!p) return SHAFA_LACK_OF_MEMORY;
+    p->slots = (Slot *)calloc((size_t)n_slots, sizeof(Slot));
+    if (!p->slots) { free(p); return SHAFA_LACK_OF_MEMORY; }
+    p->n_slots = n_slots;
+    for (int i = 0; i < n_slots; ++i) {
+        Slot &s = p->slots[i];
+        shafa_hipd_batch *bh = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void **)&s.d_small, 514 * sizeof(u64));
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s.h_small, 514 * sizeof(u64), hipHostMallocDefault);
+        if (e != hipSuccess) { shafa_pipe_destroy(p); return shafa_set_hip_error(e, "shafa_pipe_create"); }
+        if ((rc = shafa_hipd_batch_create(1, (size_t)1 << 27, &bh))) { shafa_pipe_destroy(p); return rc; }
+        s.batch = (Batch *)bh;
+    }
+    *out = p;
+    return SHAFA_SUCCESS;
+}
+
+void shafa_pipe_destroy(shafa_pipe *p)
+{
+    if (!p) return;
+    hipDeviceSynchronize();
+    for (int i = 0; i < p->n_slots; ++i) {
+        Slot &s = p->slots[i];
+        if (s.batch) shafa_hipd_batch_destroy((shafa_hipd_batch *)s.batch);
+        if (s.h_in) hipHostFree(s.h_in);
+        if (s.h_out) hipHostFree(s.h_out);
+        if (s.d_in) hipFree(s.d_in);
+        if (s.d_out) hipFree(s.d_out);
+        if (s.d_mid) hipFree(s.d_mid);
+        if (s.d_small) hipFree(s.d_small);
+        if (s.h_small) hipHostFree(s.h_small);
+        if (s.st) hipStreamDestroy(s.st);
+    }
+    free(p->slots);
+    free(p);
+}
+
+int shafa_pipe_slots(const shafa_pipe *p) { return p ? p->n_slots : 0; }
+
+uint8_t *shafa_pipe_in(shafa_pipe *p, int slot, size_t bytes)
+{
+    if (!p || slot < 0 || slot >= p->n_slots || p->slots[slot].busy) return nullptr;
+    Slot &s = p->slots[slot];
+    if (grow_pinned(&s.h_in, &s.h_in_cap, bytes ? bytes : 1)) return nullptr;
+    return s.h_in;
+}
+
+int shafa_pipe_submit(shafa_pipe *p, int slot, int op, size_t in_n, const shafa_code_table *table,
+                      size_t n_symbols, size_t out_cap, int flags)
+{
+    if (!p || slot < 0 || slot >= p->n_slots) return SHAFA_OUTSIDE_MODULE;
+    Slot &s = p->slots[slot];
+    if (s.busy || in_n > s.h_in_cap) return SHAFA_OUTSIDE_MODULE;
+    s.op = op;
+    s.in_n = in_n;
+    s.n_symbols = n_symbols;
+    s.out_cap = out_cap;
+    s.want_in_hist = (flags & SHAFA_PIPE_INPUT_HIST) != 0;
+    s.busy = true;
+    s.rc = slot_submit(s, table);            // errors are reported by shafa_pipe_wait, in block order
+    return SHAFA_SUCCESS;
+}
+
+int shafa_pipe_wait(shafa_pipe *p, int slot, shafa_pipe_result *res)
+{
+    if (!p || slot < 0 || slot >= p->n_slots || !res) return SHAFA_OUTSIDE_MODULE;
+    Slot &s = p->slots[slot];
+    if (!s.busy) return SHAFA_OUTSIDE_MODULE;
+    s.busy = false;
+    memset(res, 0, sizeof(*res));
+    int rc = shafa_hipd_finish((shafa_hipd_batch *)s.batch, s.st, 1, nullptr);   // synchronises the slot's stream
+    if (s.rc) return s.rc;
+    if (rc) return rc;
+    res->out = s.h_out;
+    switch (s.op) {
+    case SHAFA_OP_HIST:
+        memcpy(res->freq, s.h_small, 256 * sizeof(u64));
+        return SHAFA_SUCCESS;
+    case SHAFA_OP_SF_DECODE:
+        res->out_n = s.n_symbols;
+        return SHAFA_SUCCESS;
+    case SHAFA_OP_RLE_ENCODE:
+        memcpy(res->freq, s.h_small, 256 * sizeof(u64));
+        if (s.want_in_hist) memcpy(res->freq_in, s.h_small + 256, 256 * sizeof(u64));
+        break;
+    case SHAFA_OP_SF_ENCODE:
+        if (s.h_small[512] > s.out_cap) return SHAFA_LACK_OF_MEMORY;
+        break;
+    case SHAFA_OP_SF_RLE_DECODE:
+        res->mid_n = s.n_symbols;
+        break;
+    default:
+        break;
+    }
+    // the result's size is only known now: fetch exactly that many bytes (other slots keep the GPU busy)
+    const size_t sz = (size_t)s.h_small[512];
+    if (sz > s.h_out_cap) return SHAFA_LACK_OF_MEMORY;
+    if (sz) {
+        HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, sz, hipMemcpyDeviceToHost, s.st));
+        HIP_TRY(hipStreamSynchronize(s.st));
+    }
+    res->out_n = sz;
+    return SHAFA_SUCCESS;
+}
+
+}  // extern "C"

@@ -769,6 +769,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_write13(const DecBlk *__restr
     const u64 nsym = blk.n_sym;
     u32 want = first >= nsym ? 0u : (nsym - first < (u64)cnt ? (u32)(nsym - first) : cnt);
     u8 *op = blk.out + first;
+    if (dbg & 2) op = (u8 *)((unsigned long long)op & ~15ull);          // timing experiment only
     const u32 cbase = tid * CH_BITS, sh = 32 - K1;
     u32 p = entry, na = 0;
     u64 acc = 0;

@@ -3,12 +3,17 @@
  * same names, arguments, path ownership and error numbers, with every per-block computation sent
  * to the GPU through the C-ABI of libshafa_hip.so:
  *
- *     reference call site                     here
- *     f.c:248  block_compression          ->  shafa_hip_rle_encode   (+ fused make_freq, f.c:310)
- *     f.c:325  make_freq                  ->  shafa_hip_hist256
- *     c.c:411  compress_to_buffer         ->  shafa_hip_sf_encode
- *     d.c:735  process_shafa_decomp       ->  shafa_hip_sf_decode (+ shafa_hip_rle_decode)
- *     d.c:342  rle_block_decompressor     ->  shafa_hip_rle_decode
+ *     reference call site                     here (ops of the layer-3 block pipeline, include/shafa_hip.h)
+ *     f.c:248  block_compression          ->  SHAFA_OP_RLE_ENCODE   (+ fused make_freq, f.c:310)
+ *     f.c:325  make_freq                  ->  SHAFA_OP_HIST / SHAFA_PIPE_INPUT_HIST
+ *     c.c:411  compress_to_buffer         ->  SHAFA_OP_SF_ENCODE
+ *     d.c:735  process_shafa_decomp       ->  SHAFA_OP_SF_DECODE / SHAFA_OP_SF_RLE_DECODE
+ *     d.c:342  rle_block_decompressor     ->  SHAFA_OP_RLE_DECODE
+ *
+ * Where the reference starts a thread per block and joins them in order (multithread.c), the
+ * drivers here keep PIPE_SLOTS blocks in flight: block b is read straight into a pinned buffer and
+ * submitted, and the oldest block is retired (waited for and written) when the slots are full.
+ * --no-multithread keeps one block in flight, like the reference's sequential mode.
  *
  * The host keeps what the reference's drivers do around those calls: block splitting, the block-0
  * RLE decision, the '@'-framed text files, ordered writes.  There is no CPU implementation of the
@@ -22,6 +27,9 @@
 
 bool NO_MULTITHREAD = false;
 bool SHAFA_VERBOSE = true;
+
+enum { PIPE_SLOTS = 3 };
+static int pipe_depth(void) { return NO_MULTITHREAD ? 1 : PIPE_SLOTS; }
 
 static double now_ms(void)
 {
@@ -140,24 +148,37 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
     char *p_rle_freq = p_rle ? shafa_add_ext(p_rle, SHAFA_FREQ_EXT) : NULL;
     char *p_freq = shafa_add_ext(*path, SHAFA_FREQ_EXT);
     uint64_t *sizes = malloc(n_blocks * sizeof(uint64_t)), *rle_sizes = malloc(n_blocks * sizeof(uint64_t));
-    uint8_t *buf = malloc(bs), *rle = malloc(2 * bs + 3);
     FILE *f_rle = NULL, *f_rle_freq = NULL, *f_freq = NULL;
     bool use_rle = true;
-    if (!p_rle || !p_rle_freq || !p_freq || !sizes || !rle_sizes || !buf || !rle) err = SHAFA_LACK_OF_MEMORY;
+    shafa_pipe *pipe = NULL;
+    shafa_pipe_result *res = malloc(sizeof(*res));
+    if (!p_rle || !p_rle_freq || !p_freq || !sizes || !rle_sizes || !res) err = SHAFA_LACK_OF_MEMORY;
+    if (!err) err = shafa_pipe_create(pipe_depth(), &pipe);
+    const uint64_t depth = pipe ? (uint64_t)shafa_pipe_slots(pipe) : 1;
 
-    for (uint64_t b = 0; b < n_blocks && !err; ++b) {
-        const uint64_t n = (b + 1 == n_blocks) ? last : bs;
-        sizes[b] = n;
-        if (fread(buf, 1, n, in) != n) { err = SHAFA_FILE_STREAM_FAILED; break; }
-        uint64_t freq[256];
-        size_t rle_n = 0;
-        if (use_rle) {
-            /* block_compression + make_freq of the RLE bytes, one GPU pass (f.c:248,310) */
-            err = shafa_hip_rle_encode(buf, n, rle, 2 * n + 3, &rle_n, freq);
-            if (err) break;
-            if (b == 0) use_rle = shafa_rle_worthwhile(n, rle_n, force_rle);   /* f.c:250-258 */
+    /* submit block `sub`, retire block `ret`; block 0 is retired alone because it decides use_rle (f.c:250-258) */
+    uint64_t sub = 0, ret = 0;
+    while (!err && ret < n_blocks) {
+        const bool can_submit = sub < n_blocks && sub - ret < depth && (sub == 0 || ret > 0);
+        if (can_submit) {
+            const uint64_t n = (sub + 1 == n_blocks) ? last : bs;
+            const int slot = (int)(sub % depth);
+            uint8_t *buf = shafa_pipe_in(pipe, slot, n);
+            if (!buf) { err = SHAFA_LACK_OF_MEMORY; break; }
+            sizes[sub] = n;
+            if (fread(buf, 1, n, in) != n) { err = SHAFA_FILE_STREAM_FAILED; break; }
+            /* block 0: RLE + both histograms (the decision is not known yet); later blocks: what is written */
+            const int op = use_rle ? SHAFA_OP_RLE_ENCODE : SHAFA_OP_HIST;
+            const int flags = (sub == 0 || force_freq) ? SHAFA_PIPE_INPUT_HIST : 0;
+            err = shafa_pipe_submit(pipe, slot, op, n, NULL, 0, 0, flags);
+            ++sub;
+            continue;
         }
-        if (b == 0) {                                                           /* f.c:262-295 */
+        const uint64_t bk = ret, n = sizes[bk];
+        err = shafa_pipe_wait(pipe, (int)(bk % depth), res);
+        if (err) break;
+        if (bk == 0) {                                                          /* f.c:250-295 */
+            use_rle = shafa_rle_worthwhile(n, res->out_n, force_rle);
             if (use_rle) {
                 f_rle = fopen(p_rle, "wb");
                 f_rle_freq = fopen(p_rle_freq, "wb");
@@ -170,18 +191,19 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
                 if (fprintf(f_freq, "@N@%lu", (unsigned long)n_blocks) < 4) { err = SHAFA_FILE_STREAM_FAILED; break; }
             }
         }
+        const bool was_rle = bk == 0 || use_rle;                                /* op the block ran with */
         if (use_rle) {
-            rle_sizes[b] = rle_n;
-            if (fwrite(rle, 1, rle_n, f_rle) != rle_n) { err = SHAFA_FILE_STREAM_FAILED; break; }
-            err = put_freq_block(f_rle_freq, rle_n, freq, b + 1 == n_blocks);
+            rle_sizes[bk] = res->out_n;
+            if (fwrite(res->out, 1, res->out_n, f_rle) != res->out_n) { err = SHAFA_FILE_STREAM_FAILED; break; }
+            err = put_freq_block(f_rle_freq, res->out_n, res->freq, bk + 1 == n_blocks);
             if (err) break;
         }
-        if (!use_rle || force_freq) {
-            err = shafa_hip_hist256(buf, n, freq);                              /* make_freq, f.c:325 */
-            if (err) break;
-            err = put_freq_block(f_freq, n, freq, b + 1 == n_blocks);
-        }
+        if (!use_rle || force_freq)                                             /* make_freq of the original, f.c:325 */
+            err = put_freq_block(f_freq, n, was_rle ? res->freq_in : res->freq, bk + 1 == n_blocks);
+        ++ret;
     }
+    shafa_pipe_destroy(pipe);
+    free(res);
     if (f_rle) fclose(f_rle);
     if (f_rle_freq) fclose(f_rle_freq);
     if (f_freq) fclose(f_freq);
@@ -197,7 +219,7 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
             p_rle = NULL;
         }
     }
-    free(p_rle); free(p_rle_freq); free(p_freq); free(sizes); free(rle_sizes); free(buf); free(rle);
+    free(p_rle); free(p_rle_freq); free(p_freq); free(sizes); free(rle_sizes);
     return (_modules_error)err;
 }
 
@@ -279,42 +301,47 @@ _modules_error shafa_compress(char **path)
     else if (!out) err = SHAFA_FILE_INACCESSIBLE;
     else if (fprintf(out, "@%lu", (unsigned long)n_blocks) < 2) err = SHAFA_FILE_STREAM_FAILED;
 
-    uint8_t *buf = NULL, *enc = NULL;
-    size_t buf_cap = 0, enc_cap = 0;
-    for (uint64_t b = 0; b < n_blocks && !err; ++b) {
-        uint64_t size = 0;
-        char *codes = NULL;
-        if (!read_block(&t, &size, &codes, SHAFA_COD_BLOCK_MAX)) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* c.c:369 */
-        const char keep = t.buf[t.pos];
-        t.buf[t.pos] = '\0';
-        shafa_code_table tab;
-        err = shafa_cod_parse(codes, &tab);                                      /* c.c:115-177 */
-        t.buf[t.pos] = keep;
-        if (err) break;
-        if (size > buf_cap) {
-            free(buf);
-            buf = malloc(size ? size : 1);
-            buf_cap = size;
+    shafa_pipe *pipe = NULL;
+    shafa_pipe_result *res = malloc(sizeof(*res));
+    if (!err && !res) err = SHAFA_LACK_OF_MEMORY;
+    if (!err) err = shafa_pipe_create(pipe_depth(), &pipe);
+    const uint64_t depth = pipe ? (uint64_t)shafa_pipe_slots(pipe) : 1;
+    uint64_t sub = 0, ret = 0;
+    while (!err && ret < n_blocks) {
+        if (sub < n_blocks && sub - ret < depth) {
+            uint64_t size = 0;
+            char *codes = NULL;
+            if (!read_block(&t, &size, &codes, SHAFA_COD_BLOCK_MAX)) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* c.c:369 */
+            const char keep = t.buf[t.pos];
+            t.buf[t.pos] = '\0';
+            shafa_code_table tab;
+            const int perr = shafa_cod_parse(codes, &tab);                       /* c.c:115-177 */
+            t.buf[t.pos] = keep;
+            const int slot = (int)(sub % depth);
+            uint8_t *buf = shafa_pipe_in(pipe, slot, size);
             if (!buf) { err = SHAFA_LACK_OF_MEMORY; break; }
+            if (fread(buf, 1, size, in) != size) { err = SHAFA_FILE_STREAM_FAILED; break; }          /* c.c:392 */
+            unsigned lmax = 0;
+            for (int q = 0; q < 256; ++q) lmax = tab.len[q] > lmax ? tab.len[q] : lmax;
+            const size_t need = (size_t)((size * (uint64_t)lmax + 7) / 8) + 16;  /* exact upper bound, not 1.05 n (c.c:58) */
+            in_sizes[sub] = size;
+            /* a malformed table is this block's error: it must surface after the earlier blocks were written */
+            out_sizes[sub] = (uint64_t)perr;
+            err = shafa_pipe_submit(pipe, slot, perr ? SHAFA_OP_HIST : SHAFA_OP_SF_ENCODE, perr ? 0 : size, &tab, 0, need, 0);
+            ++sub;
+            continue;
         }
-        if (fread(buf, 1, size, in) != size) { err = SHAFA_FILE_STREAM_FAILED; break; }          /* c.c:392 */
-        unsigned lmax = 0;
-        for (int s = 0; s < 256; ++s) lmax = tab.len[s] > lmax ? tab.len[s] : lmax;
-        const size_t need = (size_t)((size * (uint64_t)lmax + 7) / 8) + 16;      /* exact upper bound, not 1.05 n (c.c:58) */
-        if (need > enc_cap) {
-            free(enc);
-            enc = malloc(need);
-            enc_cap = need;
-            if (!enc) { err = SHAFA_LACK_OF_MEMORY; break; }
-        }
-        size_t out_n = 0;
-        err = shafa_hip_sf_encode(buf, size, &tab, enc, enc_cap, &out_n);        /* binary_coding on the GPU */
+        const int perr = (int)out_sizes[ret];
+        err = shafa_pipe_wait(pipe, (int)(ret % depth), res);                    /* binary_coding on the GPU */
+        if (perr) err = perr;
         if (err) break;
-        in_sizes[b] = size;
-        out_sizes[b] = out_n;
-        if (fprintf(out, "@%lu@", (unsigned long)out_n) < 2 || fwrite(enc, 1, out_n, out) != out_n)
+        out_sizes[ret] = res->out_n;
+        if (fprintf(out, "@%lu@", (unsigned long)res->out_n) < 2 || fwrite(res->out, 1, res->out_n, out) != res->out_n)
             err = SHAFA_FILE_STREAM_FAILED;                                      /* c.c:256-258 */
+        ++ret;
     }
+    shafa_pipe_destroy(pipe);
+    free(res);
     if (out) fclose(out);
     fclose(in);
     if (!err) {
@@ -330,7 +357,7 @@ _modules_error shafa_compress(char **path)
         *path = p_shaf;
         p_shaf = NULL;
     }
-    free(p_shaf); free(in_sizes); free(buf); free(enc); free(t.buf);
+    free(p_shaf); free(in_sizes); free(t.buf);
     return (_modules_error)err;
 }
 
@@ -369,23 +396,30 @@ _modules_error rle_decompress(char **path)
         char *skip = NULL;
         if (!read_block(&t, &sizes[b], &skip, SHAFA_FREQ_BLOCK_MAX)) err = SHAFA_FILE_STREAM_FAILED;
     }
-    uint8_t *buf = NULL, *dec = malloc(SHAFA_RLE_DECODE_MAX);
-    size_t buf_cap = 0;
-    if (!err && !dec) err = SHAFA_LACK_OF_MEMORY;
-    for (uint64_t b = 0; b < n_blocks && !err; ++b) {
-        if (sizes[b] > buf_cap) {
-            free(buf);
-            buf = malloc(sizes[b] ? sizes[b] : 1);
-            buf_cap = sizes[b];
+    shafa_pipe *pipe = NULL;
+    shafa_pipe_result *res = malloc(sizeof(*res));
+    if (!err && !res) err = SHAFA_LACK_OF_MEMORY;
+    if (!err) err = shafa_pipe_create(pipe_depth(), &pipe);
+    const uint64_t depth = pipe ? (uint64_t)shafa_pipe_slots(pipe) : 1;
+    uint64_t sub = 0, ret = 0;
+    while (!err && ret < n_blocks) {
+        if (sub < n_blocks && sub - ret < depth) {
+            const int slot = (int)(sub % depth);
+            uint8_t *buf = shafa_pipe_in(pipe, slot, sizes[sub]);
             if (!buf) { err = SHAFA_LACK_OF_MEMORY; break; }
+            if (fread(buf, 1, sizes[sub], in) != sizes[sub]) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* d.c:84 */
+            err = shafa_pipe_submit(pipe, slot, SHAFA_OP_RLE_DECODE, sizes[sub], NULL, 0, 0, 0);   /* rle_block_decompressor */
+            ++sub;
+            continue;
         }
-        if (fread(buf, 1, sizes[b], in) != sizes[b]) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* d.c:84 */
-        size_t n = 0;
-        err = shafa_hip_rle_decode(buf, sizes[b], dec, SHAFA_RLE_DECODE_MAX, &n);      /* rle_block_decompressor */
+        err = shafa_pipe_wait(pipe, (int)(ret % depth), res);
         if (err) break;
-        finals[b] = n;
-        if (fwrite(dec, 1, n, out) != n) err = SHAFA_FILE_STREAM_FAILED;
+        finals[ret] = res->out_n;
+        if (fwrite(res->out, 1, res->out_n, out) != res->out_n) err = SHAFA_FILE_STREAM_FAILED;
+        ++ret;
     }
+    shafa_pipe_destroy(pipe);
+    free(res);
     if (out) fclose(out);
     fclose(in);
     if (!err) {
@@ -394,7 +428,7 @@ _modules_error rle_decompress(char **path)
         *path = p_out;
         p_out = NULL;
     }
-    free(p_out); free(p_freq); free(sizes); free(buf); free(dec); free(t.buf);
+    free(p_out); free(p_freq); free(sizes); free(t.buf);
     return (_modules_error)err;
 }
 
@@ -435,47 +469,46 @@ _modules_error shafa_decompress(char **path, bool decompress_rle)
     uint64_t *sf_sizes = !err ? malloc((n_blocks ? n_blocks : 1) * 3 * sizeof(uint64_t)) : NULL;
     uint64_t *sizes = sf_sizes ? sf_sizes + n_blocks : NULL, *finals = sf_sizes ? sf_sizes + 2 * n_blocks : NULL;
     if (!err && !sf_sizes) err = SHAFA_LACK_OF_MEMORY;
-    uint8_t *payload = NULL, *sym = NULL, *dec = decompress_rle ? malloc(SHAFA_RLE_DECODE_MAX) : NULL;
-    size_t pay_cap = 0, sym_cap = 0;
-    if (!err && decompress_rle && !dec) err = SHAFA_LACK_OF_MEMORY;
-    for (uint64_t b = 0; b < n_blocks && !err; ++b) {
-        uint64_t sf_n = 0, n_sym = 0;
-        if (!shaf_read_u64(in, '@', &sf_n, true)) { err = SHAFA_FILE_STREAM_FAILED; break; }     /* d.c:697 */
-        if (sf_n > pay_cap) {
-            free(payload);
-            payload = malloc(sf_n ? sf_n : 1);
-            pay_cap = sf_n;
+    shafa_pipe *pipe = NULL;
+    shafa_pipe_result *res = malloc(sizeof(*res));
+    if (!err && !res) err = SHAFA_LACK_OF_MEMORY;
+    if (!err) err = shafa_pipe_create(pipe_depth(), &pipe);
+    const uint64_t depth = pipe ? (uint64_t)shafa_pipe_slots(pipe) : 1;
+    uint64_t sub = 0, ret = 0;
+    while (!err && ret < n_blocks) {
+        if (sub < n_blocks && sub - ret < depth) {
+            uint64_t sf_n = 0, n_sym = 0;
+            if (!shaf_read_u64(in, '@', &sf_n, true)) { err = SHAFA_FILE_STREAM_FAILED; break; }     /* d.c:697 */
+            const int slot = (int)(sub % depth);
+            uint8_t *payload = shafa_pipe_in(pipe, slot, sf_n);
             if (!payload) { err = SHAFA_LACK_OF_MEMORY; break; }
+            if (fread(payload, 1, sf_n, in) != sf_n) { err = SHAFA_FILE_STREAM_FAILED; break; }       /* d.c:706 */
+            char *codes = NULL;
+            if (!read_block(&t, &n_sym, &codes, SHAFA_COD_BLOCK_MAX)) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* d.c:709,716 */
+            const char keep = t.buf[t.pos];
+            t.buf[t.pos] = '\0';
+            shafa_code_table tab;
+            const int perr = shafa_cod_parse(codes, &tab);
+            t.buf[t.pos] = keep;
+            sf_sizes[sub] = sf_n;
+            sizes[sub] = n_sym;
+            finals[sub] = (uint64_t)perr;                /* this block's own error, reported in block order */
+            /* shafa_block_decompressor (+ rle_block_decompressor, d.c:574-586) */
+            err = shafa_pipe_submit(pipe, slot, perr ? SHAFA_OP_HIST : (decompress_rle ? SHAFA_OP_SF_RLE_DECODE : SHAFA_OP_SF_DECODE),
+                                    perr ? 0 : sf_n, &tab, n_sym, 0, 0);
+            ++sub;
+            continue;
         }
-        if (fread(payload, 1, sf_n, in) != sf_n) { err = SHAFA_FILE_STREAM_FAILED; break; }       /* d.c:706 */
-        char *codes = NULL;
-        if (!read_block(&t, &n_sym, &codes, SHAFA_COD_BLOCK_MAX)) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* d.c:709,716 */
-        const char keep = t.buf[t.pos];
-        t.buf[t.pos] = '\0';
-        shafa_code_table tab;
-        err = shafa_cod_parse(codes, &tab);
-        t.buf[t.pos] = keep;
+        const int perr = (int)finals[ret];
+        err = shafa_pipe_wait(pipe, (int)(ret % depth), res);
+        if (perr) err = perr;
         if (err) break;
-        if (n_sym > sym_cap) {
-            free(sym);
-            sym = malloc(n_sym ? n_sym : 1);
-            sym_cap = n_sym;
-            if (!sym) { err = SHAFA_LACK_OF_MEMORY; break; }
-        }
-        err = shafa_hip_sf_decode(payload, sf_n, &tab, sym, n_sym);                   /* shafa_block_decompressor */
-        if (err) break;
-        sf_sizes[b] = sf_n;
-        sizes[b] = n_sym;
-        const uint8_t *wr = sym;
-        size_t wr_n = n_sym;
-        if (decompress_rle) {                                                          /* d.c:574-586 */
-            err = shafa_hip_rle_decode(sym, n_sym, dec, SHAFA_RLE_DECODE_MAX, &wr_n);
-            if (err) break;
-            wr = dec;
-            finals[b] = wr_n;
-        }
-        if (fwrite(wr, 1, wr_n, out) != wr_n) err = SHAFA_FILE_STREAM_FAILED;
+        finals[ret] = res->out_n;
+        if (fwrite(res->out, 1, res->out_n, out) != res->out_n) err = SHAFA_FILE_STREAM_FAILED;
+        ++ret;
     }
+    shafa_pipe_destroy(pipe);
+    free(res);
     if (out) fclose(out);
     fclose(in);
     if (!err) {
@@ -484,6 +517,6 @@ _modules_error shafa_decompress(char **path, bool decompress_rle)
         *path = p_out;
         p_out = NULL;
     }
-    free(p_out); free(p_tmp); free(p_cod); free(sf_sizes); free(payload); free(sym); free(dec); free(t.buf);
+    free(p_out); free(p_tmp); free(p_cod); free(sf_sizes); free(t.buf);
     return (_modules_error)err;
 }

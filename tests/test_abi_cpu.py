@@ -17,16 +17,16 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 def declared_symbols(header):
     with open(header) as f:
         text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
-    return sorted(set(re.findall(r"\b(shafa_hipd?_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(shafa_(?:hipd?|pipe)_\w+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol(shafa):
     syms = declared_symbols(os.path.join(ROOT, "include", "shafa_hip.h"))
-    assert len(syms) >= 18, syms
+    assert len(syms) >= 24, syms
     L = ctypes.CDLL(shafa.LIB_PATH)
     missing = [s for s in syms if not hasattr(L, s)]
     assert not missing, f"declared in include/shafa_hip.h but not exported: {missing}"
-    assert L.shafa_hip_abi_version() == 1
+    assert L.shafa_hip_abi_version() == 2
     assert ctypes.sizeof(shafa.CodeTable) == 256 + 256 * 32
 
 

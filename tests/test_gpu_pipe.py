@@ -1,0 +1,115 @@
+"""GPU parity tests, part 3: the layer-3 block pipeline (shafa_pipe_*).  Every op
+of the pipeline is checked bit-exactly against the oracle while several blocks are in flight, and
+results must come back in submission order whatever the per-block sizes."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import streams, to_shafa_table
+
+pytestmark = pytest.mark.gpu
+
+
+def blocks_of(oracle, shafa, count, base):
+    import golden.make_golden as mg
+    zt = shafa.zipf_table(1.2)
+    s = streams(oracle, shafa)
+    out = []
+    for i in range(count):
+        n = base + 7919 * i * (i % 3)                       # different sizes so slots finish out of step
+        out.append(mg.runs_stream(100 + i, n, zt) if i % 2 else s["zipf"](n))
+    return out
+
+
+def test_pipe_every_op_matches_oracle_with_blocks_in_flight(oracle, shafa):
+    blocks = blocks_of(oracle, shafa, 7, 300000)
+    pipe = shafa.Pipe(3)
+    assert pipe.n_slots == 3
+    # encode side: RLE (+ both histograms), then SF encode of the RLE bytes
+    rle, tabs, enc = [], [], []
+
+    def run(n_items, submit, retire):
+        sub = ret = 0
+        while ret < n_items:
+            if sub < n_items and sub - ret < pipe.n_slots:
+                submit(sub, sub % pipe.n_slots)
+                sub += 1
+            else:
+                retire(ret, ret % pipe.n_slots)
+                ret += 1
+
+    def ret_rle(i, slot):
+        rc, out, r = pipe.wait(slot)
+        want = oracle.rle_encode(blocks[i])
+        assert out == want.tobytes(), f"block {i}: rle bytes differ"
+        assert list(r.freq) == list(oracle.hist256(want)), f"block {i}: rle histogram"
+        assert list(r.freq_in) == list(oracle.hist256(blocks[i])), f"block {i}: input histogram"
+        rle.append(np.frombuffer(out, dtype=np.uint8))
+
+    run(len(blocks), lambda i, slot: pipe.submit(slot, shafa.OP_RLE_ENCODE, blocks[i], flags=shafa.PIPE_INPUT_HIST), ret_rle)
+
+    def ret_hist(i, slot):
+        rc, out, r = pipe.wait(slot)
+        assert list(r.freq) == list(oracle.hist256(blocks[i])), f"block {i}: hist"
+
+    run(len(blocks), lambda i, slot: pipe.submit(slot, shafa.OP_HIST, blocks[i]), ret_hist)
+
+    for b in rle:
+        tabs.append(oracle.sf_build(oracle.hist256(b)))
+
+    def sub_enc(i, slot):
+        lmax = max(to_shafa_table(shafa, tabs[i]).lens())
+        pipe.submit(slot, shafa.OP_SF_ENCODE, rle[i], table=to_shafa_table(shafa, tabs[i]), out_cap=(len(rle[i]) * lmax + 7) // 8 + 16)
+
+    def ret_enc(i, slot):
+        rc, out, r = pipe.wait(slot)
+        orc, want = oracle.sf_encode(rle[i], tabs[i])
+        assert orc == 0 and out == want.tobytes(), f"block {i}: sf payload differs"
+        enc.append(np.frombuffer(out, dtype=np.uint8))
+
+    run(len(blocks), sub_enc, ret_enc)
+
+    # decode side: SF only, RLE only, and the fused SF+RLE op
+    def ret_sfdec(i, slot):
+        rc, out, r = pipe.wait(slot)
+        assert out == rle[i].tobytes(), f"block {i}: sf decode"
+
+    run(len(blocks), lambda i, slot: pipe.submit(slot, shafa.OP_SF_DECODE, enc[i], table=to_shafa_table(shafa, tabs[i]),
+                                                 n_symbols=len(rle[i])), ret_sfdec)
+
+    def ret_rledec(i, slot):
+        rc, out, r = pipe.wait(slot)
+        assert out == blocks[i].tobytes(), f"block {i}: rle decode"
+
+    run(len(blocks), lambda i, slot: pipe.submit(slot, shafa.OP_RLE_DECODE, rle[i]), ret_rledec)
+
+    def ret_fused(i, slot):
+        rc, out, r = pipe.wait(slot)
+        assert r.mid_n == len(rle[i])
+        assert out == blocks[i].tobytes(), f"block {i}: fused sf+rle decode"
+
+    run(len(blocks), lambda i, slot: pipe.submit(slot, shafa.OP_SF_RLE_DECODE, enc[i], table=to_shafa_table(shafa, tabs[i]),
+                                                 n_symbols=len(rle[i])), ret_fused)
+    pipe.close()
+
+
+def test_pipe_errors_surface_at_wait_in_block_order(oracle, shafa):
+    s = streams(oracle, shafa)
+    good = s["zipf"](50000)
+    tab = oracle.sf_build(oracle.hist256(good))
+    _, enc = oracle.sf_encode(good, tab)
+    pipe = shafa.Pipe(2)
+    # slot 0: fine; slot 1: truncated stream -> FILE_UNRECOGNIZABLE at wait(1), not at submit
+    pipe.submit(0, shafa.OP_SF_DECODE, enc, table=to_shafa_table(shafa, tab), n_symbols=len(good))
+    pipe.submit(1, shafa.OP_SF_DECODE, enc[: len(enc) // 2], table=to_shafa_table(shafa, tab), n_symbols=len(good))
+    rc0, out0, _ = pipe.wait(0, raw_rc=True)
+    rc1, out1, _ = pipe.wait(1, raw_rc=True)
+    assert rc0 == 0 and out0 == good.tobytes()
+    assert rc1 == shafa.FILE_UNRECOGNIZABLE
+    # a busy slot refuses a second submit; an idle slot refuses wait
+    pipe.submit(0, shafa.OP_HIST, good)
+    with pytest.raises(shafa.ShafaError):
+        pipe.submit(0, shafa.OP_HIST, good)
+    pipe.wait(0)
+    rc, _, _ = pipe.wait(0, raw_rc=True)
+    assert rc == shafa.OUTSIDE_MODULE
+    pipe.close()
