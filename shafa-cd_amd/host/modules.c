@@ -21,6 +21,7 @@
  */
 #include "shafa_host.h"
 
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -28,8 +29,114 @@
 bool NO_MULTITHREAD = false;
 bool SHAFA_VERBOSE = true;
 
+/* SHAFA_TRACE=1: stage timings on stderr (diagnostics only) */
+static void trace(const char *what, double t0)
+{
+    static int on = -1;
+    if (on < 0) on = getenv("SHAFA_TRACE") != NULL;
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    if (on) fprintf(stderr, "[trace] %-28s %9.2f ms\n", what, ts.tv_sec * 1e3 + ts.tv_nsec / 1e6 - t0);
+}
+
 enum { PIPE_SLOTS = 3 };
 static int pipe_depth(void) { return NO_MULTITHREAD ? 1 : PIPE_SLOTS; }
+
+/* ------------------------------------------------------------------ ordered writer
+ * The reference's write callbacks run in block order on the worker threads (multithread.c:75-86).
+ * Here one writer thread takes "@size@" + payload jobs in order, so the main thread can already
+ * read the next block while the previous result is written.  With --no-multithread the jobs are
+ * written inline.  A job's payload is a slot's pinned result buffer: the slot must not be
+ * submitted again before writer_wait() on the job's ticket. */
+typedef struct { FILE *f; char hdr[40]; size_t hdr_n; const uint8_t *data; size_t n; } wjob;
+typedef struct {
+    pthread_t th;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    wjob q[8];
+    uint64_t pushed, done;
+    int err;
+    bool threaded, stop;
+} writer_t;
+
+static int wjob_run(const wjob *j)
+{
+    if (j->hdr_n && fwrite(j->hdr, 1, j->hdr_n, j->f) != j->hdr_n) return SHAFA_FILE_STREAM_FAILED;
+    if (j->n && fwrite(j->data, 1, j->n, j->f) != j->n) return SHAFA_FILE_STREAM_FAILED;
+    return SHAFA_SUCCESS;
+}
+
+static void *writer_main(void *arg)
+{
+    writer_t *w = arg;
+    pthread_mutex_lock(&w->mu);
+    for (;;) {
+        while (w->done == w->pushed && !w->stop) pthread_cond_wait(&w->cv, &w->mu);
+        if (w->done == w->pushed) break;
+        const wjob j = w->q[w->done % 8];
+        pthread_mutex_unlock(&w->mu);
+        const int e = wjob_run(&j);
+        pthread_mutex_lock(&w->mu);
+        if (e && !w->err) w->err = e;
+        ++w->done;
+        pthread_cond_broadcast(&w->cv);
+    }
+    pthread_mutex_unlock(&w->mu);
+    return NULL;
+}
+
+static void writer_start(writer_t *w)
+{
+    memset(w, 0, sizeof(*w));
+    pthread_mutex_init(&w->mu, NULL);
+    pthread_cond_init(&w->cv, NULL);
+    w->threaded = !NO_MULTITHREAD && pthread_create(&w->th, NULL, writer_main, w) == 0;
+}
+
+/* returns the job's ticket (>= 1) */
+static uint64_t writer_push(writer_t *w, FILE *f, const char *hdr, const uint8_t *data, size_t n)
+{
+    wjob j = {.f = f, .data = data, .n = n};
+    j.hdr_n = hdr ? strlen(hdr) : 0;
+    if (j.hdr_n) memcpy(j.hdr, hdr, j.hdr_n);
+    if (!w->threaded) {
+        const int e = wjob_run(&j);
+        if (e && !w->err) w->err = e;
+        return ++w->pushed, ++w->done;
+    }
+    pthread_mutex_lock(&w->mu);
+    while (w->pushed - w->done == 8) pthread_cond_wait(&w->cv, &w->mu);
+    w->q[w->pushed % 8] = j;
+    const uint64_t t = ++w->pushed;
+    pthread_cond_broadcast(&w->cv);
+    pthread_mutex_unlock(&w->mu);
+    return t;
+}
+
+/* wait until job `ticket` is on disk; returns the first write error so far */
+static int writer_wait(writer_t *w, uint64_t ticket)
+{
+    if (!w->threaded) return w->err;
+    pthread_mutex_lock(&w->mu);
+    while (w->done < ticket) pthread_cond_wait(&w->cv, &w->mu);
+    const int e = w->err;
+    pthread_mutex_unlock(&w->mu);
+    return e;
+}
+
+static int writer_stop(writer_t *w)
+{
+    if (w->threaded) {
+        pthread_mutex_lock(&w->mu);
+        w->stop = true;
+        pthread_cond_broadcast(&w->cv);
+        pthread_mutex_unlock(&w->mu);
+        pthread_join(w->th, NULL);
+    }
+    pthread_mutex_destroy(&w->mu);
+    pthread_cond_destroy(&w->cv);
+    return w->err;
+}
 
 static double now_ms(void)
 {
@@ -157,7 +264,9 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
     const uint64_t depth = pipe ? (uint64_t)shafa_pipe_slots(pipe) : 1;
 
     /* submit block `sub`, retire block `ret`; block 0 is retired alone because it decides use_rle (f.c:250-258) */
-    uint64_t sub = 0, ret = 0;
+    uint64_t sub = 0, ret = 0, ticket[PIPE_SLOTS] = {0};
+    writer_t wr;
+    writer_start(&wr);
     while (!err && ret < n_blocks) {
         const bool can_submit = sub < n_blocks && sub - ret < depth && (sub == 0 || ret > 0);
         if (can_submit) {
@@ -170,6 +279,7 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
             /* block 0: RLE + both histograms (the decision is not known yet); later blocks: what is written */
             const int op = use_rle ? SHAFA_OP_RLE_ENCODE : SHAFA_OP_HIST;
             const int flags = (sub == 0 || force_freq) ? SHAFA_PIPE_INPUT_HIST : 0;
+            if ((err = writer_wait(&wr, ticket[slot]))) break;                  /* the slot's previous result is on disk */
             err = shafa_pipe_submit(pipe, slot, op, n, NULL, 0, 0, flags);
             ++sub;
             continue;
@@ -194,13 +304,17 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
         const bool was_rle = bk == 0 || use_rle;                                /* op the block ran with */
         if (use_rle) {
             rle_sizes[bk] = res->out_n;
-            if (fwrite(res->out, 1, res->out_n, f_rle) != res->out_n) { err = SHAFA_FILE_STREAM_FAILED; break; }
+            ticket[bk % depth] = writer_push(&wr, f_rle, NULL, res->out, res->out_n);
             err = put_freq_block(f_rle_freq, res->out_n, res->freq, bk + 1 == n_blocks);
             if (err) break;
         }
         if (!use_rle || force_freq)                                             /* make_freq of the original, f.c:325 */
             err = put_freq_block(f_freq, n, was_rle ? res->freq_in : res->freq, bk + 1 == n_blocks);
         ++ret;
+    }
+    {
+        const int werr = writer_stop(&wr);
+        if (!err) err = werr;
     }
     shafa_pipe_destroy(pipe);
     free(res);
@@ -304,9 +418,13 @@ _modules_error shafa_compress(char **path)
     shafa_pipe *pipe = NULL;
     shafa_pipe_result *res = malloc(sizeof(*res));
     if (!err && !res) err = SHAFA_LACK_OF_MEMORY;
+    trace("C: files open", t0);
     if (!err) err = shafa_pipe_create(pipe_depth(), &pipe);
+    trace("C: pipe created", t0);
     const uint64_t depth = pipe ? (uint64_t)shafa_pipe_slots(pipe) : 1;
-    uint64_t sub = 0, ret = 0;
+    uint64_t sub = 0, ret = 0, ticket[PIPE_SLOTS] = {0};
+    writer_t wr;
+    writer_start(&wr);
     while (!err && ret < n_blocks) {
         if (sub < n_blocks && sub - ret < depth) {
             uint64_t size = 0;
@@ -327,20 +445,32 @@ _modules_error shafa_compress(char **path)
             in_sizes[sub] = size;
             /* a malformed table is this block's error: it must surface after the earlier blocks were written */
             out_sizes[sub] = (uint64_t)perr;
+            trace("C:   read", t0);
+            if ((err = writer_wait(&wr, ticket[slot]))) break;                  /* the slot's previous result is on disk */
             err = shafa_pipe_submit(pipe, slot, perr ? SHAFA_OP_HIST : SHAFA_OP_SF_ENCODE, perr ? 0 : size, &tab, 0, need, 0);
+            trace("C:   submitted", t0);
             ++sub;
             continue;
         }
         const int perr = (int)out_sizes[ret];
         err = shafa_pipe_wait(pipe, (int)(ret % depth), res);                    /* binary_coding on the GPU */
+        trace("C:   waited", t0);
         if (perr) err = perr;
         if (err) break;
         out_sizes[ret] = res->out_n;
-        if (fprintf(out, "@%lu@", (unsigned long)res->out_n) < 2 || fwrite(res->out, 1, res->out_n, out) != res->out_n)
-            err = SHAFA_FILE_STREAM_FAILED;                                      /* c.c:256-258 */
+        char hdr[40];
+        snprintf(hdr, sizeof(hdr), "@%lu@", (unsigned long)res->out_n);         /* c.c:256-258 */
+        ticket[ret % depth] = writer_push(&wr, out, hdr, res->out, res->out_n);
+        trace("C:   write queued", t0);
         ++ret;
     }
+    {
+        const int werr = writer_stop(&wr);
+        if (!err) err = werr;
+    }
+    trace("C: loop done", t0);
     shafa_pipe_destroy(pipe);
+    trace("C: pipe destroyed", t0);
     free(res);
     if (out) fclose(out);
     fclose(in);
@@ -401,13 +531,16 @@ _modules_error rle_decompress(char **path)
     if (!err && !res) err = SHAFA_LACK_OF_MEMORY;
     if (!err) err = shafa_pipe_create(pipe_depth(), &pipe);
     const uint64_t depth = pipe ? (uint64_t)shafa_pipe_slots(pipe) : 1;
-    uint64_t sub = 0, ret = 0;
+    uint64_t sub = 0, ret = 0, ticket[PIPE_SLOTS] = {0};
+    writer_t wr;
+    writer_start(&wr);
     while (!err && ret < n_blocks) {
         if (sub < n_blocks && sub - ret < depth) {
             const int slot = (int)(sub % depth);
             uint8_t *buf = shafa_pipe_in(pipe, slot, sizes[sub]);
             if (!buf) { err = SHAFA_LACK_OF_MEMORY; break; }
             if (fread(buf, 1, sizes[sub], in) != sizes[sub]) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* d.c:84 */
+            if ((err = writer_wait(&wr, ticket[slot]))) break;
             err = shafa_pipe_submit(pipe, slot, SHAFA_OP_RLE_DECODE, sizes[sub], NULL, 0, 0, 0);   /* rle_block_decompressor */
             ++sub;
             continue;
@@ -415,8 +548,12 @@ _modules_error rle_decompress(char **path)
         err = shafa_pipe_wait(pipe, (int)(ret % depth), res);
         if (err) break;
         finals[ret] = res->out_n;
-        if (fwrite(res->out, 1, res->out_n, out) != res->out_n) err = SHAFA_FILE_STREAM_FAILED;
+        ticket[ret % depth] = writer_push(&wr, out, NULL, res->out, res->out_n);
         ++ret;
+    }
+    {
+        const int werr = writer_stop(&wr);
+        if (!err) err = werr;
     }
     shafa_pipe_destroy(pipe);
     free(res);
@@ -474,7 +611,9 @@ _modules_error shafa_decompress(char **path, bool decompress_rle)
     if (!err && !res) err = SHAFA_LACK_OF_MEMORY;
     if (!err) err = shafa_pipe_create(pipe_depth(), &pipe);
     const uint64_t depth = pipe ? (uint64_t)shafa_pipe_slots(pipe) : 1;
-    uint64_t sub = 0, ret = 0;
+    uint64_t sub = 0, ret = 0, ticket[PIPE_SLOTS] = {0};
+    writer_t wr;
+    writer_start(&wr);
     while (!err && ret < n_blocks) {
         if (sub < n_blocks && sub - ret < depth) {
             uint64_t sf_n = 0, n_sym = 0;
@@ -494,6 +633,7 @@ _modules_error shafa_decompress(char **path, bool decompress_rle)
             sizes[sub] = n_sym;
             finals[sub] = (uint64_t)perr;                /* this block's own error, reported in block order */
             /* shafa_block_decompressor (+ rle_block_decompressor, d.c:574-586) */
+            if ((err = writer_wait(&wr, ticket[slot]))) break;
             err = shafa_pipe_submit(pipe, slot, perr ? SHAFA_OP_HIST : (decompress_rle ? SHAFA_OP_SF_RLE_DECODE : SHAFA_OP_SF_DECODE),
                                     perr ? 0 : sf_n, &tab, n_sym, 0, 0);
             ++sub;
@@ -504,8 +644,12 @@ _modules_error shafa_decompress(char **path, bool decompress_rle)
         if (perr) err = perr;
         if (err) break;
         finals[ret] = res->out_n;
-        if (fwrite(res->out, 1, res->out_n, out) != res->out_n) err = SHAFA_FILE_STREAM_FAILED;
+        ticket[ret % depth] = writer_push(&wr, out, NULL, res->out, res->out_n);
         ++ret;
+    }
+    {
+        const int werr = writer_stop(&wr);
+        if (!err) err = werr;
     }
     shafa_pipe_destroy(pipe);
     free(res);

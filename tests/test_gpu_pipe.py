@@ -57,7 +57,7 @@ def test_pipe_every_op_matches_oracle_with_blocks_in_flight(oracle, shafa):
         tabs.append(oracle.sf_build(oracle.hist256(b)))
 
     def sub_enc(i, slot):
-        lmax = max(to_shafa_table(shafa, tabs[i]).lens())
+        lmax = int(max(to_shafa_table(shafa, tabs[i]).lens()))
         pipe.submit(slot, shafa.OP_SF_ENCODE, rle[i], table=to_shafa_table(shafa, tabs[i]), out_cap=(len(rle[i]) * lmax + 7) // 8 + 16)
 
     def ret_enc(i, slot):
