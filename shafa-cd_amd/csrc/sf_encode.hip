@@ -353,6 +353,7 @@ __global__ __launch_bounds__(ENC_THREADS) void sf_encode_generic(const EncBlk *_
 // ------------------------------------------------------------------------------------------------
 void sfenc2_launch(hipStream_t st, const EncBlk *dblk, int count, u32 total_tiles, u64 *ddesc, u32 *dtick);
 void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 *d_tile_bits, u64 *d_tile_off);
+void sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u64 *d_desc, u32 *d_tickets);
 
 int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                  const u64 *h_in_n, const shafa_code_table *h_tables, u8 *d_out, const u64 *h_out_off,
@@ -477,6 +478,7 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     } while (0)
     if (cls_count[1]) {
         if (use_v1) LAUNCH_FAST(4, 1);
+        else if (enc_v == 4) sfenc4_launch(st, dblk + cls_first[1], cls_count[1], max_tiles[1], ddesc, dtick);
         else if (enc_v == 2) sfenc2_launch(st, dblk + cls_first[1], cls_count[1], (u32)total_tiles[1], ddesc, dtick);
         else sfenc3_launch(st, dblk + cls_first[1], cls_count[1], max_tiles[1], (u32 *)(ws + o_tbits), ddesc);
     }

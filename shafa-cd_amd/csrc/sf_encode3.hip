@@ -39,49 +39,70 @@ __device__ __forceinline__ u32 dpp_scan(u32 v)
 // ------------------------------------------------------------------------------------------------
 // count: tile_bits[tile] = sum of code lengths; grid = (tiles, blocks)
 // ------------------------------------------------------------------------------------------------
+constexpr int E3_CTPW = 16;                            // tiles per workgroup of sfe3_count (one LUT fill)
+
 __global__ __launch_bounds__(E3_THREADS) void sfe3_count(const EncBlk *__restrict__ blks, u32 *__restrict__ tile_bits)
 {
-    __shared__ u32 lut[256];
-    __shared__ u32 wsum[4];
+    // Entry = len | absent << 12: a lane sums 128 of them (len sum <= 2048 < 4096), so one add per symbol carries
+    // both the bit total and the number of symbols without a code.  The 256 entries are replicated 32 times,
+    // copy c at dword sym * 32 + c, and lane l reads copy l & 31: every look-up hits its own bank, so a wave's
+    // 64 random look-ups take the minimum two LDS passes instead of ~4.5 with a shared 1 KiB table.
+    __shared__ __attribute__((aligned(16))) u32 lut[256 * 32];
     const EncBlk blk = blks[blockIdx.y];
-    const u32 tile = blockIdx.x;
-    if (tile >= blk.n_tiles) return;
+    const u32 tile0 = blockIdx.x * E3_CTPW;
+    if (tile0 >= blk.n_tiles) return;
     const int tid = threadIdx.x;
-    lut[tid] = gload<u32>((const u32 *)blk.lut + tid);
-    __syncthreads();
-    const u64 base = (u64)tile * E3_TILE;
-    u32 tot = 0, flags = 0;
-    if (base + E3_TILE <= blk.n) {
-        uint4 v[E3_ITEMS];
+    {
+        const u32 x = gload<u32>((const u32 *)blk.lut + tid);
+        const u32 e = ((x >> 16) & 31u) | ((x >> 31) << 12);
+        uint4 *dst = (uint4 *)(lut + tid * 32);
 #pragma unroll
-        for (int it = 0; it < E3_ITEMS; ++it) v[it] = gload<uint4>(blk.in + base + (u64)it * (E3_THREADS * 16) + (u64)tid * 16);
-#pragma unroll
-        for (int it = 0; it < E3_ITEMS; ++it) {
-            const u32 w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const u32 x = lut[(w[j >> 2] >> (8 * (j & 3))) & 0xFFu];
-                flags |= x;
-                tot += (x >> 16) & 31u;
-            }
-        }
-    } else {                                           // ragged last tile of the block
-        for (int it = 0; it < E3_ITEMS; ++it) {
-            const u64 idx = base + (u64)it * (E3_THREADS * 16) + (u64)tid * 16;
-            for (int j = 0; j < 16; ++j) {
-                if (idx + j < blk.n) {
-                    const u32 x = lut[gload<u8>(blk.in + idx + j)];
-                    flags |= x;
-                    tot += (x >> 16) & 31u;
-                }
-            }
-        }
+        for (int c = 0; c < 8; ++c) dst[c] = make_uint4(e, e, e, e);
     }
-    if (flags & 0x80000000u) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
-    const u32 s = dpp_scan(tot);
-    if ((tid & 63) == 63) wsum[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) tile_bits[blk.desc_base + tile] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const u32 copy4 = (u32)(tid & 31) << 2;            // byte offset of this lane's copy inside a 128-byte row
+    const u8 *lutb = (const u8 *)lut;
+    const u32 lane = tid & 63, wv = tid >> 6;
+    const u32 tile_end = tile0 + E3_CTPW < blk.n_tiles ? tile0 + E3_CTPW : blk.n_tiles;
+    u32 absent = 0;
+    // after the fill the waves are independent: wave w counts tiles tile0 + w, + 4, ... (8 KiB = 8 x 16 B per lane),
+    // the next tile's loads are issued before the current tile's look-ups
+    constexpr int CI = E3_TILE / (64 * 16);
+    uint4 cur[CI], nxt[CI];
+    auto load = [&](u32 tile, uint4 *v) {
+        const u64 base = (u64)tile * E3_TILE;
+        if (tile < tile_end && base + E3_TILE <= blk.n) {
+#pragma unroll
+            for (int it = 0; it < CI; ++it) v[it] = gload<uint4>(blk.in + base + (u64)it * 1024 + (u64)lane * 16);
+        }
+    };
+    load(tile0 + wv, cur);
+    for (u32 tile = tile0 + wv; tile < tile_end; tile += 4) {
+        const u64 base = (u64)tile * E3_TILE;
+        load(tile + 4, nxt);
+        u32 tot = 0;
+        if (base + E3_TILE <= blk.n) {
+#pragma unroll
+            for (int it = 0; it < CI; ++it) {
+                const u32 w[4] = {cur[it].x, cur[it].y, cur[it].z, cur[it].w};
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    tot += *(const u32 *)(lutb + ((((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) << 7) | copy4));
+            }
+        } else {                                       // ragged last tile of the block
+            for (int it = 0; it < CI; ++it) {
+                const u64 idx = base + (u64)it * 1024 + (u64)lane * 16;
+                for (int j = 0; j < 16; ++j)
+                    if (idx + j < blk.n) tot += lut[(u32)gload<u8>(blk.in + idx + j) * 32];
+            }
+        }
+        absent |= tot >> 12;                           // a lane sums 128 entries: len sum <= 2048 < 4096
+        const u32 s = dpp_scan(tot & 0xFFFu);
+        if (lane == 63) tile_bits[blk.desc_base + tile] = s;
+#pragma unroll
+        for (int it = 0; it < CI; ++it) cur[it] = nxt[it];
+    }
+    if (absent) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -123,6 +144,8 @@ struct Pack3Shared {
     u32 lut[256];                // code | len << 16
     u32 wtot[4 * E3_ITEMS];
     u32 prev[16];
+    u64 prefix;                  // CHAINED: bits before the tile (from the look-back)
+    u32 tile;                    // CHAINED: ticket
 };
 
 __device__ __forceinline__ u64 bswap64(u64 x)
@@ -130,19 +153,30 @@ __device__ __forceinline__ u64 bswap64(u64 x)
     return ((u64)bswap32((u32)x) << 32) | bswap32((u32)(x >> 32));
 }
 
-__global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict__ blks, const u32 *__restrict__ tile_bits,
-                                                        const u64 *__restrict__ tile_off, u32 dbg)
+// CHAINED = single pass: no count/scan kernels; the tile takes a ticket (tiles of a block start in order, so a
+// tile's predecessors are always running or done), publishes its bit total and gets the bits before it by a
+// decoupled look-back over the block's tile descriptors.  The input is read once (n + out bytes of traffic).
+template <bool CHAINED>
+__global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict__ blks, int nblk,
+                                                        const u64 *__restrict__ tile_off, u64 *__restrict__ desc,
+                                                        u32 *__restrict__ tickets)
 {
     __shared__ __attribute__((aligned(16))) Pack3Shared sh;
-    const EncBlk blk = blks[blockIdx.y];
-    const u32 tile = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);            // wave-uniform: keeps the wave selects scalar
+    const EncBlk blk = blks[CHAINED ? blockIdx.x % (u32)nblk : blockIdx.y];   // CHAINED: blocks interleaved over the grid
+    u32 tile = blockIdx.x;
+    if (CHAINED) {
+        if (tid == 0) sh.tile = atomicAdd(tickets + blk.ticket, 1u);
+        __syncthreads();
+        tile = sh.tile;
+    }
     if (tile >= blk.n_tiles) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u64 base = (u64)tile * E3_TILE;
     const bool full = base + E3_TILE <= blk.n;
 
     // everything this tile needs from memory is requested up front, nothing depends on anything else
-    const u64 B = tile_off[blk.desc_base + tile];
+    u64 B = CHAINED ? 0ull : tile_off[blk.desc_base + tile];
     uint4 cur[E3_ITEMS];
 #pragma unroll
     for (int it = 0; it < E3_ITEMS; ++it) {
@@ -163,8 +197,8 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
     u32 pv = 0;
     if (tid < 16 && tile > 0) pv = gload<u32>(blk.in + base - 64 + 4 * tid);
     {
-        const u32 x = gload<u32>((const u32 *)blk.lut + tid) & 0x7FFFFFFFu;     // absent symbols: count flagged them
-        sh.lut[tid] = x;
+        const u32 x = gload<u32>((const u32 *)blk.lut + tid);
+        sh.lut[tid] = (x >> 31) ? (1u << 28) : x;      // no code: "length" 4096, caught in the item totals below
     }
     for (int i = tid; i < E3_SW64 + 2; i += E3_THREADS) sh.stage[i] = 0;
     if (tid < 16) sh.prev[tid] = pv;
@@ -207,6 +241,12 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
         glen[it] = packed;
         itot[it] = tot;
     }
+    {
+        u32 absent = 0;
+#pragma unroll
+        for (int it = 0; it < E3_ITEMS; ++it) { absent |= itot[it] >> 12; itot[it] &= 0xFFFu; }
+        if (absent) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);     // data symbol without a code (output undefined, in bounds)
+    }
     u32 incl[E3_ITEMS];
 #pragma unroll
     for (int it = 0; it < E3_ITEMS; ++it) incl[it] = dpp_scan(itot[it]);
@@ -215,19 +255,38 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
         for (int it = 0; it < E3_ITEMS; ++it) sh.wtot[it * 4 + wv] = incl[it];
     }
     __syncthreads();                                                                           // 2
-    const u32 s = (u32)B & 63;                         // bit phase of the tile inside its first output u64
     u32 ioff[E3_ITEMS];
     u32 run = 0;
 #pragma unroll
     for (int it = 0; it < E3_ITEMS; ++it) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            if (w == wv) ioff[it] = s + run + incl[it] - itot[it];
+            if (w == wv) ioff[it] = run + incl[it] - itot[it];
             run += sh.wtot[it * 4 + w];
         }
     }
-    const u32 T = run;                                 // tile bit total (== tile_bits[tile])
+    const u32 T = run;                                 // tile bit total
     const bool last = (tile == blk.n_tiles - 1);
+    if (CHAINED) {
+        if (wv == 0) {
+            u64 *bdesc = desc + blk.desc_base;
+            u64 Bv = 0;
+            if (tile > 0) {
+                if (lane == 0) desc_store(bdesc + tile, DESC_AGG, T);
+                Bv = lookback_sum(bdesc, (int)tile, blk.err);
+            }
+            if (lane == 0) {
+                desc_store(bdesc + tile, DESC_PREFIX, Bv + T);
+                sh.prefix = Bv;
+                if (last) gstore<u64>(blk.out_n, (Bv + T + 7) >> 3);
+            }
+        }
+        __syncthreads();
+        B = sh.prefix;
+    }
+    const u32 s = (u32)B & 63;                         // bit phase of the tile inside its first output u64
+#pragma unroll
+    for (int it = 0; it < E3_ITEMS; ++it) ioff[it] += s;
     const u64 g64 = B >> 6;                            // first output u64 owned by the tile
     const u64 E = B + T;
     const u32 nfull = (u32)((E >> 6) - g64);           // whole output words owned
@@ -264,7 +323,7 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
             for (int g = 0; g < 4; ++g) {
                 const u32 L = (glen[it] >> (8 * g)) & 0xFFu;
                 // a group of <= 64 bits touches at most two 64-bit words; L == 0 ORs nothing
-                const u64 Gl = L ? grp[it][g] << (64 - L) : 0ull;   // left-aligned
+                const u64 Gl = grp[it][g] << ((64 - L) & 63);       // left-aligned (L == 0: the group is 0)
                 const u32 sft = q & 63, i = (q >> 6) - r0;          // i == -1: only the low part is in this window
                 const u64 hi = Gl >> sft;
                 const u64 lo = (Gl << 1) << (63 - sft);             // == Gl << (64 - sft), 0 when sft == 0
@@ -299,12 +358,18 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
 }  // namespace
 
 // launched from sfenc_launch (sf_encode.hip) for the Lmax <= 16 class; ws3 = [tile_bits u32 * tiles][tile_off u64 * tiles]
+// single pass (SHAFA_ENC_V=4): desc/tickets zeroed by the caller
+void sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u64 *d_desc, u32 *d_tickets)
+{
+    hipLaunchKernelGGL(sfe3_pack<true>, dim3(max_tiles * (u32)count), dim3(E3_THREADS), 0, st, dblk, count,
+                       (const u64 *)nullptr, d_desc, d_tickets);
+}
+
 void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 *d_tile_bits, u64 *d_tile_off)
 {
-    const dim3 grid(max_tiles, (u32)count);
-    hipLaunchKernelGGL(sfe3_count, grid, dim3(E3_THREADS), 0, st, dblk, d_tile_bits);
+    const dim3 grid(max_tiles, (u32)count), grid_c((max_tiles + E3_CTPW - 1) / E3_CTPW, (u32)count);
+    hipLaunchKernelGGL(sfe3_count, grid_c, dim3(E3_THREADS), 0, st, dblk, d_tile_bits);
     hipLaunchKernelGGL(sfe3_scan, dim3((u32)count), dim3(E3_THREADS), 0, st, dblk, (const u32 *)d_tile_bits, d_tile_off);
-    const char *dbg_env = getenv("SHAFA_ENC_DBG");
-    hipLaunchKernelGGL(sfe3_pack, grid, dim3(E3_THREADS), 0, st, dblk, (const u32 *)d_tile_bits, (const u64 *)d_tile_off,
-                       dbg_env ? (u32)atoi(dbg_env) : 0u);
+    hipLaunchKernelGGL(sfe3_pack<false>, grid, dim3(E3_THREADS), 0, st, dblk, count, (const u64 *)d_tile_off,
+                       (u64 *)nullptr, (u32 *)nullptr);
 }
