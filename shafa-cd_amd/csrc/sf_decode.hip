@@ -98,10 +98,10 @@ __device__ __forceinline__ Code code_at(const u32 *data, const u16 *lut, const u
 }
 
 // stage one tile (+halo) of the stream into LDS as big-endian words; bytes past in_n read as zero
-__device__ __forceinline__ void load_tile(u32 *data, const DecBlk &blk, u32 tile)
+__device__ __forceinline__ void load_tile(u32 *data, const DecBlk &blk, u32 tile, u32 t = threadIdx.x)
 {
     const u64 base = (u64)tile * DTILE;
-    for (u32 i = threadIdx.x; i < DATA_WORDS / 4; i += DEC_THREADS) {
+    for (u32 i = t; i < DATA_WORDS / 4; i += DEC_THREADS) {
         const u64 off = base + (u64)i * 16;
         u32 w[4] = {0, 0, 0, 0};
         if (off + 16 <= blk.in_n) {
@@ -280,7 +280,7 @@ __device__ __forceinline__ u32 wave_map_of(u32 qv)
 // copy a device table (16-byte aligned, padded to 16 bytes in the workspace) into LDS
 __device__ __forceinline__ void fill_lds16(void *dst, const void *src, u32 bytes)
 {
-    for (u32 i = threadIdx.x; i < (bytes + 15) / 16; i += DEC_THREADS)
+    for (u32 i = threadIdx.x; i < (bytes + 15) / 16; i += blockDim.x)
         ((uint4 *)dst)[i] = gload<uint4>((const uint4 *)src + i);
 }
 
@@ -732,37 +732,46 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_count13(const DecBlk *__restr
     }
 }
 
-// sfd_write13: dynamic LDS: data | lut13[2^13] u16 (MULTI: sym3[2^13] u32) | wsum[4]
-template <bool MULTI>
-__global__ __launch_bounds__(DEC_THREADS) void sfd_write13(const DecBlk *__restrict__ blks,
-                                                           const u8 *__restrict__ chunk_entry,
-                                                           const u16 *__restrict__ chunk_cnt,
-                                                           const u64 *__restrict__ tile_off, u32 tpw, u32 dbg)
+// sfd_write13: static LDS: SUBS x data | lut13[2^13] u16 (MULTI: sym3[2^12] u32) | SUBS x wsum[4]
+// A workgroup is SUBS groups of 256 lanes, each decoding its own tile, sharing one copy of the table: the loop is
+// latency bound (dependent LDS look-ups), so what counts is waves per CU, and the table is what limits them.
+template <bool MULTI, int SUBS>
+__global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *__restrict__ blks,
+                                                                  const u8 *__restrict__ chunk_entry,
+                                                                  const u16 *__restrict__ chunk_cnt,
+                                                                  const u64 *__restrict__ tile_off, u32 tpw, u32 dbg)
 {
-    __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + (MULTI ? (4 << SYM3_MAXK) : (2 << LEN_MAXK)) + 64];
+    constexpr int TAB = MULTI ? (4 << SYM3_MAXK) : (2 << LEN_MAXK);
+    __shared__ __attribute__((aligned(16))) u8 smem[SUBS * LDS_DATA + TAB + SUBS * 16 + 64];
     const DecBlk blk = blks[blockIdx.y];
-    if (blockIdx.x * tpw >= blk.n_tiles) return;
-    u32 *data = (u32 *)smem;
-    u16 *lut = (u16 *)(smem + LDS_DATA);
-    u32 *wsum = (u32 *)(smem + LDS_DATA + (MULTI ? (4 << SYM3_MAXK) : (2 << LEN_MAXK)));
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 first_tile = blockIdx.x * tpw * SUBS;
+    if (first_tile >= blk.n_tiles) return;
+    const u32 sub = threadIdx.x >> 8, tid = threadIdx.x & 255u, lane = tid & 63, wv = tid >> 6;
+    u32 *data = (u32 *)(smem + sub * LDS_DATA);
+    u16 *lut = (u16 *)(smem + SUBS * LDS_DATA);
+    u32 *wsum = (u32 *)(smem + SUBS * LDS_DATA + TAB) + sub * 4;
     const u32 K1 = blk.K1;
-    if (tile_off[(size_t)blk.tile_base + blockIdx.x * tpw] >= blk.n_sym) return;   // all padding / past the end
+    if (tile_off[(size_t)blk.tile_base + first_tile] >= blk.n_sym) return;   // all padding / past the end
     const u32 K3 = K1 < (u32)SYM3_MAXK ? K1 : (u32)SYM3_MAXK;
     fill_lds16(lut, MULTI ? (const void *)blk.sym3 : (const void *)blk.lut13, MULTI ? (4u << K3) : (2u << K1));
     bool bad = false;
-    const u32 tile_end = (blockIdx.x + 1) * tpw < blk.n_tiles ? (blockIdx.x + 1) * tpw : blk.n_tiles;
-    for (u32 tile = blockIdx.x * tpw; tile < tile_end; ++tile) {
+    for (u32 it = 0; it < tpw && first_tile + it * SUBS < blk.n_tiles; ++it) {
+    const u32 tile = first_tile + it * SUBS + sub;
     const size_t gt = (size_t)blk.tile_base + tile;
-    const u64 toff = tile_off[gt];
-    if (toff >= blk.n_sym) break;                       // uniform: the rest is padding / past the end
+    bool active = tile < blk.n_tiles;                   // uniform per 256-lane group
+    const u64 toff = active ? tile_off[gt] : 0ull;
+    active = active && toff < blk.n_sym;                // the rest is padding / past the end
     __syncthreads();                                    // previous tile's LDS reads are done
-    load_tile(data, blk, tile);
-    const u32 entry = chunk_entry[gt * DEC_THREADS + tid];
-    const u32 cnt = chunk_cnt[gt * DEC_THREADS + tid];
+    u32 entry = 0, cnt = 0;
+    if (active) {
+        load_tile(data, blk, tile, tid);
+        entry = chunk_entry[gt * DEC_THREADS + tid];
+        cnt = chunk_cnt[gt * DEC_THREADS + tid];
+    }
     const u32 incl = wave_incl_scan_add<u32>(cnt);
     if (lane == 63) wsum[wv] = incl;
     __syncthreads();
+    if (!active) continue;
     u32 base = 0;
     for (u32 w = 0; w < wv; ++w) base += wsum[w];
     const u64 first = toff + base + incl - cnt;         // global index of this chunk's first symbol
@@ -1132,6 +1141,8 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     if (const char *e = getenv("SHAFA_DEC_TPW")) tpw = (u32)atoi(e) > 0 ? (u32)atoi(e) : 1u;
     while (tpw > 1 && (u64)ceil_div_u64(max_tiles, tpw) * nblocks < 2048) tpw >>= 1;     // keep the chip full
     const dim3 grid_f((u32)ceil_div_u64(max_tiles, tpw), (u32)nblocks);
+    constexpr int WSUBS = 2;                           // 256-lane groups per workgroup of sfd_write13
+    const dim3 grid_w((u32)ceil_div_u64(max_tiles, tpw * WSUBS), (u32)nblocks);
     const u32 dbg = getenv("SHAFA_DEC_DBG") ? (u32)atoi(getenv("SHAFA_DEC_DBG")) : 0u;
     if (packed) {
         const size_t lds_count16 = lds_data + DEC_THREADS * 8 + lds_lut + 32 + DEC_THREADS + 64;
@@ -1171,10 +1182,10 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
                        (u64 *)(ws + o_toff));
     if (fast13) {
         if (multi)
-            hipLaunchKernelGGL(sfd_write13<true>, grid_f, dim3(DEC_THREADS), 0, st, dblk,
+            hipLaunchKernelGGL((sfd_write13<true, WSUBS>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
                                (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, dbg);
         else
-            hipLaunchKernelGGL(sfd_write13<false>, grid_f, dim3(DEC_THREADS), 0, st, dblk,
+            hipLaunchKernelGGL((sfd_write13<false, WSUBS>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
                                (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, dbg);
     } else {
         hipLaunchKernelGGL(sfd_write, grid_t, dim3(DEC_THREADS), lds_write, st, dblk, l2cap, (const u8 *)(ws + o_cent),
