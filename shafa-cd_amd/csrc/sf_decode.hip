@@ -63,6 +63,9 @@ struct DecBlk {
     u32 tile_base;         // first tile of this block in the per-tile arrays
     u32 n_tiles;
     u32 n_l2;              // level-2 entries
+    u32 n_states;          // internal trie nodes = states of the counting automaton (<= 255 for a complete code)
+    u32 *fsm4;             // [state][nibble]: next state * 64 | codes completed << 16   (complete codes; sfd_tables)
+    u32 *fsm1;             // [state][bit]   : same, for one bit
 };
 
 // stream words are kept big-endian in LDS, one pad word per 8 (chunk stride 9 words: no bank conflicts)
@@ -315,6 +318,20 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
             pos += L;
         }
         blk.sym3[i] = syms | (pos << 24) | (n << 28);
+    }
+    // counting automaton: state = internal trie node (0 = root = between two codes); consuming a nibble (or a bit)
+    // moves to the next state and completes 0..4 codes.  next state is stored as the byte offset of its row.
+    for (u32 i = threadIdx.x; i < blk.n_states * 16; i += DEC_THREADS) {
+        u32 node = i >> 4, done = 0;
+        for (int b = 3; b >= 0; --b) {
+            const u32 c = blk.trie[2 * node + ((i >> b) & 1u)];
+            if (c & 0x80000000u) { ++done; node = 0; } else node = c;
+        }
+        blk.fsm4[i] = (node * 64u) | (done << 16);
+    }
+    for (u32 i = threadIdx.x; i < blk.n_states * 2; i += DEC_THREADS) {
+        const u32 c = blk.trie[i];
+        blk.fsm1[i] = (c & 0x80000000u) ? (1u << 16) : (c * 64u);
     }
 }
 
@@ -620,9 +637,9 @@ struct BitBuf {
 
 // entry offset of every chunk of the tile: quarter chase with history, wave maps through LDS, then each lane
 // picks its nibble.  cm = the tile's 256 chunk maps (LDS), hist = 256 u64 (LDS), wmb = 64 bytes (LDS).
-__device__ __forceinline__ u32 chunk_entry_of(const u64 *cm, u64 *hist, u8 *wmb, u32 tile_entry_v)
+__device__ __forceinline__ u32 chunk_entry_of(const u64 *cm, u64 *hist, u8 *wmb, u32 tile_entry_v, u32 tid = threadIdx.x)
 {
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, q = lane >> 4;
+    const u32 lane = tid & 63, wv = tid >> 6, q = lane >> 4;
     u64 h;
     const u32 qv = quarter_chase<true>(cm + wv * 64, &h);
     hist[tid] = h;                                              // tid == wv*64 + q*16 + d
@@ -729,6 +746,95 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_count13(const DecBlk *__restr
     if (lane == 0) wsum[wv] = tot;
     __syncthreads();
     if (tid == 0) tile_cnt[gt] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+}
+
+// sfd_countfsm: symbol counts with the nibble automaton (complete codes, Lmax <= 16).  Every lane takes exactly 64
+// table steps for its 256 bits whatever the code lengths are: no bit-buffer bookkeeping, no divergence between
+// lanes, ~4 VALU instructions per nibble.  static LDS: data | cmap[256] u64 | fsm4[256*16] u32 | fsm1[256*2] u32 |
+// hist[256] u64 | wmb[64] | wsum[4]
+template <int SUBS>
+__global__ __launch_bounds__(DEC_THREADS * SUBS) __attribute__((amdgpu_waves_per_eu(8, 8))) void sfd_countfsm(const DecBlk *__restrict__ blks,
+                                                                   const u64 *__restrict__ chunkfn,
+                                                                   const u8 *__restrict__ tile_entry,
+                                                                   u8 *__restrict__ chunk_entry, u16 *__restrict__ chunk_cnt,
+                                                                   u32 *__restrict__ tile_cnt, u32 tpw)
+{
+    // SUBS groups of 256 lanes, one tile each, share the automaton tables (the chain of 64 dependent look-ups per
+    // lane is latency bound: waves per CU is what counts)
+    constexpr int PER_SUB = LDS_DATA + DEC_THREADS * 16 + 64 + 16;
+    __shared__ __attribute__((aligned(16))) u8 smem[SUBS * PER_SUB + 16384 + 2048 + 64];
+    const DecBlk blk = blks[blockIdx.y];
+    const u32 first_tile = blockIdx.x * tpw * SUBS;
+    if (first_tile >= blk.n_tiles) return;
+    const u32 sub = threadIdx.x >> 8, tid = threadIdx.x & 255u, lane = tid & 63, wv = tid >> 6;
+    u8 *mine = smem + sub * PER_SUB;
+    u32 *data = (u32 *)mine;
+    u64 *cm = (u64 *)(mine + LDS_DATA);
+    u64 *hist = cm + DEC_THREADS;
+    u8 *wmb = (u8 *)(hist + DEC_THREADS);
+    u32 *wsum = (u32 *)(wmb + 64);
+    const u8 *f4 = smem + SUBS * PER_SUB;
+    const u8 *f1 = f4 + 16384;
+
+    fill_lds16((void *)f4, blk.fsm4, blk.n_states * 64);
+    fill_lds16((void *)f1, blk.fsm1, blk.n_states * 8);
+    for (u32 it = 0; it < tpw && first_tile + it * SUBS < blk.n_tiles; ++it) {
+    const u32 tile = first_tile + it * SUBS + sub;
+    const bool active = tile < blk.n_tiles;            // uniform per 256-lane group
+    const size_t gt = (size_t)blk.tile_base + (active ? tile : first_tile);
+    __syncthreads();                                   // previous tile's LDS reads are done
+    load_tile(data, blk, active ? tile : first_tile, tid);
+    cm[tid] = chunkfn[gt * DEC_THREADS + tid];
+    __syncthreads();
+    const u32 entry = chunk_entry_of(cm, hist, wmb, tile_entry[gt], tid);
+    const u32 limit = tile_bit_limit(blk, tile);
+    const bool last = limit < (u32)(DTILE + HALO_WORDS * 4) * 8;          // the stream ends inside this window
+    const u32 cw = tid * (CH_BITS / 32), cbase = tid * CH_BITS;
+    u32 st = 0, cnt = 0, p = entry;
+    auto bit_step = [&](u32 q) {                        // consume tile-local bit q
+        const u32 bit = (data[widx(q >> 5)] >> (31 - (q & 31))) & 1u;
+        const u32 e = *(const u32 *)(f1 + (st >> 3) + bit * 4);
+        st = e & 0xFFFFu;
+        cnt += e >> 16;
+    };
+    if (!last) {
+        while (p & 3) { bit_step(cbase + p); ++p; }    // up to the next nibble boundary (p <= 16 afterwards)
+        const u32 j0 = p >> 2;                          // first whole nibble of word 0 (0..4)
+#pragma unroll
+        for (int wi = 0; wi < 8; ++wi) {
+            const u32 w = data[widx(cw + wi)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const u32 nib4 = j < 7 ? (w >> (26 - 4 * j)) & 0x3Cu : (w << 2) & 0x3Cu;
+                const u32 e = *(const u32 *)(f4 + st + nib4);
+                if (wi == 0 && j < 4) {                 // nibbles before the entry belong to the previous chunk
+                    if ((u32)j >= j0) { st = e & 0xFFFFu; cnt += e >> 16; }
+                } else {
+                    st = e & 0xFFFFu;
+                    cnt += e >> 16;
+                }
+            }
+        }
+        cnt += st != 0;                                 // the code in progress at bit 256 started in this chunk
+    } else {
+        // last tile of the block: bit by bit; only codes that end inside the stream are symbols
+        const u32 stop = cbase + CH_BITS < limit ? cbase + CH_BITS : limit;
+        u32 q = cbase + p;
+        for (; q < stop; ++q) bit_step(q);
+        if (st != 0 && q == cbase + CH_BITS) {          // finish the code in progress (it started in this chunk)
+            const u32 before = cnt;
+            for (; q < limit && cnt == before; ++q) bit_step(q);
+        }
+    }
+    if (active) {
+        chunk_entry[gt * DEC_THREADS + tid] = (u8)entry;
+        chunk_cnt[gt * DEC_THREADS + tid] = (u16)cnt;
+    }
+    const u32 tot = wave_reduce_add<u32>(cnt);
+    if (lane == 0) wsum[wv] = tot;
+    __syncthreads();
+    if (active && tid == 0) tile_cnt[gt] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
 }
 
@@ -1075,6 +1181,8 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const size_t o_pair = off; off += pair_all ? (size_t)nblocks * (2u << LEN_MAXK) : 0;
     const size_t o_cnt3 = off; off += pair_all ? (size_t)nblocks * (2u << LEN_MAXK) : 0;
     const size_t o_sym3 = off; off += pair_all ? (size_t)nblocks * (4u << LEN_MAXK) : 0;
+    const size_t o_fsm4 = off; off += pair_all ? (size_t)nblocks * 16384 : 0;
+    const size_t o_fsm1 = off; off += pair_all ? (size_t)nblocks * 2048 : 0;
     const size_t o_cfn = off; off += packed ? (size_t)total_tiles * DEC_THREADS * 8 : (size_t)total_tiles * R * DEC_THREADS;
     int rc = batch_reserve(bt, off);
     if (rc) return rc;
@@ -1098,12 +1206,15 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         e.pairlut = pair_all ? ws + o_pair + (size_t)b * (2u << LEN_MAXK) : nullptr;
         e.cnt3 = pair_all ? (u16 *)(ws + o_cnt3 + (size_t)b * (2u << LEN_MAXK)) : nullptr;
         e.sym3 = pair_all ? (u32 *)(ws + o_sym3 + (size_t)b * (4u << LEN_MAXK)) : nullptr;
+        e.fsm4 = pair_all ? (u32 *)(ws + o_fsm4 + (size_t)b * 16384) : nullptr;
+        e.fsm1 = pair_all ? (u32 *)(ws + o_fsm1 + (size_t)b * 2048) : nullptr;
         tbase += ntiles[b];
         if (!ntiles[b]) continue;
         HostTab &h = tabs[b];
         e.K = h.K;
         e.K1 = h.K1;
         e.lmax = h.lmax;
+        e.n_states = (u32)(h.trie.size() / 2);
         e.lut2 = (const u16 *)(ws + tpos);
         e.n_l2 = (u32)h.lut2.size();
         if (h.lut2.size()) memcpy(hs + tpos, h.lut2.data(), h.lut2.size() * 2);
@@ -1143,6 +1254,8 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const dim3 grid_f((u32)ceil_div_u64(max_tiles, tpw), (u32)nblocks);
     constexpr int WSUBS = 2;                           // 256-lane groups per workgroup of sfd_write13
     const dim3 grid_w((u32)ceil_div_u64(max_tiles, tpw * WSUBS), (u32)nblocks);
+    constexpr int CSUBS = 4;                           // 256-lane groups per workgroup of sfd_countfsm
+    const dim3 grid_c((u32)ceil_div_u64(max_tiles, tpw * CSUBS), (u32)nblocks);
     const u32 dbg = getenv("SHAFA_DEC_DBG") ? (u32)atoi(getenv("SHAFA_DEC_DBG")) : 0u;
     if (packed) {
         const size_t lds_count16 = lds_data + DEC_THREADS * 8 + lds_lut + 32 + DEC_THREADS + 64;
@@ -1157,7 +1270,11 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         hipLaunchKernelGGL(sfd_tiles16, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u64 *)(ws + o_tilefn),
                            ws + o_tent);
         if (fast13) {
-            if (multi)
+            if (multi && !getenv("SHAFA_DEC_NOFSM"))
+                hipLaunchKernelGGL((sfd_countfsm<CSUBS>), grid_c, dim3(DEC_THREADS * CSUBS), 0, st, dblk,
+                                   (const u64 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
+                                   (u32 *)(ws + o_tcnt), tpw);
+            else if (multi)
                 hipLaunchKernelGGL(sfd_count13<true>, grid_f, dim3(DEC_THREADS), 0, st, dblk,
                                    (const u64 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
                                    (u32 *)(ws + o_tcnt), tpw);
