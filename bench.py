@@ -222,10 +222,19 @@ def main():
     alg = total_in + total_enc
     enc_gbs = alg / enc_t / 1e9
     dec_gbs = alg / dec_t / 1e9 if have_decode else None
+    # HBM traffic per launch: measured offline with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes
+    # (tools/gpu_pmc_traffic.sh, gfx950 FETCH correction applied) on this workload; scaled by the launch's bytes.
+    traffic = {"sf_encode": None, "sf_decode": None}
+    tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    if args.dist == "zipf" and args.block_mib == 64 and os.path.exists(tpath):
+        with open(tpath) as f:
+            per_byte = json.load(f)["bytes_per_input_byte"]
+        traffic = {k: per_byte[k] * total_in for k in traffic}
     dominant = "sf_decode" if have_decode and dec_t > enc_t else "sf_encode"
     roof = {"bound": "hbm", "kernel": dominant,
             "achieved": dec_gbs if dominant == "sf_decode" else enc_gbs,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic[dominant],
+            "traffic_source": "profiles/r1_traffic.json (rocprofv3 PMC, separate run)" if traffic[dominant] else None}
     roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
 
     if rank == 0:
@@ -245,10 +254,11 @@ def main():
             "encode_ms": enc_t * 1e3, "decode_ms": dec_t * 1e3 if have_decode else None,
             "roofline": roof,
             "roofline_encode": {"bound": "hbm", "achieved": enc_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": enc_gbs / HBM_PEAK_GBS, "traffic": None,
+                                "frac": enc_gbs / HBM_PEAK_GBS, "traffic": traffic["sf_encode"],
                                 "algorithmic_bytes_per_launch": alg},
             "roofline_decode": ({"bound": "hbm", "achieved": dec_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": dec_gbs / HBM_PEAK_GBS, "traffic": None} if have_decode else None),
+                                 "frac": dec_gbs / HBM_PEAK_GBS, "traffic": traffic["sf_decode"],
+                                 "algorithmic_bytes_per_launch": alg} if have_decode else None),
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, pkg, zt)
