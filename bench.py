@@ -43,6 +43,7 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-sample-blocks", type=int, default=16)
     ap.add_argument("--encode-only", action="store_true")
+    ap.add_argument("--zipf-s", type=float, default=1.2, help="Zipf exponent of the synthetic bytes (metric config: 1.2)")
     return ap.parse_args()
 
 
@@ -115,7 +116,7 @@ def main():
     bs = args.block_mib << 20
     nb = args.blocks
     shard = nb * bs
-    zt = pkg.zipf_table(1.2)
+    zt = pkg.zipf_table(args.zipf_s)
     st = torch.cuda.Stream(device=dev)
 
     # ---- resident inputs: this rank's shard of the global synthetic stream -----------------------
@@ -226,7 +227,7 @@ def main():
     # (tools/gpu_pmc_traffic.sh, gfx950 FETCH correction applied) on this workload; scaled by the launch's bytes.
     traffic = {"sf_encode": None, "sf_decode": None}
     tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
-    if args.dist == "zipf" and args.block_mib == 64 and os.path.exists(tpath):
+    if args.dist == "zipf" and args.zipf_s == 1.2 and args.block_mib == 64 and os.path.exists(tpath):
         with open(tpath) as f:
             per_byte = json.load(f)["bytes_per_input_byte"]
         traffic = {k: per_byte[k] * total_in for k in traffic}
@@ -237,6 +238,7 @@ def main():
             "traffic_source": "profiles/r1_traffic.json (rocprofv3 PMC, separate run)" if traffic[dominant] else None}
     roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
 
+    dist_name = args.dist if args.zipf_s == 1.2 or args.dist != 'zipf' else 'zipf(s=%g)' % args.zipf_s
     if rank == 0:
         out = {
             "metric": "GiB/s Shannon-Fano encode+decode, 64 MiB blocks, 1/2/4/8 GPUs; bit-exact",
@@ -244,7 +246,7 @@ def main():
             "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"cfg4 shard: {nb} x {args.block_mib} MiB {args.dist} blocks per GPU "
+            "config": {"workload": f"cfg4 shard: {nb} x {args.block_mib} MiB {dist_name} blocks per GPU "
                                    f"(-b {'M' if args.block_mib == 64 else args.block_mib}), Module C encode + "
                                    f"Module D decode" + ("" if have_decode else " [decode unavailable: encode only]"),
                        "blocks_per_gpu": nb, "block_bytes": bs, "parallelism": f"blocks sharded over {world} GPU(s)",

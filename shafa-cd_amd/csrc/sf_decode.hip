@@ -26,6 +26,8 @@
 #include "common.hpp"
 #include "internal.hpp"
 
+#include <algorithm>
+
 #include <stdlib.h>
 
 namespace {
@@ -40,6 +42,8 @@ constexpr int LUT_MAXK = 11;
 constexpr int LUT2_MAX = 4096;                     // level-2 entries kept in LDS (8 KiB)
 constexpr int SYM3_MAXK = 12;                      // window of the three-codes table of sfd_write13: 16 KiB
 constexpr int LDS_DATA = (DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
+constexpr int LONG_PFX = 128;                      // codes longer than SYM3_MAXK bits, grouped by their first SYM3_MAXK bits
+constexpr int LONG_BYTES = 16 + LONG_PFX * 2 + LONG_PFX * 16 * 2;   // [n u16 x8 pad][pfx u16 x128][ent u16 x128x16]
 constexpr int LEN_MAXK = 13;                       // length-only LUT of the packed DP: 8 KiB
 
 struct DecBlk {
@@ -53,7 +57,7 @@ struct DecBlk {
     const u16 *lut2;       // level 2 (codes of K+1 .. K+8 bits): sym | len << 8 ; 0 = go to the trie
     const u8 *lenlut;      // 2^K1 entries: len only (DP of the packed path); 0 = longer than K1 bits
     u16 *cnt3;             // 2^K1 entries: up to three codes per window: total bits | len0 << 4 | n << 12
-    u32 *sym3;             // 2^K1 entries: sym0 | sym1 << 8 | sym2 << 16 | total bits << 24 | n << 28
+    u32 *sym3;             // 2^K3 entries: sym0 | sym1 << 8 | sym2 << 16 | total bits << 24 (5 bits) | n << 29
     u8 *pairlut;           // 2^(K1+1) entries: (len(p)-1) | (len(p+1)-1) << 4 from a K1+1-bit window (complete codes)
     const u16 *lut13;      // 2^K1 entries: sym | len << 8, single level (only when Lmax <= 13), else NULL
     const u32 *trie;       // pairs {child0, child1}: 0x80000000|sym = leaf, 0xFFFFFFFF = missing
@@ -66,6 +70,7 @@ struct DecBlk {
     u32 n_states;          // internal trie nodes = states of the counting automaton (<= 255 for a complete code)
     u32 *fsm4;             // [state][nibble]: next state * 64 | codes completed << 16   (complete codes; sfd_tables)
     u32 *fsm1;             // [state][bit]   : same, for one bit
+    const u16 *longtab;    // LONG_BYTES: sorted 12-bit prefixes of the codes of 13..16 bits + 16 entries sym | len << 8 each
 };
 
 // stream words are kept big-endian in LDS, one pad word per 8 (chunk stride 9 words: no bank conflicts)
@@ -280,6 +285,20 @@ __device__ __forceinline__ u32 wave_map_of(u32 qv)
     return v;
 }
 
+// code of 13..16 bits at the head of `win32` (next stream bit at the MSB): binary search of its first 12 bits in
+// the sorted prefix list, then 4 more bits index the group.  Returns sym | len << 8, 0 when there is none.
+__device__ __forceinline__ u32 long_code(const u16 *lt, u32 win32)
+{
+    const u32 n = lt[0], key = win32 >> 20;
+    const u16 *pfx = lt + 8, *ent = lt + 8 + LONG_PFX;
+    u32 lo = 0, hi = n;
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (pfx[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n && pfx[lo] == key) ? ent[lo * 16 + ((win32 >> 16) & 15u)] : 0u;
+}
+
 // copy a device table (16-byte aligned, padded to 16 bytes in the workspace) into LDS
 __device__ __forceinline__ void fill_lds16(void *dst, const void *src, u32 bytes)
 {
@@ -295,14 +314,14 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
     const DecBlk blk = blks[blockIdx.x];
     if (!blk.n_tiles) return;
     const u32 K1 = blk.K1, mask = (1u << K1) - 1;
-    for (u32 i = threadIdx.x; i < (2u << K1); i += DEC_THREADS)
+    for (u32 i = threadIdx.x; blk.pairlut && i < (2u << K1); i += DEC_THREADS)
         blk.pairlut[i] = (u8)((blk.lenlut[i >> 1] - 1u) | ((blk.lenlut[i & mask] - 1u) << 4));
     const u32 K3 = K1 < (u32)SYM3_MAXK ? K1 : (u32)SYM3_MAXK;
     for (u32 i = threadIdx.x; i <= mask; i += DEC_THREADS) {
         u32 pos = 0, n = 0, l0 = 0;
         for (; n < 3; ++n) {
             const u32 L = blk.lut13[(i << pos) & mask] >> 8;     // window shifted left, zero filled
-            if (L > K1 - pos) break;                             // would use bits outside the window
+            if (L == 0 || L > K1 - pos) break;                   // longer than the window / would use bits outside it
             if (n == 0) l0 = L;
             pos += L;
         }
@@ -313,11 +332,11 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
         for (; n < 3; ++n) {
             const u32 e = blk.lut13[((i << (K1 - K3)) << pos) & mask];
             const u32 L = e >> 8;
-            if (L > K3 - pos) break;
+            if (L == 0 || L > K3 - pos) break;
             syms |= (e & 0xFFu) << (8 * n);
             pos += L;
         }
-        blk.sym3[i] = syms | (pos << 24) | (n << 28);
+        blk.sym3[i] = syms | (pos << 24) | (n << 29);
     }
     // counting automaton: state = internal trie node (0 = root = between two codes); consuming a nibble (or a bit)
     // moves to the next state and completes 0..4 codes.  next state is stored as the byte offset of its row.
@@ -336,21 +355,26 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
 }
 
 // sfd_sync16: dynamic LDS: data | lenlut[2^13] u8 (PAIR: pairlut[2^14]) | cmap[256] u64 | wmb[64] u8
-template <bool PAIR>
+template <bool PAIR, bool LONG>
 __global__ __launch_bounds__(DEC_THREADS) void sfd_sync16(const DecBlk *__restrict__ blks,
                                                           u64 *__restrict__ chunkfn, u64 *__restrict__ tilefn, u32 tpw)
 {
     // static LDS: constant addresses fold into the ds_read offset field (no per-lookup address add)
-    __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + (PAIR ? 2 : 1) * (1 << LEN_MAXK) + DEC_THREADS * 8 + 64];
+    __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + (PAIR ? 2 : 1) * (1 << LEN_MAXK) + DEC_THREADS * 8 + 64 + (LONG ? LONG_BYTES : 0)];
     const DecBlk blk = blks[blockIdx.y];
     if (blockIdx.x * tpw >= blk.n_tiles) return;
     u32 *data = (u32 *)smem;
     u8 *lenlut = smem + LDS_DATA;
     u64 *cmap = (u64 *)(lenlut + (PAIR ? 2u : 1u) * (1u << LEN_MAXK));
     u8 *wmb = (u8 *)(cmap + DEC_THREADS);
+    const u16 *lt = (const u16 *)(wmb + 64);
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 K1 = blk.K1;
 
+    if (LONG) {                                        // blocks of the launch without long codes: empty list
+        if (blk.longtab) fill_lds16((void *)lt, blk.longtab, LONG_BYTES);
+        else if (tid == 0) *(u16 *)lt = 0;
+    }
     fill_lds16(lenlut, PAIR ? (const void *)blk.pairlut : (const void *)blk.lenlut, PAIR ? (2u << K1) : (1u << K1));
     const u32 tile_end = (blockIdx.x + 1) * tpw < blk.n_tiles ? (blockIdx.x + 1) * tpw : blk.n_tiles;
     for (u32 tile = blockIdx.x * tpw; tile < tile_end; ++tile) {      // one table load serves tpw tiles
@@ -393,7 +417,15 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_sync16(const DecBlk *__restri
 #pragma unroll
             for (int r = 31; r >= 0; --r) {
                 u32 l = len[r];
-                if (__builtin_expect(l == 0, 0)) l = slow_len(data, blk.trie, (cw + wi) * 32 + r);
+                if (__builtin_expect(l == 0, 0)) {
+                    if (LONG) {                        // 14..16 bits: resolved from LDS (complete code: always found)
+                        const u32 win = r ? __builtin_amdgcn_alignbit(w0, w1, 32 - r) : w0;
+                        l = long_code(lt, win) >> 8;
+                        l = l ? l : 1u;
+                    } else {
+                        l = slow_len(data, blk.trie, (cw + wi) * 32 + r);
+                    }
+                }
                 const u32 x = nib(ring, l - 1);
                 ring = (ring << 4) | x;
             }
@@ -841,14 +873,14 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) __attribute__((amdgpu_waves_per
 // sfd_write13: static LDS: SUBS x data | lut13[2^13] u16 (MULTI: sym3[2^12] u32) | SUBS x wsum[4]
 // A workgroup is SUBS groups of 256 lanes, each decoding its own tile, sharing one copy of the table: the loop is
 // latency bound (dependent LDS look-ups), so what counts is waves per CU, and the table is what limits them.
-template <bool MULTI, int SUBS>
+template <bool MULTI, int SUBS, bool LONG>
 __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *__restrict__ blks,
                                                                   const u8 *__restrict__ chunk_entry,
                                                                   const u16 *__restrict__ chunk_cnt,
                                                                   const u64 *__restrict__ tile_off, u32 tpw, u32 dbg)
 {
     constexpr int TAB = MULTI ? (4 << SYM3_MAXK) : (2 << LEN_MAXK);
-    __shared__ __attribute__((aligned(16))) u8 smem[SUBS * LDS_DATA + TAB + SUBS * 16 + 64];
+    __shared__ __attribute__((aligned(16))) u8 smem[SUBS * LDS_DATA + TAB + SUBS * 16 + 64 + (LONG ? LONG_BYTES : 0)];
     const DecBlk blk = blks[blockIdx.y];
     const u32 first_tile = blockIdx.x * tpw * SUBS;
     if (first_tile >= blk.n_tiles) return;
@@ -856,10 +888,15 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *
     u32 *data = (u32 *)(smem + sub * LDS_DATA);
     u16 *lut = (u16 *)(smem + SUBS * LDS_DATA);
     u32 *wsum = (u32 *)(smem + SUBS * LDS_DATA + TAB) + sub * 4;
+    const u16 *lt = (const u16 *)(smem + SUBS * LDS_DATA + TAB + SUBS * 16 + 16);
     const u32 K1 = blk.K1;
     if (tile_off[(size_t)blk.tile_base + first_tile] >= blk.n_sym) return;   // all padding / past the end
     const u32 K3 = K1 < (u32)SYM3_MAXK ? K1 : (u32)SYM3_MAXK;
     fill_lds16(lut, MULTI ? (const void *)blk.sym3 : (const void *)blk.lut13, MULTI ? (4u << K3) : (2u << K1));
+    if (LONG) {
+        if (blk.longtab) fill_lds16((void *)lt, blk.longtab, LONG_BYTES);
+        else if (threadIdx.x == 0) *(u16 *)lt = 0;
+    }
     bool bad = false;
     for (u32 it = 0; it < tpw && first_tile + it * SUBS < blk.n_tiles; ++it) {
     const u32 tile = first_tile + it * SUBS + sub;
@@ -898,11 +935,12 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *
         bool have_pend = false;
         while (want) {                                  // up to three symbols per lookup; stops on the count
             u32 e = tab[bb.peek32() >> sh3];
-            if (__builtin_expect((e >> 28) == 0, 0)) {  // first code longer than the window: one code from lut13
-                const u32 e1 = gload<u16>(blk.lut13 + (bb.peek32() >> sh));
-                e = (e1 & 0xFFu) | ((e1 >> 8) << 24) | (1u << 28);
+            if (__builtin_expect((e >> 29) == 0, 0)) {  // first code longer than the window: one code from lut13 / the long table
+                u32 e1 = LONG ? long_code(lt, bb.peek32()) : (u32)gload<u16>(blk.lut13 + (bb.peek32() >> sh));
+                if (e1 == 0) { bad = true; e1 = 1u << 8; }      // not a code (complete tables never get here)
+                e = (e1 & 0xFFu) | ((e1 >> 8) << 24) | (1u << 29);
             }
-            const u32 n = e >> 28, take = n < want ? n : want, syms = e & 0xFFFFFFu;
+            const u32 n = e >> 29, take = n < want ? n : want, syms = e & 0xFFFFFFu;
             acc |= (u64)syms << (8 * nb);
             const u32 room = 8 - nb;                    // bytes of `syms` that fitted
             nb += take;
@@ -918,7 +956,7 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *
                 nb -= 8;
                 acc = room < 3 ? (u64)(syms >> (8 * room)) : 0ull;
             }
-            bb.skip(data, (e >> 24) & 15u);
+            bb.skip(data, (e >> 24) & 31u);
         }
         if (have_pend) { gstore<u64>(op, pend); op += 8; }
         for (u32 q = 0; q < nb; ++q) gstore<u8>(op + q, (u8)(acc >> (8 * q)));
@@ -1039,8 +1077,9 @@ struct HostTab {
     std::vector<u32> trie;     // pairs
     std::vector<u16> lut, lut2, lut13;
     std::vector<u8> lenlut;
+    std::vector<u16> longtab;  // LONG_BYTES / 2 entries when 12 < Lmax <= 16 and the code is complete
     u32 K, K1, lmax;
-    bool ok, empty, complete;
+    bool ok, empty, complete, complete16;
 };
 
 void build_host_tab(const shafa_code_table &t, HostTab &h)
@@ -1048,6 +1087,7 @@ void build_host_tab(const shafa_code_table &t, HostTab &h)
     h.trie.assign(2, 0xFFFFFFFFu);
     h.ok = true;
     h.complete = false;
+    h.complete16 = false;
     h.lmax = 0;
     for (int s = 0; s < 256; ++s) h.lmax = t.len[s] > h.lmax ? t.len[s] : h.lmax;
     h.empty = h.lmax == 0;
@@ -1055,7 +1095,7 @@ void build_host_tab(const shafa_code_table &t, HostTab &h)
     h.lut.assign((size_t)1 << h.K, 0);
     h.K1 = h.lmax < (u32)LEN_MAXK ? (h.lmax ? h.lmax : 1) : (u32)LEN_MAXK;
     h.lenlut.assign(((size_t)1 << h.K1) + 4, 0);
-    if (h.lmax <= (u32)LEN_MAXK) h.lut13.assign(((size_t)1 << h.K1) + 2, 0);
+    h.lut13.assign(((size_t)1 << h.K1) + 2, 0);        // codes of <= K1 bits; 0 = longer
     auto code_of = [&](int s) {
         u64 code = 0;       // only the first 32 bits are ever needed here
         const u32 L = t.len[s] < 32 ? t.len[s] : 32;
@@ -1097,6 +1137,31 @@ void build_host_tab(const shafa_code_table &t, HostTab &h)
     if (!h.ok) return;
     h.complete = h.lmax <= (u32)LEN_MAXK;               // every K1-bit window starts a code: pair table usable
     for (size_t i = 0; h.complete && i < ((size_t)1 << h.K1); ++i) h.complete = h.lenlut[i] != 0;
+    if (h.lmax <= 16) {                                 // prefix-free (checked above) + Kraft sum 1 = complete tree
+        u64 kraft = 0;
+        for (int s = 0; s < 256; ++s) if (t.len[s]) kraft += 1ull << (16 - t.len[s]);
+        h.complete16 = kraft == 65536;
+    }
+    if (h.complete16 && h.lmax > (u32)SYM3_MAXK) {      // codes of 13..16 bits, grouped by their first 12 bits
+        h.longtab.assign(LONG_BYTES / 2, 0);
+        std::vector<u32> keys;
+        for (int s = 0; s < 256; ++s) if (t.len[s] > (u32)SYM3_MAXK) keys.push_back(code_of(s) >> (t.len[s] - SYM3_MAXK));
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        if (keys.size() > (size_t)LONG_PFX) { h.complete16 = false; h.longtab.clear(); }
+        else {
+            h.longtab[0] = (u16)keys.size();
+            for (size_t g = 0; g < keys.size(); ++g) h.longtab[8 + g] = (u16)keys[g];
+            for (int s = 0; s < 256; ++s) {
+                const u32 L = t.len[s];
+                if (L <= (u32)SYM3_MAXK) continue;
+                const u32 code = code_of(s), key = code >> (L - SYM3_MAXK);
+                const size_t g = std::lower_bound(keys.begin(), keys.end(), key) - keys.begin();
+                const u32 suf = (code & ((1u << (L - SYM3_MAXK)) - 1)) << (16 - L), cnt = 1u << (16 - L);
+                for (u32 i = 0; i < cnt; ++i) h.longtab[8 + LONG_PFX + g * 16 + suf + i] = (u16)(s | (L << 8));
+            }
+        }
+    }
     // level 2: group the codes of K+1..K+8 bits by their first K bits
     for (int s = 0; s < 256; ++s) {
         const u32 L = t.len[s];
@@ -1139,6 +1204,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     size_t tab_bytes = 0;
     std::vector<u32> ntiles(nblocks, 0);
     bool pair_all = !getenv("SHAFA_DEC_NOPAIR");
+    bool c16_all = !getenv("SHAFA_DEC_NOLONG");
     for (int b = 0; b < nblocks; ++b) {
         if ((h_in_off[b] & 15) || (h_out_off[b] & 15)) return SHAFA_OUTSIDE_MODULE;
         build_host_tab(h_tables[b], tabs[b]);
@@ -1156,9 +1222,10 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         if (h.lmax > lmax_all) lmax_all = h.lmax;
         tab_bytes += ((h.lut.size() * 2 + 15) & ~(size_t)15) + ((h.trie.size() * 4 + 15) & ~(size_t)15) +
                      ((h.lenlut.size() + 15) & ~(size_t)15) + ((h.lut2.size() * 2 + 16 + 15) & ~(size_t)15) +
-                     ((h.lut13.size() * 2 + 15) & ~(size_t)15);
+                     ((h.lut13.size() * 2 + 15) & ~(size_t)15) + (h.longtab.empty() ? 0 : (size_t)LONG_BYTES);
         if (h.lut2.size() > max_l2) max_l2 = (u32)h.lut2.size();
         pair_all = pair_all && h.complete;
+        c16_all = c16_all && h.complete16;
     }
     if (!total_tiles) return SHAFA_SUCCESS;
     u32 R = 16;
@@ -1176,13 +1243,16 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const size_t o_cent = off; off += (size_t)total_tiles * DEC_THREADS; off = (off + 15) & ~(size_t)15;
     const size_t o_ccnt = off; off += (size_t)total_tiles * DEC_THREADS * 2; off = (off + 15) & ~(size_t)15;
     const bool packed = (R == 16);
-    const bool fast13 = lmax_all <= (u32)LEN_MAXK && !getenv("SHAFA_DEC_GENERIC");   // single-level LUT symbol passes
-    const bool multi = fast13 && pair_all && !getenv("SHAFA_DEC_NOMULTI");            // three codes per lookup
+    // 13 < Lmax <= 16, complete codes: same kernels, the rare long codes resolved from a small LDS table
+    const bool long_all = packed && !pair_all && c16_all && lmax_all > (u32)LEN_MAXK && !getenv("SHAFA_DEC_GENERIC");
+    const bool fast13 = (lmax_all <= (u32)LEN_MAXK || long_all) && !getenv("SHAFA_DEC_GENERIC");   // LUT symbol passes
+    const bool multi = fast13 && (pair_all || long_all) && !getenv("SHAFA_DEC_NOMULTI");            // three codes per lookup
+    const bool need_tabs = pair_all || long_all;
     const size_t o_pair = off; off += pair_all ? (size_t)nblocks * (2u << LEN_MAXK) : 0;
-    const size_t o_cnt3 = off; off += pair_all ? (size_t)nblocks * (2u << LEN_MAXK) : 0;
-    const size_t o_sym3 = off; off += pair_all ? (size_t)nblocks * (4u << LEN_MAXK) : 0;
-    const size_t o_fsm4 = off; off += pair_all ? (size_t)nblocks * 16384 : 0;
-    const size_t o_fsm1 = off; off += pair_all ? (size_t)nblocks * 2048 : 0;
+    const size_t o_cnt3 = off; off += need_tabs ? (size_t)nblocks * (2u << LEN_MAXK) : 0;
+    const size_t o_sym3 = off; off += need_tabs ? (size_t)nblocks * (4u << LEN_MAXK) : 0;
+    const size_t o_fsm4 = off; off += need_tabs ? (size_t)nblocks * 16384 : 0;
+    const size_t o_fsm1 = off; off += need_tabs ? (size_t)nblocks * 2048 : 0;
     const size_t o_cfn = off; off += packed ? (size_t)total_tiles * DEC_THREADS * 8 : (size_t)total_tiles * R * DEC_THREADS;
     int rc = batch_reserve(bt, off);
     if (rc) return rc;
@@ -1204,10 +1274,10 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         e.n_tiles = ntiles[b];
         e.tile_base = tbase;
         e.pairlut = pair_all ? ws + o_pair + (size_t)b * (2u << LEN_MAXK) : nullptr;
-        e.cnt3 = pair_all ? (u16 *)(ws + o_cnt3 + (size_t)b * (2u << LEN_MAXK)) : nullptr;
-        e.sym3 = pair_all ? (u32 *)(ws + o_sym3 + (size_t)b * (4u << LEN_MAXK)) : nullptr;
-        e.fsm4 = pair_all ? (u32 *)(ws + o_fsm4 + (size_t)b * 16384) : nullptr;
-        e.fsm1 = pair_all ? (u32 *)(ws + o_fsm1 + (size_t)b * 2048) : nullptr;
+        e.cnt3 = need_tabs ? (u16 *)(ws + o_cnt3 + (size_t)b * (2u << LEN_MAXK)) : nullptr;
+        e.sym3 = need_tabs ? (u32 *)(ws + o_sym3 + (size_t)b * (4u << LEN_MAXK)) : nullptr;
+        e.fsm4 = need_tabs ? (u32 *)(ws + o_fsm4 + (size_t)b * 16384) : nullptr;
+        e.fsm1 = need_tabs ? (u32 *)(ws + o_fsm1 + (size_t)b * 2048) : nullptr;
         tbase += ntiles[b];
         if (!ntiles[b]) continue;
         HostTab &h = tabs[b];
@@ -1219,9 +1289,14 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         e.n_l2 = (u32)h.lut2.size();
         if (h.lut2.size()) memcpy(hs + tpos, h.lut2.data(), h.lut2.size() * 2);
         tpos += (h.lut2.size() * 2 + 16 + 15) & ~(size_t)15;
-        e.lut13 = h.lut13.empty() ? nullptr : (const u16 *)(ws + tpos);
-        if (!h.lut13.empty()) memcpy(hs + tpos, h.lut13.data(), h.lut13.size() * 2);
+        e.lut13 = (const u16 *)(ws + tpos);
+        memcpy(hs + tpos, h.lut13.data(), h.lut13.size() * 2);
         tpos += (h.lut13.size() * 2 + 15) & ~(size_t)15;
+        if (!h.longtab.empty()) {
+            e.longtab = (const u16 *)(ws + tpos);
+            memcpy(hs + tpos, h.longtab.data(), LONG_BYTES);
+            tpos += LONG_BYTES;
+        }
         e.lenlut = ws + tpos;
         memcpy(hs + tpos, h.lenlut.data(), h.lenlut.size());
         tpos += (h.lenlut.size() + 15) & ~(size_t)15;
@@ -1259,18 +1334,20 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const u32 dbg = getenv("SHAFA_DEC_DBG") ? (u32)atoi(getenv("SHAFA_DEC_DBG")) : 0u;
     if (packed) {
         const size_t lds_count16 = lds_data + DEC_THREADS * 8 + lds_lut + 32 + DEC_THREADS + 64;
-        if (pair_all) {
-            hipLaunchKernelGGL(sfd_tables, grid_b, dim3(DEC_THREADS), 0, st, dblk);
-            hipLaunchKernelGGL(sfd_sync16<true>, grid_f, dim3(DEC_THREADS), 0, st, dblk,
+        if (need_tabs) hipLaunchKernelGGL(sfd_tables, grid_b, dim3(DEC_THREADS), 0, st, dblk);
+        if (pair_all)
+            hipLaunchKernelGGL((sfd_sync16<true, false>), grid_f, dim3(DEC_THREADS), 0, st, dblk,
                                (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw);
-        } else {
-            hipLaunchKernelGGL(sfd_sync16<false>, grid_f, dim3(DEC_THREADS), 0, st, dblk,
+        else if (long_all)
+            hipLaunchKernelGGL((sfd_sync16<false, true>), grid_f, dim3(DEC_THREADS), 0, st, dblk,
                                (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw);
-        }
+        else
+            hipLaunchKernelGGL((sfd_sync16<false, false>), grid_f, dim3(DEC_THREADS), 0, st, dblk,
+                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw);
         hipLaunchKernelGGL(sfd_tiles16, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u64 *)(ws + o_tilefn),
                            ws + o_tent);
         if (fast13) {
-            if (multi && !getenv("SHAFA_DEC_NOFSM"))
+            if (multi && (long_all || !getenv("SHAFA_DEC_NOFSM")))
                 hipLaunchKernelGGL((sfd_countfsm<CSUBS>), grid_c, dim3(DEC_THREADS * CSUBS), 0, st, dblk,
                                    (const u64 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
                                    (u32 *)(ws + o_tcnt), tpw);
@@ -1298,11 +1375,14 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     hipLaunchKernelGGL(sfd_offsets, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u32 *)(ws + o_tcnt),
                        (u64 *)(ws + o_toff));
     if (fast13) {
-        if (multi)
-            hipLaunchKernelGGL((sfd_write13<true, WSUBS>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
+        if (multi && long_all)
+            hipLaunchKernelGGL((sfd_write13<true, WSUBS, true>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
+                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, dbg);
+        else if (multi)
+            hipLaunchKernelGGL((sfd_write13<true, WSUBS, false>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
                                (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, dbg);
         else
-            hipLaunchKernelGGL((sfd_write13<false, WSUBS>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
+            hipLaunchKernelGGL((sfd_write13<false, WSUBS, false>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
                                (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, dbg);
     } else {
         hipLaunchKernelGGL(sfd_write, grid_t, dim3(DEC_THREADS), lds_write, st, dblk, l2cap, (const u8 *)(ws + o_cent),

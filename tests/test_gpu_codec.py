@@ -237,3 +237,60 @@ def test_full_pipeline_roundtrip_batch(oracle, shafa):
     bt.finish(st, nb)
     assert (d_on.cpu().numpy() == bs).all()
     assert torch.equal(d_orig, d_in), "D(C(T(F(x)))) != x"
+
+
+def test_sf_decode_codes_of_14_to_16_bits_fast_path(oracle, shafa):
+    """Complete codes with 13 < Lmax <= 16 (steep Zipf): the nibble-ring DP, the counting automaton and the
+    three-code write pass with the long codes resolved from the LDS prefix table."""
+    for s, seed in ((1.6, 31), (2.0, 32), (2.5, 33)):
+        zt = shafa.zipf_table(s)
+        for n in (4096, 70001, (1 << 21) + 13):
+            data = oracle.gen_bytes(seed + n, n, zt)
+            otab = oracle.sf_build(oracle.hist256(data))
+            got, enc = decode_roundtrip(oracle, shafa, data, otab)
+            assert got.tobytes() == data.tobytes(), f"s={s} n={n} lmax={otab.lens().max()}: {first_diff(got, data)}"
+    # the table of a big block (Lmax 15/16) applied to a stream that is dense in its rarest symbols
+    zt = shafa.zipf_table(2.0)
+    big = oracle.gen_bytes(77, 1 << 24, zt)
+    otab = oracle.sf_build(oracle.hist256(big))
+    lens = otab.lens()
+    assert 13 < lens.max() <= 16, lens.max()
+    rare = np.nonzero(lens >= 13)[0].astype(np.uint8)
+    mix = big[:300000].copy()
+    mix[::3] = rare[np.arange(mix[::3].size) % rare.size]          # every third symbol has a 13..16-bit code
+    got, enc = decode_roundtrip(oracle, shafa, mix, otab)
+    assert got.tobytes() == mix.tobytes(), first_diff(got, mix)
+    # truncated stream on this path is still an error
+    rc, _ = shafa.sf_decode(enc[: enc.size // 2], to_shafa_table(shafa, otab), len(mix), raw_rc=True)
+    assert rc == shafa.FILE_UNRECOGNIZABLE
+
+
+def test_sf_decode_batch_mixing_short_and_long_tables(oracle, shafa):
+    """One launch whose blocks have Lmax 12 and Lmax 15/16 (all complete): the long-code kernels serve both."""
+    import torch
+    dev = torch.device("cuda:0")
+    st = torch.cuda.Stream()
+    blocks = [oracle.gen_bytes(5, 500000, shafa.zipf_table(1.2)), oracle.gen_bytes(6, 400001, shafa.zipf_table(2.0)),
+              oracle.gen_bytes(7, 300000, shafa.zipf_table(1.2)), oracle.gen_bytes(8, 1 << 20, shafa.zipf_table(1.6))]
+    tabs = [oracle.sf_build(oracle.hist256(b)) for b in blocks]
+    assert max(t.lens().max() for t in tabs) > 13 and min(t.lens().max() for t in tabs) <= 13
+    encs = []
+    for b, t in zip(blocks, tabs):
+        rc, e = oracle.sf_encode(b, t)
+        assert rc == 0
+        encs.append(e)
+    cap = ((max(len(e) for e in encs) + 255) // 256) * 256
+    ocap = ((max(len(b) for b in blocks) + 255) // 256) * 256
+    nb = len(blocks)
+    h_in = np.zeros(nb * cap, dtype=np.uint8)
+    for i, e in enumerate(encs):
+        h_in[i * cap:i * cap + len(e)] = e
+    d_in = torch.from_numpy(h_in).to(dev)
+    d_out = torch.zeros(nb * ocap, dtype=torch.uint8, device=dev)
+    bt = shafa.Batch(nb, ocap)
+    bt.sf_decode(st, d_in, [i * cap for i in range(nb)], [len(e) for e in encs], [to_shafa_table(shafa, t) for t in tabs],
+                 [len(b) for b in blocks], d_out, [i * ocap for i in range(nb)])
+    bt.finish(st, nb)
+    out = d_out.cpu().numpy()
+    for i, b in enumerate(blocks):
+        assert out[i * ocap:i * ocap + len(b)].tobytes() == b.tobytes(), f"block {i}: {first_diff(out[i * ocap:i * ocap + len(b)], b)}"
