@@ -1,0 +1,16 @@
+#!/bin/bash
+# per-kernel averages for tools/kernel_table.py (all five kernel families); usage: gpu_kstats_table.sh <blocks>
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+export TMPDIR=/tmp
+out=gpurun_out/kstats_table
+rm -rf $out; mkdir -p $out
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o r -- python3 tools/kernel_table.py ${1:-16} > $out/table.txt 2> $out/err.log
+cat $out/table.txt | tail -8
+f=$(find $out -name '*kernel_stats.csv' | head -1)
+python3 - "$f" <<'PY'
+import csv, sys, re
+for r in csv.DictReader(open(sys.argv[1])):
+    n = re.sub(r'\(.*', '', r['Name'].replace('(anonymous namespace)::', '').replace('void ', ''))[:48]
+    if float(r['Percentage']) < 0.3: continue
+    print(f"{n:50s} calls {r['Calls']:>5s} avg_us {float(r['AverageNs'])/1e3:10.1f}  {float(r['Percentage']):5.1f}%")
+PY
