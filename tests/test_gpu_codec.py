@@ -294,3 +294,42 @@ def test_sf_decode_batch_mixing_short_and_long_tables(oracle, shafa):
     out = d_out.cpu().numpy()
     for i, b in enumerate(blocks):
         assert out[i * ocap:i * ocap + len(b)].tobytes() == b.tobytes(), f"block {i}: {first_diff(out[i * ocap:i * ocap + len(b)], b)}"
+
+
+def _random_complete_table(oracle, rng, nsyms, skew):
+    """Shannon-Fano table of a random histogram: `skew` stretches the counts geometrically (deeper trees)."""
+    freq = np.zeros(256, dtype=np.uint64)
+    syms = rng.permutation(256)[:nsyms]
+    w = rng.random(nsyms) ** skew
+    freq[syms] = np.maximum(1, (w / w.max() * 2.0 ** 40).astype(np.uint64))
+    return oracle.sf_build(freq), syms.astype(np.uint8), w / w.sum()
+
+
+def test_sf_roundtrip_random_tables_and_sizes(oracle, shafa):
+    """Property test over random complete tables (Lmax from 2 to > 16, i.e. every decode path) and ragged sizes:
+    the HIP encoder equals the oracle's bytes and the HIP decoder returns the data; sizes straddle chunk (32 B),
+    tile (8 KiB) and multi-tile-per-workgroup boundaries of the encoded stream."""
+    rng = np.random.default_rng(20261003)
+    seen = set()
+    for trial in range(40):
+        nsyms = int(rng.integers(2, 257))
+        skew = float(rng.choice([0.5, 1.0, 3.0, 8.0, 20.0]))
+        otab, syms, prob = _random_complete_table(oracle, rng, nsyms, skew)
+        lmax = int(otab.lens().max())
+        seen.add("<=13" if lmax <= 13 else "14-16" if lmax <= 16 else ">16")
+        n = int(rng.choice([1, 5, 31, 257, 4097, 8191, 8193, 40001, 65536 * 4 + 3, 1 << 20]))
+        data = syms[rng.choice(nsyms, size=n, p=prob)]
+        if n >= nsyms and trial % 3 == 0:
+            data[:nsyms] = syms                                    # every symbol, including the rarest codes
+        rc, want = oracle.sf_encode(data, otab)
+        assert rc == 0
+        t = to_shafa_table(shafa, otab)
+        got = shafa.sf_encode(data, t)
+        assert got.tobytes() == want.tobytes(), f"trial {trial} encode lmax={lmax} n={n}: {first_diff(got, want)}"
+        if nsyms >= 2:
+            back = shafa.sf_decode(want, t, n)
+            assert back.tobytes() == data.tobytes(), f"trial {trial} decode lmax={lmax} n={n} nsyms={nsyms}: {first_diff(back, data)}"
+            if want.size > 2:                                       # a truncated stream is an error on every path
+                rc2, _ = shafa.sf_decode(want[: want.size - 2], t, n, raw_rc=True)
+                assert rc2 == shafa.FILE_UNRECOGNIZABLE, f"trial {trial} lmax={lmax} n={n}: truncated stream accepted"
+    assert seen == {"<=13", "14-16", ">16"}, seen
