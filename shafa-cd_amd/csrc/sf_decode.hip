@@ -44,6 +44,8 @@ constexpr int SYM3_MAXK = 12;                      // window of the three-codes 
 constexpr int LDS_DATA = (DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
 constexpr int LONG_PFX = 128;                      // codes longer than SYM3_MAXK bits, grouped by their first SYM3_MAXK bits
 constexpr int LONG_BYTES = 16 + LONG_PFX * 2 + LONG_PFX * 16 * 2;   // [n u16 x8 pad][pfx u16 x128][ent u16 x128x16]
+// codes of 13..32 bits: [n u16 x8 pad][pfx u16 x128][root u16 x128][nodes {child0, child1} u16 x2 x256]; child = node | 0x8000|sym
+constexpr int LONG32_BYTES = 16 + LONG_PFX * 2 + LONG_PFX * 2 + 256 * 4 + LONG_PFX * 2;   // + root13 u16 x128 (13-bit prefixes)
 constexpr int LEN_MAXK = 13;                       // length-only LUT of the packed DP: 8 KiB
 
 struct DecBlk {
@@ -57,7 +59,7 @@ struct DecBlk {
     const u16 *lut2;       // level 2 (codes of K+1 .. K+8 bits): sym | len << 8 ; 0 = go to the trie
     const u8 *lenlut;      // 2^K1 entries: len only (DP of the packed path); 0 = longer than K1 bits
     u16 *cnt3;             // 2^K1 entries: up to three codes per window: total bits | len0 << 4 | n << 12
-    u32 *sym3;             // 2^K3 entries: sym0 | sym1 << 8 | sym2 << 16 | total bits << 24 (5 bits) | n << 29
+    u32 *sym3;             // 2^K3 entries: sym0 | sym1 << 8 | sym2 << 16 | total bits << 24 (6 bits) | n << 30
     u8 *pairlut;           // 2^(K1+1) entries: (len(p)-1) | (len(p+1)-1) << 4 from a K1+1-bit window (complete codes)
     const u16 *lut13;      // 2^K1 entries: sym | len << 8, single level (only when Lmax <= 13), else NULL
     const u32 *trie;       // pairs {child0, child1}: 0x80000000|sym = leaf, 0xFFFFFFFF = missing
@@ -70,6 +72,8 @@ struct DecBlk {
     u32 n_states;          // internal trie nodes = states of the counting automaton (<= 255 for a complete code)
     u32 *fsm4;             // [state][nibble]: next state * 64 | codes completed << 16   (complete codes; sfd_tables)
     u32 *fsm1;             // [state][bit]   : same, for one bit
+    const u8 *lenlut32;    // 2^13 entries: len <= 13, or 128 + k = internal node root13[k] of long32 (16 < Lmax <= 32 launches)
+    const u16 *long32;     // LONG32_BYTES: sorted 12-bit prefixes of the codes of 13..32 bits + their sub-tries
     const u16 *longtab;    // LONG_BYTES: sorted 12-bit prefixes of the codes of 13..16 bits + 16 entries sym | len << 8 each
 };
 
@@ -199,6 +203,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tiles(const DecBlk *__restric
                                                          const u8 *__restrict__ tilefn, u8 *__restrict__ tile_entry)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];   // 256 * R bytes of maps + 256 entries
+    __shared__ u8 segmap[8 * 32], segent[8];
     const DecBlk blk = blks[blockIdx.x];
     u8 *maps = smem;
     u8 *ent = smem + (size_t)R * DEC_THREADS;
@@ -209,7 +214,23 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tiles(const DecBlk *__restric
         const u8 *src = tilefn + (size_t)(blk.tile_base + t0) * R;
         for (u32 i = tid; i < nt * R / 4; i += DEC_THREADS) ((u32 *)maps)[i] = ((const u32 *)src)[i];
         __syncthreads();
-        if (tid == 0) {
+        if (R == 32) {
+            // thread (sg, d) follows entry d through segment sg (32 tiles), thread 0 links the 8 segments, then one
+            // thread per segment walks it from its real entry: 32 + 8 + 32 dependent reads instead of 256
+            const u32 sg = tid >> 5, d = tid & 31u, lo = sg * 32 < nt ? sg * 32 : nt, hi = lo + 32 < nt ? lo + 32 : nt;
+            u32 x = d;
+            for (u32 t = lo; t < hi; ++t) x = maps[t * R + (x & 31u)];
+            segmap[sg * 32 + d] = (u8)x;
+            __syncthreads();
+            if (tid == 0) {
+                for (u32 q = 0; q < 8; ++q) { segent[q] = (u8)v; v = segmap[q * 32 + (v & 31u)]; }
+            }
+            __syncthreads();
+            if (d == 0) {
+                u32 y = segent[sg];
+                for (u32 t = lo; t < hi; ++t) { ent[t] = (u8)y; y = maps[t * R + (y & 31u)]; }
+            }
+        } else if (tid == 0) {
             for (u32 t = 0; t < nt; ++t) { ent[t] = (u8)v; v = maps[t * R + v]; }
         }
         __syncthreads();
@@ -299,6 +320,27 @@ __device__ __forceinline__ u32 long_code(const u16 *lt, u32 win32)
     return (lo < n && pfx[lo] == key) ? ent[lo * 16 + ((win32 >> 16) & 15u)] : 0u;
 }
 
+// code of 13..32 bits at the head of `win32`: binary search of its first 12 bits, then a walk of the sub-trie.
+// Returns sym | len << 8, 0 when there is none.
+__device__ __forceinline__ u32 long_code32(const u16 *lt, u32 win32)
+{
+    const u32 n = lt[0], key = win32 >> 20;
+    const u16 *pfx = lt + 8, *root = lt + 8 + LONG_PFX, *nodes = lt + 8 + 2 * LONG_PFX;
+    u32 lo = 0, hi = n;
+    while (lo < hi) {
+        const u32 mid = (lo + hi) >> 1;
+        if (pfx[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= n || pfx[lo] != key) return 0u;
+    u32 node = root[lo];
+    for (u32 depth = (u32)SYM3_MAXK; depth < 32; ++depth) {
+        const u32 c = nodes[2 * node + ((win32 >> (31 - depth)) & 1u)];
+        if (c & 0x8000u) return (c & 0xFFu) | ((depth + 1) << 8);
+        node = c;
+    }
+    return 0u;
+}
+
 // copy a device table (16-byte aligned, padded to 16 bytes in the workspace) into LDS
 __device__ __forceinline__ void fill_lds16(void *dst, const void *src, u32 bytes)
 {
@@ -336,7 +378,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
             syms |= (e & 0xFFu) << (8 * n);
             pos += L;
         }
-        blk.sym3[i] = syms | (pos << 24) | (n << 29);
+        blk.sym3[i] = syms | (pos << 24) | (n << 30);
     }
     // counting automaton: state = internal trie node (0 = root = between two codes); consuming a nibble (or a bit)
     // moves to the next state and completes 0..4 codes.  next state is stored as the byte offset of its row.
@@ -449,6 +491,227 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_sync16(const DecBlk *__restri
         for (int d = 1; d < 16; d <<= 1) m |= __shfl_xor(m, d, 64);
         if (tid == 0) tilefn[(size_t)blk.tile_base + tile] = m;
     }
+    }
+}
+
+// ================================================================================================
+// Complete codes with 16 < Lmax <= 32 (rare bytes of real files at -b M).  Entry offsets reach 31, so chunk maps
+// are 32 bytes (the byte-map plumbing of the generic path: sfd_tiles, [tile][d][chunk] layout), but the heavy loops
+// are the fast ones: the DP keeps the low nibble of every exit in the register ring plus one bit per position for
+// "exit >= 16"; a code longer than 16 bits at some bit position (rare: its probability) is followed forward to
+// the end of the chunk instead of being looked up in the ring.
+// ================================================================================================
+__device__ __forceinline__ u32 tile_bit_limit(const DecBlk &blk, u32 tile);
+
+__device__ __forceinline__ u32 win32_at(const u32 *data, u32 p)
+{
+    const u32 w = p >> 5, r = p & 31;
+    const u32 w0 = data[widx(w)], w1 = data[widx(w + 1)];
+    return r ? __builtin_amdgcn_alignbit(w0, w1, 32 - r) : w0;
+}
+
+// length of a code longer than 13 bits: `esc` = 128 + k from lenlut32 names the trie node reached after 13 bits
+__device__ __forceinline__ u32 sync32_long_len(const u16 *lt, u32 esc, u32 win)
+{
+    const u16 *nodes = lt + 8 + 2 * LONG_PFX, *root13 = nodes + 512;
+    u32 node = root13[esc - 128u];
+    for (u32 depth = 13; depth < 32; ++depth) {
+        const u32 c = nodes[2 * node + ((win >> (31 - depth)) & 1u)];
+        if (c & 0x8000u) return depth + 1;
+        node = c;
+    }
+    return 1u;
+}
+
+// static LDS: data | maps[32][256] u8 | lenlut[2^13] u8 | long32 | wfn[4][32] u8
+__global__ __launch_bounds__(DEC_THREADS) void sfd_sync32(const DecBlk *__restrict__ blks, u8 *__restrict__ chunkfn,
+                                                          u8 *__restrict__ tilefn, u32 tpw)
+{
+    constexpr u32 R = 32;
+    __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + R * DEC_THREADS + (1 << LEN_MAXK) + LONG32_BYTES + 4 * R + 64];
+    const DecBlk blk = blks[blockIdx.y];
+    if (blockIdx.x * tpw >= blk.n_tiles) return;
+    u32 *data = (u32 *)smem;
+    u8 *maps = smem + LDS_DATA;
+    u8 *lenlut = maps + R * DEC_THREADS;
+    const u16 *lt = (const u16 *)(lenlut + (1 << LEN_MAXK));
+    u8 *wfn = (u8 *)lt + LONG32_BYTES;
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 K1 = blk.K1, lmax = blk.lmax, sh = 32 - K1;
+
+    if (blk.long32) fill_lds16((void *)lt, blk.long32, LONG32_BYTES);
+    else if (tid == 0) *(u16 *)lt = 0;
+    fill_lds16(lenlut, blk.lenlut32, 1u << K1);
+    const u32 tile_end = (blockIdx.x + 1) * tpw < blk.n_tiles ? (blockIdx.x + 1) * tpw : blk.n_tiles;
+    for (u32 tile = blockIdx.x * tpw; tile < tile_end; ++tile) {
+    __syncthreads();                                   // previous tile's LDS reads are done
+    load_tile(data, blk, tile);
+    __syncthreads();
+
+    // ring nibble j / hb bit j = low nibble / "exit >= 16" of position p + 1 + j; positions 256 + j exit at j
+    // ring2 nibble j = low nibble of position p + 17 + j (codes of 17..32 bits look there)
+    u64 ring = 0xFEDCBA9876543210ull, ring2 = 0xFEDCBA9876543210ull, mapB = 0;
+    u32 hb = 0xFFFF0000u, hbB = 0;
+    const u32 cw = tid * (CH_BITS / 32);
+    u32 w1 = data[widx(cw + 8)];
+    for (int wi = 7; wi >= 0; --wi) {
+        const u32 w0 = data[widx(cw + wi)];
+        u32 len[32];
+#pragma unroll
+        for (int r = 31; r >= 0; --r) {
+            const u32 win = r ? __builtin_amdgcn_alignbit(w0, w1, 32 - r) : w0;
+            len[r] = lenlut[win >> sh];
+        }
+#pragma unroll
+        for (int r = 31; r >= 0; --r) {
+            u32 l = len[r];
+            u32 xlo;
+            if (__builtin_expect(l >= 128, 0)) {       // longer than 13 bits (rare): walk the sub-trie; 17..32 bits look in ring2
+                l = sync32_long_len(lt, l, r ? __builtin_amdgcn_alignbit(w0, w1, 32 - r) : w0);
+                xlo = l > 16 ? nib(ring2, l - 17) : nib(ring, l - 1);
+            } else {
+                xlo = nib(ring, l - 1);
+            }
+            const u32 xhi = (hb >> (l - 1)) & 1u;
+            ring2 = (ring2 << 4) | (u32)(ring >> 60);
+            ring = (ring << 4) | xlo;
+            hb = (hb << 1) | xhi;
+            if (wi == 0 && r == 16) { mapB = ring; hbB = hb; }     // exits of positions 16..31
+        }
+        w1 = w0;
+    }
+    // the 32 exits of this chunk as bytes: maps[d][tid]
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        maps[((u32)d << 8) + tid] = (u8)(nib(ring, (u32)d) | (((hb >> d) & 1u) << 4));
+        maps[((u32)(d + 16) << 8) + tid] = (u8)(nib(mapB, (u32)d) | (((hbB >> d) & 1u) << 4));
+    }
+    __syncthreads();
+
+    // chunk maps to global: rows d < lmax, 256 bytes each (coalesced)
+    u8 *cf = chunkfn + ((size_t)(blk.tile_base + tile) * R << 8);
+    for (u32 i = tid; i < lmax * (DEC_THREADS / 4); i += DEC_THREADS)
+        ((u32 *)cf)[i] = ((const u32 *)maps)[i];
+    // wave maps: two halves of 32 chunks, lane (h, d) follows entry d through half h; then joined
+    {
+        const u32 h = lane >> 5, d = lane & 31u;
+        u32 v = d;
+        for (u32 c = 0; c < 32; ++c) v = maps[((v & 31u) << 8) + wv * 64 + h * 32 + c];
+        const u32 v2 = (u32)__shfl((int)v, 32 + (int)(__shfl((int)v, (int)d, 64) & 31), 64);   // second half applied to the first
+        if (lane < 32) wfn[wv * R + d] = (u8)v2;
+    }
+    __syncthreads();
+    u8 *tf = tilefn + (size_t)(blk.tile_base + tile) * R;
+    if (tid < lmax) {
+        u32 v = tid;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v = wfn[w * R + (v & 31u)];
+        tf[tid] = (u8)v;
+    }
+    }
+}
+
+// counting automaton with 32-entry byte maps.  static LDS: data | maps[32][256] | fsm4 | fsm1 | wfn[4][32] | went[4][2] | ent[256] | wsum[4]
+__global__ __launch_bounds__(DEC_THREADS) void sfd_countfsm32(const DecBlk *__restrict__ blks,
+                                                              const u8 *__restrict__ chunkfn,
+                                                              const u8 *__restrict__ tile_entry,
+                                                              u8 *__restrict__ chunk_entry, u16 *__restrict__ chunk_cnt,
+                                                              u32 *__restrict__ tile_cnt, u32 tpw)
+{
+    constexpr u32 R = 32;
+    __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + R * DEC_THREADS + 16384 + 2048 + 4 * R + 16 + DEC_THREADS + 64];
+    const DecBlk blk = blks[blockIdx.y];
+    if (blockIdx.x * tpw >= blk.n_tiles) return;
+    u32 *data = (u32 *)smem;
+    u8 *maps = smem + LDS_DATA;
+    const u8 *f4 = maps + R * DEC_THREADS;
+    const u8 *f1 = f4 + 16384;
+    u8 *wfn = (u8 *)f1 + 2048;
+    u8 *went = wfn + 4 * R;
+    u8 *ent = went + 16;
+    u32 *wsum = (u32 *)(ent + DEC_THREADS);
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 lmax = blk.lmax;
+
+    fill_lds16((void *)f4, blk.fsm4, blk.n_states * 64);
+    fill_lds16((void *)f1, blk.fsm1, blk.n_states * 8);
+    const u32 tile_end = (blockIdx.x + 1) * tpw < blk.n_tiles ? (blockIdx.x + 1) * tpw : blk.n_tiles;
+    for (u32 tile = blockIdx.x * tpw; tile < tile_end; ++tile) {
+    const size_t gt = (size_t)blk.tile_base + tile;
+    __syncthreads();
+    load_tile(data, blk, tile);
+    {
+        const u8 *cf = chunkfn + (gt * R << 8);
+        for (u32 i = tid; i < lmax * (DEC_THREADS / 4); i += DEC_THREADS) ((u32 *)maps)[i] = ((const u32 *)cf)[i];
+    }
+    __syncthreads();
+    // half maps (lane (h, d) follows entry d through 32 chunks), wave maps, wave / half entries, chunk entries
+    const u32 h = lane >> 5, d = lane & 31u;
+    u32 hv = d;
+    for (u32 c = 0; c < 32; ++c) hv = maps[((hv & 31u) << 8) + wv * 64 + h * 32 + c];
+    {
+        const u32 v2 = (u32)__shfl((int)hv, 32 + (int)(__shfl((int)hv, (int)d, 64) & 31), 64);
+        if (lane < 32) wfn[wv * R + d] = (u8)v2;
+    }
+    __syncthreads();
+    {
+        u32 e = tile_entry[gt];
+        for (u32 w = 0; w < wv; ++w) e = wfn[w * R + (e & 31u)];         // entry of this wave
+        const u32 e1 = (u32)__shfl((int)hv, (int)(e & 31u), 64);                  // entry of its second half
+        if (lane == 0 || lane == 32) {
+            u32 v = lane ? e1 : e;
+            for (u32 c = 0; c < 32; ++c) {
+                ent[wv * 64 + h * 32 + c] = (u8)v;
+                v = maps[((v & 31u) << 8) + wv * 64 + h * 32 + c];
+            }
+        }
+    }
+    __syncthreads();
+    const u32 entry = ent[tid];
+    const u32 limit = tile_bit_limit(blk, tile);
+    const bool last = limit < (u32)(DTILE + HALO_WORDS * 4) * 8;
+    const u32 cw = tid * (CH_BITS / 32), cbase = tid * CH_BITS;
+    u32 st = 0, cnt = 0, p = entry;
+    auto bit_step = [&](u32 q) {
+        const u32 bit = (data[widx(q >> 5)] >> (31 - (q & 31))) & 1u;
+        const u32 e = *(const u32 *)(f1 + (st >> 3) + bit * 4);
+        st = e & 0xFFFFu;
+        cnt += e >> 16;
+    };
+    if (!last) {
+        while (p & 3) { bit_step(cbase + p); ++p; }    // p <= 32 afterwards
+        const u32 j0 = p >> 2;                          // first whole nibble (0..8): word 0, or the start of word 1
+#pragma unroll
+        for (int wi = 0; wi < 8; ++wi) {
+            const u32 w = data[widx(cw + wi)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const u32 nib4 = j < 7 ? (w >> (26 - 4 * j)) & 0x3Cu : (w << 2) & 0x3Cu;
+                const u32 e = *(const u32 *)(f4 + st + nib4);
+                if (wi == 0) {                          // nibbles before the entry belong to the previous chunk
+                    if ((u32)j >= j0) { st = e & 0xFFFFu; cnt += e >> 16; }
+                } else {
+                    st = e & 0xFFFFu;
+                    cnt += e >> 16;
+                }
+            }
+        }
+        cnt += st != 0;
+    } else {
+        const u32 stop = cbase + CH_BITS < limit ? cbase + CH_BITS : limit;
+        u32 q = cbase + p;
+        for (; q < stop; ++q) bit_step(q);
+        if (st != 0 && q == cbase + CH_BITS) {
+            const u32 before = cnt;
+            for (; q < limit && cnt == before; ++q) bit_step(q);
+        }
+    }
+    chunk_entry[gt * DEC_THREADS + tid] = (u8)entry;
+    chunk_cnt[gt * DEC_THREADS + tid] = (u16)cnt;
+    const u32 tot = wave_reduce_add<u32>(cnt);
+    if (lane == 0) wsum[wv] = tot;
+    __syncthreads();
+    if (tid == 0) tile_cnt[gt] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
 }
 
@@ -873,14 +1136,14 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) __attribute__((amdgpu_waves_per
 // sfd_write13: static LDS: SUBS x data | lut13[2^13] u16 (MULTI: sym3[2^12] u32) | SUBS x wsum[4]
 // A workgroup is SUBS groups of 256 lanes, each decoding its own tile, sharing one copy of the table: the loop is
 // latency bound (dependent LDS look-ups), so what counts is waves per CU, and the table is what limits them.
-template <bool MULTI, int SUBS, bool LONG>
+template <bool MULTI, int SUBS, int LONG>
 __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *__restrict__ blks,
                                                                   const u8 *__restrict__ chunk_entry,
                                                                   const u16 *__restrict__ chunk_cnt,
                                                                   const u64 *__restrict__ tile_off, u32 tpw, u32 dbg)
 {
     constexpr int TAB = MULTI ? (4 << SYM3_MAXK) : (2 << LEN_MAXK);
-    __shared__ __attribute__((aligned(16))) u8 smem[SUBS * LDS_DATA + TAB + SUBS * 16 + 64 + (LONG ? LONG_BYTES : 0)];
+    __shared__ __attribute__((aligned(16))) u8 smem[SUBS * LDS_DATA + TAB + SUBS * 16 + 64 + (LONG == 1 ? LONG_BYTES : LONG == 2 ? LONG32_BYTES : 0)];
     const DecBlk blk = blks[blockIdx.y];
     const u32 first_tile = blockIdx.x * tpw * SUBS;
     if (first_tile >= blk.n_tiles) return;
@@ -894,7 +1157,8 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *
     const u32 K3 = K1 < (u32)SYM3_MAXK ? K1 : (u32)SYM3_MAXK;
     fill_lds16(lut, MULTI ? (const void *)blk.sym3 : (const void *)blk.lut13, MULTI ? (4u << K3) : (2u << K1));
     if (LONG) {
-        if (blk.longtab) fill_lds16((void *)lt, blk.longtab, LONG_BYTES);
+        const u16 *src = LONG == 1 ? blk.longtab : blk.long32;
+        if (src) fill_lds16((void *)lt, src, LONG == 1 ? LONG_BYTES : LONG32_BYTES);
         else if (threadIdx.x == 0) *(u16 *)lt = 0;
     }
     bool bad = false;
@@ -935,12 +1199,13 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *
         bool have_pend = false;
         while (want) {                                  // up to three symbols per lookup; stops on the count
             u32 e = tab[bb.peek32() >> sh3];
-            if (__builtin_expect((e >> 29) == 0, 0)) {  // first code longer than the window: one code from lut13 / the long table
-                u32 e1 = LONG ? long_code(lt, bb.peek32()) : (u32)gload<u16>(blk.lut13 + (bb.peek32() >> sh));
+            if (__builtin_expect((e >> 30) == 0, 0)) {  // first code longer than the window: one code from lut13 / the long table
+                u32 e1 = LONG == 1 ? long_code(lt, bb.peek32()) : LONG == 2 ? long_code32(lt, bb.peek32())
+                                   : (u32)gload<u16>(blk.lut13 + (bb.peek32() >> sh));
                 if (e1 == 0) { bad = true; e1 = 1u << 8; }      // not a code (complete tables never get here)
-                e = (e1 & 0xFFu) | ((e1 >> 8) << 24) | (1u << 29);
+                e = (e1 & 0xFFu) | ((e1 >> 8) << 24) | (1u << 30);
             }
-            const u32 n = e >> 29, take = n < want ? n : want, syms = e & 0xFFFFFFu;
+            const u32 n = e >> 30, take = n < want ? n : want, syms = e & 0xFFFFFFu;
             acc |= (u64)syms << (8 * nb);
             const u32 room = 8 - nb;                    // bytes of `syms` that fitted
             nb += take;
@@ -956,7 +1221,11 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *
                 nb -= 8;
                 acc = room < 3 ? (u64)(syms >> (8 * room)) : 0ull;
             }
-            bb.skip(data, (e >> 24) & 31u);
+            {
+                const u32 tot = (e >> 24) & 63u;
+                p += tot;
+                if (LONG == 2 && __builtin_expect(tot > 31, 0)) bb.init(data, cbase + p); else bb.skip(data, tot);
+            }
         }
         if (have_pend) { gstore<u64>(op, pend); op += 8; }
         for (u32 q = 0; q < nb; ++q) gstore<u8>(op + q, (u8)(acc >> (8 * q)));
@@ -1078,8 +1347,10 @@ struct HostTab {
     std::vector<u16> lut, lut2, lut13;
     std::vector<u8> lenlut;
     std::vector<u16> longtab;  // LONG_BYTES / 2 entries when 12 < Lmax <= 16 and the code is complete
+    std::vector<u16> long32;   // LONG32_BYTES / 2 entries when 12 < Lmax <= 32 and the code is complete
+    std::vector<u8> lenlut32;  // lenlut with escape ids 128 + k for the 13-bit prefixes of longer codes (with long32)
     u32 K, K1, lmax;
-    bool ok, empty, complete, complete16;
+    bool ok, empty, complete, complete16, complete32;
 };
 
 void build_host_tab(const shafa_code_table &t, HostTab &h)
@@ -1088,6 +1359,7 @@ void build_host_tab(const shafa_code_table &t, HostTab &h)
     h.ok = true;
     h.complete = false;
     h.complete16 = false;
+    h.complete32 = false;
     h.lmax = 0;
     for (int s = 0; s < 256; ++s) h.lmax = t.len[s] > h.lmax ? t.len[s] : h.lmax;
     h.empty = h.lmax == 0;
@@ -1141,6 +1413,78 @@ void build_host_tab(const shafa_code_table &t, HostTab &h)
         u64 kraft = 0;
         for (int s = 0; s < 256; ++s) if (t.len[s]) kraft += 1ull << (16 - t.len[s]);
         h.complete16 = kraft == 65536;
+    }
+    if (h.lmax > (u32)SYM3_MAXK && h.lmax <= 32) {      // complete tree with codes of 13..32 bits
+        u64 kraft = 0;
+        for (int s = 0; s < 256; ++s) if (t.len[s]) kraft += 1ull << (32 - t.len[s]);
+        h.complete32 = kraft == (1ull << 32);
+    }
+    if (h.complete32) {                                 // 12-bit prefixes of the codes of 13..32 bits + their sub-tries
+        h.long32.assign(LONG32_BYTES / 2, 0);
+        struct Item { u32 key, node; };
+        std::vector<Item> roots;
+        // walk the trie to depth SYM3_MAXK
+        std::vector<Item> frontier{{0u, 0u}};
+        for (int depth = 0; depth < SYM3_MAXK; ++depth) {
+            std::vector<Item> next;
+            for (const Item &it : frontier)
+                for (u32 b = 0; b < 2; ++b) {
+                    const u32 c = h.trie[2 * it.node + b];
+                    if (c != 0xFFFFFFFFu && !(c & 0x80000000u)) next.push_back({(it.key << 1) | b, c});
+                }
+            frontier.swap(next);
+        }
+        roots = frontier;                               // internal nodes at depth 12, keys ascending by construction? sort anyway
+        std::sort(roots.begin(), roots.end(), [](const Item &a, const Item &b) { return a.key < b.key; });
+        std::vector<u32> order;                         // sub-trie nodes, renumbered in BFS order
+        std::vector<int> newid(h.trie.size() / 2, -1);
+        if (roots.size() > (size_t)LONG_PFX) h.complete32 = false;
+        for (size_t g = 0; g < roots.size() && h.complete32; ++g) {
+            std::vector<u32> q{roots[g].node};
+            for (size_t qi = 0; qi < q.size(); ++qi) {
+                const u32 nd = q[qi];
+                newid[nd] = (int)order.size();
+                order.push_back(nd);
+                for (u32 b = 0; b < 2; ++b) {
+                    const u32 c = h.trie[2 * nd + b];
+                    if (!(c & 0x80000000u)) q.push_back(c);
+                }
+            }
+        }
+        // BFS numbering above interleaves ids before children are numbered: assign child ids in a second pass
+        if (order.size() > 256) h.complete32 = false;
+        if (h.complete32) {
+            h.long32[0] = (u16)roots.size();
+            for (size_t g = 0; g < roots.size(); ++g) {
+                h.long32[8 + g] = (u16)roots[g].key;
+                h.long32[8 + LONG_PFX + g] = (u16)newid[roots[g].node];
+            }
+            for (size_t i = 0; i < order.size(); ++i)
+                for (u32 b = 0; b < 2; ++b) {
+                    const u32 c = h.trie[2 * order[i] + b];
+                    h.long32[8 + 2 * LONG_PFX + 2 * i + b] = (c & 0x80000000u) ? (u16)(0x8000u | (c & 0xFFu)) : (u16)newid[c];
+                }
+            // 13-bit prefixes of the codes longer than 13 bits: lenlut32 names their trie node
+            if (h.lmax > (u32)LEN_MAXK) {
+                h.lenlut32.assign(h.lenlut.begin(), h.lenlut.end());
+                std::vector<Item> f13{{0u, 0u}};
+                for (int depth = 0; depth < LEN_MAXK; ++depth) {
+                    std::vector<Item> next;
+                    for (const Item &it : f13)
+                        for (u32 b = 0; b < 2; ++b) {
+                            const u32 c = h.trie[2 * it.node + b];
+                            if (c != 0xFFFFFFFFu && !(c & 0x80000000u)) next.push_back({(it.key << 1) | b, c});
+                        }
+                    f13.swap(next);
+                }
+                if (f13.size() > (size_t)LONG_PFX) { h.complete32 = false; h.long32.clear(); h.lenlut32.clear(); }
+                else
+                    for (size_t k = 0; k < f13.size(); ++k) {
+                        h.long32[8 + 2 * LONG_PFX + 512 + k] = (u16)newid[f13[k].node];
+                        h.lenlut32[f13[k].key] = (u8)(128 + k);
+                    }
+            }
+        } else h.long32.clear();
     }
     if (h.complete16 && h.lmax > (u32)SYM3_MAXK) {      // codes of 13..16 bits, grouped by their first 12 bits
         h.longtab.assign(LONG_BYTES / 2, 0);
@@ -1205,6 +1549,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     std::vector<u32> ntiles(nblocks, 0);
     bool pair_all = !getenv("SHAFA_DEC_NOPAIR");
     bool c16_all = !getenv("SHAFA_DEC_NOLONG");
+    bool c32_all = !getenv("SHAFA_DEC_NOLONG");
     for (int b = 0; b < nblocks; ++b) {
         if ((h_in_off[b] & 15) || (h_out_off[b] & 15)) return SHAFA_OUTSIDE_MODULE;
         build_host_tab(h_tables[b], tabs[b]);
@@ -1222,10 +1567,12 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         if (h.lmax > lmax_all) lmax_all = h.lmax;
         tab_bytes += ((h.lut.size() * 2 + 15) & ~(size_t)15) + ((h.trie.size() * 4 + 15) & ~(size_t)15) +
                      ((h.lenlut.size() + 15) & ~(size_t)15) + ((h.lut2.size() * 2 + 16 + 15) & ~(size_t)15) +
-                     ((h.lut13.size() * 2 + 15) & ~(size_t)15) + (h.longtab.empty() ? 0 : (size_t)LONG_BYTES);
+                     ((h.lut13.size() * 2 + 15) & ~(size_t)15) + (h.longtab.empty() ? 0 : (size_t)LONG_BYTES) +
+                     (h.long32.empty() ? 0 : (size_t)((LONG32_BYTES + 15) & ~15)) + ((h.lenlut32.size() + 15) & ~(size_t)15);
         if (h.lut2.size() > max_l2) max_l2 = (u32)h.lut2.size();
         pair_all = pair_all && h.complete;
         c16_all = c16_all && h.complete16;
+        c32_all = c32_all && (h.complete16 || h.complete32);
     }
     if (!total_tiles) return SHAFA_SUCCESS;
     u32 R = 16;
@@ -1247,7 +1594,9 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const bool long_all = packed && !pair_all && c16_all && lmax_all > (u32)LEN_MAXK && !getenv("SHAFA_DEC_GENERIC");
     const bool fast13 = (lmax_all <= (u32)LEN_MAXK || long_all) && !getenv("SHAFA_DEC_GENERIC");   // LUT symbol passes
     const bool multi = fast13 && (pair_all || long_all) && !getenv("SHAFA_DEC_NOMULTI");            // three codes per lookup
-    const bool need_tabs = pair_all || long_all;
+    // 16 < Lmax <= 32, complete codes: 32-entry byte maps with the fast DP / automaton / three-code passes
+    const bool mid32 = !packed && R == 32 && c32_all && !getenv("SHAFA_DEC_GENERIC");
+    const bool need_tabs = pair_all || long_all || mid32;
     const size_t o_pair = off; off += pair_all ? (size_t)nblocks * (2u << LEN_MAXK) : 0;
     const size_t o_cnt3 = off; off += need_tabs ? (size_t)nblocks * (2u << LEN_MAXK) : 0;
     const size_t o_sym3 = off; off += need_tabs ? (size_t)nblocks * (4u << LEN_MAXK) : 0;
@@ -1297,7 +1646,18 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
             memcpy(hs + tpos, h.longtab.data(), LONG_BYTES);
             tpos += LONG_BYTES;
         }
+        if (!h.long32.empty()) {
+            e.long32 = (const u16 *)(ws + tpos);
+            memcpy(hs + tpos, h.long32.data(), LONG32_BYTES);
+            tpos += (LONG32_BYTES + 15) & ~15;
+        }
+        if (!h.lenlut32.empty()) {
+            e.lenlut32 = ws + tpos;
+            memcpy(hs + tpos, h.lenlut32.data(), h.lenlut32.size());
+            tpos += (h.lenlut32.size() + 15) & ~(size_t)15;
+        }
         e.lenlut = ws + tpos;
+        if (!e.lenlut32) e.lenlut32 = e.lenlut;            // no code longer than 13 bits: the plain table
         memcpy(hs + tpos, h.lenlut.data(), h.lenlut.size());
         tpos += (h.lenlut.size() + 15) & ~(size_t)15;
         e.lut = (const u16 *)(ws + tpos);
@@ -1364,6 +1724,13 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
                                (const u8 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
                                (u32 *)(ws + o_tcnt));
         }
+    } else if (mid32) {
+        hipLaunchKernelGGL(sfd_tables, grid_b, dim3(DEC_THREADS), 0, st, dblk);
+        hipLaunchKernelGGL(sfd_sync32, grid_f, dim3(DEC_THREADS), 0, st, dblk, ws + o_cfn, ws + o_tilefn, tpw);
+        hipLaunchKernelGGL(sfd_tiles, grid_b, dim3(DEC_THREADS), lds_tiles, st, dblk, R, (const u8 *)(ws + o_tilefn),
+                           ws + o_tent);
+        hipLaunchKernelGGL(sfd_countfsm32, grid_f, dim3(DEC_THREADS), 0, st, dblk, (const u8 *)(ws + o_cfn),
+                           (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt), (u32 *)(ws + o_tcnt), tpw);
     } else {
         hipLaunchKernelGGL(sfd_sync, grid_t, dim3(DEC_THREADS), lds_sync, st, dblk, R, l2cap, ws + o_cfn, ws + o_tilefn);
         hipLaunchKernelGGL(sfd_tiles, grid_b, dim3(DEC_THREADS), lds_tiles, st, dblk, R, (const u8 *)(ws + o_tilefn),
@@ -1374,15 +1741,18 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     }
     hipLaunchKernelGGL(sfd_offsets, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u32 *)(ws + o_tcnt),
                        (u64 *)(ws + o_toff));
-    if (fast13) {
+    if (mid32) {
+        hipLaunchKernelGGL((sfd_write13<true, WSUBS, 2>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
+                           (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, dbg);
+    } else if (fast13) {
         if (multi && long_all)
-            hipLaunchKernelGGL((sfd_write13<true, WSUBS, true>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
+            hipLaunchKernelGGL((sfd_write13<true, WSUBS, 1>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
                                (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, dbg);
         else if (multi)
-            hipLaunchKernelGGL((sfd_write13<true, WSUBS, false>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
+            hipLaunchKernelGGL((sfd_write13<true, WSUBS, 0>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
                                (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, dbg);
         else
-            hipLaunchKernelGGL((sfd_write13<false, WSUBS, false>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
+            hipLaunchKernelGGL((sfd_write13<false, WSUBS, 0>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
                                (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, dbg);
     } else {
         hipLaunchKernelGGL(sfd_write, grid_t, dim3(DEC_THREADS), lds_write, st, dblk, l2cap, (const u8 *)(ws + o_cent),

@@ -333,3 +333,28 @@ def test_sf_roundtrip_random_tables_and_sizes(oracle, shafa):
                 rc2, _ = shafa.sf_decode(want[: want.size - 2], t, n, raw_rc=True)
                 assert rc2 == shafa.FILE_UNRECOGNIZABLE, f"trial {trial} lmax={lmax} n={n}: truncated stream accepted"
     assert seen == {"<=13", "14-16", ">16"}, seen
+
+
+def test_sf_decode_codes_of_17_to_32_bits_fast_path(oracle, shafa):
+    """Complete codes with 16 < Lmax <= 32 (a long tail of rare bytes, as in real files at -b M): 32-entry maps, the
+    fast DP with the high-exit bit ring, the automaton and the three-code write pass with the 32-bit resolver."""
+    rng = np.random.default_rng(7)
+    zt = shafa.zipf_table(1.2)
+    for n, nrare in ((300000, 40), ((1 << 21) + 77, 56)):
+        data = oracle.gen_bytes(400 + n, n, np.where(zt >= 200, zt % 200, zt).astype(np.uint8))
+        for k in range(nrare):                                       # 1 .. a few hundred occurrences each
+            pos = rng.integers(0, n, size=1 + (k * k) // 8)
+            data[pos] = 200 + k
+        otab = oracle.sf_build(oracle.hist256(data))
+        lmax = int(otab.lens().max())
+        assert 16 < lmax <= 32, lmax
+        got, enc = decode_roundtrip(oracle, shafa, data, otab)
+        assert got.tobytes() == data.tobytes(), f"n={n} lmax={lmax}: {first_diff(got, data)}"
+        # dense in the rarest symbols: long codes next to each other and across chunk / tile boundaries
+        rare = np.nonzero(otab.lens() > 16)[0].astype(np.uint8)
+        mix = data[:200000].copy()
+        mix[::2] = rare[np.arange(mix[::2].size) % rare.size]
+        got, enc = decode_roundtrip(oracle, shafa, mix, otab)
+        assert got.tobytes() == mix.tobytes(), f"dense rare n={n} lmax={lmax}: {first_diff(got, mix)}"
+        rc, _ = shafa.sf_decode(enc[: enc.size // 3], to_shafa_table(shafa, otab), len(mix), raw_rc=True)
+        assert rc == shafa.FILE_UNRECOGNIZABLE
