@@ -352,7 +352,7 @@ __global__ __launch_bounds__(ENC_THREADS) void sf_encode_generic(const EncBlk *_
 // host launcher
 // ------------------------------------------------------------------------------------------------
 void sfenc2_launch(hipStream_t st, const EncBlk *dblk, int count, u32 total_tiles, u64 *ddesc, u32 *dtick);
-void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 *d_tile_bits, u64 *d_tile_off);
+void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 *d_tile_bits, u64 *d_tile_off, bool lut64);
 void sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u64 *d_desc, u32 *d_tickets);
 
 int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
@@ -480,9 +480,12 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         if (use_v1) LAUNCH_FAST(4, 1);
         else if (enc_v == 4) sfenc4_launch(st, dblk + cls_first[1], cls_count[1], max_tiles[1], ddesc, dtick);
         else if (enc_v == 2) sfenc2_launch(st, dblk + cls_first[1], cls_count[1], (u32)total_tiles[1], ddesc, dtick);
-        else sfenc3_launch(st, dblk + cls_first[1], cls_count[1], max_tiles[1], (u32 *)(ws + o_tbits), ddesc);
+        else sfenc3_launch(st, dblk + cls_first[1], cls_count[1], max_tiles[1], (u32 *)(ws + o_tbits), ddesc, false);
     }
-    if (cls_count[2]) LAUNCH_FAST(2, 2);
+    if (cls_count[2]) {
+        if (enc_v == 3) sfenc3_launch(st, dblk + cls_first[2], cls_count[2], max_tiles[2], (u32 *)(ws + o_tbits), ddesc, true);
+        else LAUNCH_FAST(2, 2);
+    }
     if (cls_count[3])
         hipLaunchKernelGGL(sf_encode_generic, dim3(max_tiles[3] * cls_count[3]), dim3(ENC_THREADS), 0, st,
                            dblk + cls_first[3], cls_count[3], ddesc, dtick);

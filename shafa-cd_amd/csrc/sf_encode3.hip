@@ -41,9 +41,11 @@ __device__ __forceinline__ u32 dpp_scan(u32 v)
 // ------------------------------------------------------------------------------------------------
 constexpr int E3_CTPW = 16;                            // tiles per workgroup of sfe3_count (one LUT fill)
 
+// LUT64: the block's table holds 64-bit entries code | len << 32 (codes of up to 32 bits)
+template <bool LUT64>
 __global__ __launch_bounds__(E3_THREADS) void sfe3_count(const EncBlk *__restrict__ blks, u32 *__restrict__ tile_bits)
 {
-    // Entry = len | absent << 12: a lane sums 128 of them (len sum <= 2048 < 4096), so one add per symbol carries
+    // Entry = len | absent << 16: a lane sums 128 of them (len sum <= 4096), so one add per symbol carries
     // both the bit total and the number of symbols without a code.  The 256 entries are replicated 32 times,
     // copy c at dword sym * 32 + c, and lane l reads copy l & 31: every look-up hits its own bank, so a wave's
     // 64 random look-ups take the minimum two LDS passes instead of ~4.5 with a shared 1 KiB table.
@@ -53,8 +55,14 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_count(const EncBlk *__restric
     if (tile0 >= blk.n_tiles) return;
     const int tid = threadIdx.x;
     {
-        const u32 x = gload<u32>((const u32 *)blk.lut + tid);
-        const u32 e = ((x >> 16) & 31u) | ((x >> 31) << 12);
+        u32 e;
+        if (LUT64) {
+            const u32 len = gload<u32>((const u32 *)blk.lut + 2 * tid + 1);
+            e = len ? len : (1u << 16);                // empty code = symbol absent from the table
+        } else {
+            const u32 x = gload<u32>((const u32 *)blk.lut + tid);
+            e = ((x >> 16) & 31u) | ((x >> 31) << 16);
+        }
         uint4 *dst = (uint4 *)(lut + tid * 32);
 #pragma unroll
         for (int c = 0; c < 8; ++c) dst[c] = make_uint4(e, e, e, e);
@@ -96,8 +104,8 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_count(const EncBlk *__restric
                     if (idx + j < blk.n) tot += lut[(u32)gload<u8>(blk.in + idx + j) * 32];
             }
         }
-        absent |= tot >> 12;                           // a lane sums 128 entries: len sum <= 2048 < 4096
-        const u32 s = dpp_scan(tot & 0xFFFu);
+        absent |= tot >> 16;
+        const u32 s = dpp_scan(tot & 0xFFFFu);
         if (lane == 63) tile_bits[blk.desc_base + tile] = s;
 #pragma unroll
         for (int it = 0; it < CI; ++it) cur[it] = nxt[it];
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_scan(const EncBlk *__restrict
 // ------------------------------------------------------------------------------------------------
 struct Pack3Shared {
     u64 stage[E3_SW64 + 2];
-    u32 lut[256];                // code | len << 16
+    u64 lut[256];                // LUT64: code | len << 32; else only the low halves are used: code | len << 16
     u32 wtot[4 * E3_ITEMS];
     u32 prev[16];
     u64 prefix;                  // CHAINED: bits before the tile (from the look-back)
@@ -156,7 +164,7 @@ __device__ __forceinline__ u64 bswap64(u64 x)
 // CHAINED = single pass: no count/scan kernels; the tile takes a ticket (tiles of a block start in order, so a
 // tile's predecessors are always running or done), publishes its bit total and gets the bits before it by a
 // decoupled look-back over the block's tile descriptors.  The input is read once (n + out bytes of traffic).
-template <bool CHAINED>
+template <bool CHAINED, bool LUT64>
 __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict__ blks, int nblk,
                                                         const u64 *__restrict__ tile_off, u64 *__restrict__ desc,
                                                         u32 *__restrict__ tickets)
@@ -197,8 +205,14 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
     u32 pv = 0;
     if (tid < 16 && tile > 0) pv = gload<u32>(blk.in + base - 64 + 4 * tid);
     {
-        const u32 x = gload<u32>((const u32 *)blk.lut + tid);
-        sh.lut[tid] = (x >> 31) ? (1u << 28) : x;      // no code: "length" 4096, caught in the item totals below
+        // no code: "length" 4096, caught in the item totals below
+        if (LUT64) {
+            const u64 x = gload<u64>((const u64 *)blk.lut + tid);
+            sh.lut[tid] = (x >> 32) ? x : (1ull << 44);
+        } else {
+            const u32 x = gload<u32>((const u32 *)blk.lut + tid);
+            ((u32 *)sh.lut)[tid] = (x >> 31) ? (1u << 28) : x;
+        }
     }
     for (int i = tid; i < E3_SW64 + 2; i += E3_THREADS) sh.stage[i] = 0;
     if (tid < 16) sh.prev[tid] = pv;
@@ -223,18 +237,35 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
         u32 tot = 0, packed = 0;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            u32 e[4];
+            u32 L;
+            if (LUT64) {
+                u64 e[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) e[j] = sh.lut[(wds[g] >> (8 * j)) & 0xFFu];
-            if (__builtin_expect(dm != 0, 0)) {
+                for (int j = 0; j < 4; ++j) e[j] = sh.lut[(wds[g] >> (8 * j)) & 0xFFu];
+                if (__builtin_expect(dm != 0, 0)) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if ((dm >> (4 * g + j)) & 1u) e[j] = 0;
+                    for (int j = 0; j < 4; ++j) if ((dm >> (4 * g + j)) & 1u) e[j] = 0;
+                }
+                const u32 l0 = (u32)(e[0] >> 32), l1 = (u32)(e[1] >> 32), l2 = (u32)(e[2] >> 32), l3 = (u32)(e[3] >> 32);
+                const u64 a = ((u64)(u32)e[0] << l1) | (u32)e[1];        // <= 64 bits
+                const u64 c = ((u64)(u32)e[2] << l3) | (u32)e[3];
+                L = l0 + l1 + l2 + l3;                                   // > 64 (rare): re-encoded as two halves at merge time
+                grp[it][g] = (a << ((l2 + l3) & 63u)) | c;
+            } else {
+                const u32 *lut32 = (const u32 *)sh.lut;
+                u32 e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = lut32[(wds[g] >> (8 * j)) & 0xFFu];
+                if (__builtin_expect(dm != 0, 0)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if ((dm >> (4 * g + j)) & 1u) e[j] = 0;
+                }
+                const u32 l0 = e[0] >> 16, l1 = e[1] >> 16, l2 = e[2] >> 16, l3 = e[3] >> 16;
+                const u32 a = ((e[0] & 0xFFFFu) << l1) | (e[1] & 0xFFFFu);
+                const u32 c = ((e[2] & 0xFFFFu) << l3) | (e[3] & 0xFFFFu);
+                L = l0 + l1 + l2 + l3;
+                grp[it][g] = ((u64)a << (l2 + l3)) | c;
             }
-            const u32 l0 = e[0] >> 16, l1 = e[1] >> 16, l2 = e[2] >> 16, l3 = e[3] >> 16;
-            const u32 a = ((e[0] & 0xFFFFu) << l1) | (e[1] & 0xFFFFu);
-            const u32 c = ((e[2] & 0xFFFFu) << l3) | (e[3] & 0xFFFFu);
-            const u32 L = l0 + l1 + l2 + l3;
-            grp[it][g] = ((u64)a << (l2 + l3)) | c;
             packed |= L << (8 * g);
             tot += L;
         }
@@ -299,9 +330,12 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
         u32 got = 0;
         const u8 *pb = (const u8 *)sh.prev;
         for (int p = 63; p >= 0 && got < s; --p) {     // >= 1 bit per symbol: 63 symbols suffice
-            const u32 x = sh.lut[pb[p]];
-            acc |= (got < 64 ? (u64)(x & 0xFFFFu) << got : 0ull);
-            got += (x >> 16) & 31u;
+            u64 code;
+            u32 len;
+            if (LUT64) { const u64 x = sh.lut[pb[p]]; code = (u32)x; len = (u32)(x >> 32) & 63u; }
+            else { const u32 x = ((const u32 *)sh.lut)[pb[p]]; code = x & 0xFFFFu; len = (x >> 16) & 31u; }
+            acc |= (got < 64 ? code << got : 0ull);
+            got += len;
         }
         acc &= (~0ull) >> (64 - s);
         atomicOr((unsigned long long *)&sh.stage[0], (unsigned long long)(acc << (64 - s)));
@@ -322,13 +356,30 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const u32 L = (glen[it] >> (8 * g)) & 0xFFu;
-                // a group of <= 64 bits touches at most two 64-bit words; L == 0 ORs nothing
-                const u64 Gl = grp[it][g] << ((64 - L) & 63);       // left-aligned (L == 0: the group is 0)
-                const u32 sft = q & 63, i = (q >> 6) - r0;          // i == -1: only the low part is in this window
-                const u64 hi = Gl >> sft;
-                const u64 lo = (Gl << 1) << (63 - sft);             // == Gl << (64 - sft), 0 when sft == 0
-                if (i < (u32)E3_SW64) atomicOr((unsigned long long *)&sh.stage[i], (unsigned long long)hi);
-                if (lo && i + 1 < (u32)E3_SW64) atomicOr((unsigned long long *)&sh.stage[i + 1], (unsigned long long)lo);
+                // `bits` (right-aligned, nb <= 64 of them) ORed into the window at bit offset qq: at most two 64-bit words
+                auto put = [&](u64 bits, u32 nb, u32 qq) {
+                    const u64 Gl = bits << ((64 - nb) & 63);            // left-aligned (nb == 0: the group is 0)
+                    const u32 sft = qq & 63, i = (qq >> 6) - r0;        // i == -1: only the low part is in this window
+                    const u64 hi = Gl >> sft;
+                    const u64 lo = (Gl << 1) << (63 - sft);             // == Gl << (64 - sft), 0 when sft == 0
+                    if (i < (u32)E3_SW64) atomicOr((unsigned long long *)&sh.stage[i], (unsigned long long)hi);
+                    if (lo && i + 1 < (u32)E3_SW64) atomicOr((unsigned long long *)&sh.stage[i + 1], (unsigned long long)lo);
+                };
+                if (LUT64 && __builtin_expect(L > 64, 0)) {
+                    // four codes of more than 64 bits together (rare): look the symbols up again, two halves of <= 64 bits
+                    const u32 wd = g == 0 ? cur[it].x : g == 1 ? cur[it].y : g == 2 ? cur[it].z : cur[it].w;
+                    u64 e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        e[j] = sh.lut[(wd >> (8 * j)) & 0xFFu];
+                        if ((dropmask[it] >> (4 * g + j)) & 1u) e[j] = 0;
+                    }
+                    const u32 l0 = (u32)(e[0] >> 32), l1 = (u32)(e[1] >> 32), l2 = (u32)(e[2] >> 32), l3 = (u32)(e[3] >> 32);
+                    put(((u64)(u32)e[0] << (l1 & 63u)) | (u32)e[1], l0 + l1, q);
+                    put(((u64)(u32)e[2] << (l3 & 63u)) | (u32)e[3], l2 + l3, q + l0 + l1);
+                } else {
+                    put(grp[it][g], L, q);
+                }
                 q += L;
             }
         }
@@ -361,15 +412,21 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
 // single pass (SHAFA_ENC_V=4): desc/tickets zeroed by the caller
 void sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u64 *d_desc, u32 *d_tickets)
 {
-    hipLaunchKernelGGL(sfe3_pack<true>, dim3(max_tiles * (u32)count), dim3(E3_THREADS), 0, st, dblk, count,
+    hipLaunchKernelGGL((sfe3_pack<true, false>), dim3(max_tiles * (u32)count), dim3(E3_THREADS), 0, st, dblk, count,
                        (const u64 *)nullptr, d_desc, d_tickets);
 }
 
-void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 *d_tile_bits, u64 *d_tile_off)
+// lut64: the blocks' tables are 64-bit (codes of 17..32 bits somewhere in the launch)
+void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 *d_tile_bits, u64 *d_tile_off, bool lut64)
 {
     const dim3 grid(max_tiles, (u32)count), grid_c((max_tiles + E3_CTPW - 1) / E3_CTPW, (u32)count);
-    hipLaunchKernelGGL(sfe3_count, grid_c, dim3(E3_THREADS), 0, st, dblk, d_tile_bits);
+    if (lut64) hipLaunchKernelGGL(sfe3_count<true>, grid_c, dim3(E3_THREADS), 0, st, dblk, d_tile_bits);
+    else hipLaunchKernelGGL(sfe3_count<false>, grid_c, dim3(E3_THREADS), 0, st, dblk, d_tile_bits);
     hipLaunchKernelGGL(sfe3_scan, dim3((u32)count), dim3(E3_THREADS), 0, st, dblk, (const u32 *)d_tile_bits, d_tile_off);
-    hipLaunchKernelGGL(sfe3_pack<false>, grid, dim3(E3_THREADS), 0, st, dblk, count, (const u64 *)d_tile_off,
-                       (u64 *)nullptr, (u32 *)nullptr);
+    if (lut64)
+        hipLaunchKernelGGL((sfe3_pack<false, true>), grid, dim3(E3_THREADS), 0, st, dblk, count, (const u64 *)d_tile_off,
+                           (u64 *)nullptr, (u32 *)nullptr);
+    else
+        hipLaunchKernelGGL((sfe3_pack<false, false>), grid, dim3(E3_THREADS), 0, st, dblk, count, (const u64 *)d_tile_off,
+                           (u64 *)nullptr, (u32 *)nullptr);
 }
