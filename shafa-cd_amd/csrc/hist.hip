@@ -2,9 +2,10 @@
 //
 // 256-bin byte histogram with 64-bit bins, many blocks per launch.  Each workgroup streams one
 // 256 KiB chunk with coalesced 16-byte loads and counts into an LDS histogram that is replicated
-// 8x (replica = lane & 7, interleaved so the replicas of one bin sit in 8 different banks): a hot
-// symbol (Zipf data: ~25 % of the lanes) then serialises 8x less on its LDS atomic.  The 8 replicas
-// are summed and added to the block's global bins with at most 256 atomics per workgroup.
+// 32x, replica = lane & 31 at dword sym * 32 + replica: every lane of a half-wave owns its bank, so
+// the LDS atomics never conflict, whatever the symbol distribution is (a hot symbol of Zipf data is
+// in ~25 % of the lanes).  The replicas are summed (rotated reads, conflict-free) and added to the
+// block's global bins with at most 256 atomics per workgroup.
 //
 // Algorithmic HBM bytes per block: n read (+ 2 KiB written).
 #include "common.hpp"
@@ -14,7 +15,7 @@ namespace {
 
 constexpr int HIST_THREADS = 256;
 constexpr u64 HIST_CHUNK = 256 * 1024;
-constexpr int HIST_REP = 8;
+constexpr int HIST_REP = 32;
 
 struct HistBlk { const u8 *in; u64 n; u64 *freq; const u64 *n_dev; };
 
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist256_kernel(const HistBlk *__
     __syncthreads();
     u32 c = 0;
 #pragma unroll
-    for (int r = 0; r < HIST_REP; ++r) c += h[tid * HIST_REP + r];
+    for (int r = 0; r < HIST_REP; ++r) c += h[tid * HIST_REP + ((r + tid) & (HIST_REP - 1))];
     if (c) atomicAdd((unsigned long long *)(blk.freq + tid), (unsigned long long)c);
 }
 
