@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-sample-blocks", type=int, default=16)
     ap.add_argument("--encode-only", action="store_true")
+    ap.add_argument("--scatter-gather", action="store_true",
+                    help="also time X1 (root scatters whole blocks) + encode + X2 (root gathers the payloads); extra JSON field")
     ap.add_argument("--zipf-s", type=float, default=1.2, help="Zipf exponent of the synthetic bytes (metric config: 1.2)")
     return ap.parse_args()
 
@@ -238,6 +240,38 @@ def main():
             "traffic_source": "profiles/r1_traffic.json (rocprofv3 PMC, separate run)" if traffic[dominant] else None}
     roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
 
+    # ---- optional: root-scatter-included encode: never part of `value` -------------
+    sg = None
+    if args.scatter_gather:
+        import pkgload as _pl
+        shd = _pl.load_submodule("sharding")
+        if world == 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("nccl", rank=0, world_size=1)
+        total_all = world * shard
+        src = None
+        if rank == 0:                                    # the reader rank holds the whole stream
+            src = torch.empty(total_all, dtype=torch.uint8, device=dev)
+            pkg.gen_bytes(None, 20260101, 0, src, total_all, d_map)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        local, first_blk, sizes = shd.scatter_blocks(src, total_all, bs, dev)              # X1
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        bt.sf_encode(st, local, in_off, in_n, tables, d_enc, out_off, out_cap, d_enc_n)     # same tables: same stream
+        bt.finish(st, nb)
+        t2 = time.perf_counter()
+        got = shd.gather_payloads(d_enc, out_off, [int(x) for x in enc_bytes], world * nb, dev)   # X2
+        torch.cuda.synchronize()
+        dist.barrier()
+        t3 = time.perf_counter()
+        assert torch.equal(local, d_in), "scattered shard differs from the resident one"
+        if rank == 0:
+            assert len(got) == world * nb and all(g is not None for g in got)
+            sg = {"x1_scatter_ms": (t1 - t0) * 1e3, "encode_ms": (t2 - t1) * 1e3, "x2_gather_ms": (t3 - t2) * 1e3,
+                  "encode_GiBs_root_scatter_gather_included": total_all / GIB / (t3 - t0)}
     dist_name = args.dist if args.zipf_s == 1.2 or args.dist != 'zipf' else 'zipf(s=%g)' % args.zipf_s
     if rank == 0:
         out = {
@@ -262,10 +296,12 @@ def main():
                                  "frac": dec_gbs / HBM_PEAK_GBS, "traffic": traffic["sf_decode"],
                                  "algorithmic_bytes_per_launch": alg} if have_decode else None),
         }
+        if sg:
+            out["scatter_gather"] = sg
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, pkg, zt)
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
