@@ -15,6 +15,8 @@
 #include "common.hpp"
 #include "internal.hpp"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int RLE_THREADS = 256;
@@ -87,24 +89,19 @@ struct RleShared {
     u32 H;          // bytes after the tile equal to its last byte (<= 255)
     u32 pad;
     u64 G;          // output byte offset of the tile
+    u16 E[260];     // fast path: equality masks of the threads, [0] = the 16 bytes before the tile, [257] = after
+    u16 lastb[258]; // fast path: last byte of every thread, [0] = the byte before the tile (0x100: none)
+    u32 slow;       // fast path: fall back to the general tile code
 };
 
-__global__ __launch_bounds__(RLE_THREADS) void rle_encode_kernel(const RleBlk *__restrict__ blks, int nblk,
-                                                                 u64 *desc_run, u64 *desc_sum, u32 *tickets)
+// General tile code: any input (runs of any length, ragged last tile).  Per element closed form.
+__device__ __forceinline__ void rle_tile_general(RleShared &sh, const RleBlk &blk, const int k, u64 *drun, u64 *dsum)
 {
-    __shared__ __attribute__((aligned(16))) RleShared sh;
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
-    const int b = blockIdx.x % nblk;
-    const RleBlk blk = blks[b];
-    if ((u32)(blockIdx.x / nblk) >= blk.n_tiles) return;
-    if (tid == 0) sh.tile = atomicAdd(tickets + blk.ticket, 1u);
-    __syncthreads();
-    const int k = (int)sh.tile;
     const u64 n = blk.n;
     const u64 tile_start = (u64)k * RLE_TILE;
     const u64 tile_end = (tile_start + RLE_TILE < n) ? tile_start + RLE_TILE : n;
     const u64 pos = tile_start + (u64)tid * 16;
-    u64 *drun = desc_run + blk.desc_base, *dsum = desc_sum + blk.desc_base;
 
     // ---- load 16 bytes; bytes past the block end become sentinels that never equal a neighbour ----
     u32 x[16];
@@ -293,6 +290,183 @@ __global__ __launch_bounds__(RLE_THREADS) void rle_encode_kernel(const RleBlk *_
     if (k == (int)blk.n_tiles - 1 && tid == 0) *blk.out_n = end_b;
 }
 
+
+// 4-bit mask of the bytes of a that equal the bytes of b (exact SWAR zero-byte test of a ^ b)
+__device__ __forceinline__ u32 eqmask4(u32 a, u32 b)
+{
+    const u32 d = a ^ b;
+    u32 t = (d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    t = ~(t | d | 0x7F7F7F7Fu);                       // 0x80 in every byte of d that is zero
+    const u32 m = t >> 7;
+    return (m | (m >> 7) | (m >> 14) | (m >> 21)) & 0xFu;
+}
+
+// Fast tile code: full tiles in which no thread's 16 bytes are all equal to the byte before them (so every run that
+// touches the tile is shorter than 32 bytes inside it) and whose entering run is shorter than 200.  Then no run needs
+// the mod-255 segmentation here and everything follows from bit masks: E = "equals the previous byte", Z = "is zero";
+// a byte is in a run of >= 4 iff three consecutive E bits cover it (3 bits of context on each side suffice).
+//   literal : non-zero byte of a run of < 4        triple {0, s, L} : head of a zero run or of a run of >= 4
+// Returns false (nothing emitted, general code must run) when the conditions do not hold.
+__device__ __forceinline__ bool rle_tile_fast(RleShared &sh, const RleBlk &blk, const int k, u64 *drun, u64 *dsum)
+{
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const u64 n = blk.n;
+    const u64 tile_start = (u64)k * RLE_TILE, tile_end = tile_start + RLE_TILE;
+    if (tile_end + 4 > n) return false;                // ragged / last tiles: general code (uniform)
+    const u64 pos = tile_start + (u64)tid * 16;
+    const uint4 v = *(const uint4 *)(blk.in + pos);
+    const u32 w[4] = {v.x, v.y, v.z, v.w};
+    sh.lastb[tid + 1] = (u16)(w[3] >> 24);
+    if (tid == 0) {
+        u32 e0 = 0, lb = 0x100u;                       // first tile: nothing before it
+        if (k > 0) {
+            const u32 q = *(const u32 *)(blk.in + tile_start - 4);      // bytes -4 .. -1
+            e0 = (eqmask4(q, q << 8) >> 1) << 13;      // E of positions -3, -2, -1 in bits 13..15
+            lb = q >> 24;
+        }
+        sh.E[0] = (u16)e0;
+        sh.lastb[0] = (u16)lb;
+        sh.slow = 0;
+    }
+    if (tid == RLE_THREADS - 1) {
+        const u32 q = *(const u32 *)(blk.in + tile_end);                // bytes 4096 .. 4099 of the tile's frame
+        sh.E[RLE_THREADS + 1] = (u16)(eqmask4(q, (q << 8) | (w[3] >> 24)) & 7u);
+    }
+    __syncthreads();
+    const u32 pb = sh.lastb[tid];
+    const u32 p0 = (w[0] << 8) | (pb & 0xFFu);
+    u32 E16 = eqmask4(w[0], p0) | (eqmask4(w[1], __builtin_amdgcn_alignbit(w[1], w[0], 24)) << 4) |
+              (eqmask4(w[2], __builtin_amdgcn_alignbit(w[2], w[1], 24)) << 8) |
+              (eqmask4(w[3], __builtin_amdgcn_alignbit(w[3], w[2], 24)) << 12);
+    if (pb > 0xFFu) E16 &= ~1u;
+    const u32 Z16 = eqmask4(w[0], 0) | (eqmask4(w[1], 0) << 4) | (eqmask4(w[2], 0) << 8) | (eqmask4(w[3], 0) << 12);
+    sh.E[tid + 1] = (u16)E16;
+    if (__syncthreads_or(E16 == 0xFFFFu)) return false;   // a thread inside one long run: general code
+
+    // run entering the tile (look-back #1) and halo; the tile's descriptor: its trailing run, never "all one run"
+    const u32 H16 = ~E16 & 0xFFFFu;                      // run heads; every thread has one here
+    if (tid == RLE_THREADS - 1) desc_store(drun + k, DESC_PREFIX, (u64)(__builtin_clz(H16) - 15));   // 16 - msb(H16)
+    if (wv == 0) {
+        const bool need_R = (sh.E[1] & 1u) != 0;
+        u64 R = 0;
+        if (need_R && k > 0) R = lookback_run(drun, k, blk.err);
+        if (tid == 0 && R >= 200) sh.slow = 1;           // the 255-byte segmentation could reach into this tile
+    } else if (wv == 1) {
+        u32 H = 0;
+        const u32 lastb = sh.lastb[RLE_THREADS];
+        const u64 q = tile_end + (u64)lane * 4;
+        u32 cnt = 0;
+        bool go = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32 c = (q + j < n) ? (u32)blk.in[q + j] : 0x400u;
+            go &= (c == lastb);
+            cnt += go ? 1u : 0u;
+        }
+        const u64 full = __ballot(cnt == 4);
+        const int l0 = (~full) ? (__ffsll((unsigned long long)~full) - 1) : 64;
+        const u32 c0 = (l0 < 64) ? (u32)__shfl((int)cnt, l0, 64) : 0u;
+        H = (u32)l0 * 4 + c0;
+        if (H > 255) H = 255;
+        if (lane == 0) sh.H = H;
+    }
+    __syncthreads();
+    if (sh.slow) return false;
+
+    // ---- classification -----------------------------------------------------------------------------------
+    const u32 B = ((u32)sh.E[tid] >> 13) | (E16 << 3) | (((u32)sh.E[tid + 2] & 7u) << 19);   // positions -3 .. 18
+    const u32 T = B & (B >> 1) & (B >> 2);
+    const u32 LC = (((T >> 1) | T | (T << 1) | (T << 2)) >> 3) & 0xFFFFu;                     // bytes of runs of >= 4
+    const u32 Lit = ~Z16 & ~LC & 0xFFFFu;
+    const u32 T3 = H16 & (Z16 | LC);
+    const u32 tot = (u32)__builtin_popcount(Lit) + 3u * (u32)__builtin_popcount(T3);
+
+    // ---- output offsets: workgroup scan + look-back #2 ----------------------------------------------------
+    const u32 incl = wave_incl_scan_add<u32>(tot);
+    if (lane == 63) sh.wsum[wv] = incl;
+    __syncthreads();
+    u32 run = 0, off = 0;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+        if (ww == wv) off = run + incl - tot;
+        run += sh.wsum[ww];
+    }
+    const u32 Tt = run;
+    if (wv == 0) {
+        u64 G = 0;
+        if (k > 0) {
+            if (tid == 0) desc_store(dsum + k, DESC_AGG, Tt);
+            G = lookback_sum(dsum, k, blk.err);
+        }
+        if (tid == 0) {
+            desc_store(dsum + k, DESC_PREFIX, G + Tt);
+            sh.G = G;
+        }
+    }
+    __syncthreads();
+    const u64 G = sh.G;
+    const u32 shift = (u32)G & 3;
+
+    // ---- tokens into LDS, then aligned word stores -----------------------------------------------------------
+    u8 *st8 = (u8 *)sh.stage;
+    u32 o = shift + off;
+    const u32 Hn = tid == RLE_THREADS - 1 ? 0u : (~(u32)sh.E[tid + 2] & 0xFFFFu);   // heads of the next thread
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const u32 xj = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        if ((T3 >> j) & 1u) {
+            const u32 hn = H16 >> (j + 1);
+            u32 L;
+            if (j < 15 && hn) L = (u32)__builtin_ctz(hn) + 1;                       // next head inside this thread
+            else if (tid != RLE_THREADS - 1) L = (16 - j) + (u32)__builtin_ctz(Hn); // in the next thread
+            else { L = (16 - j) + sh.H; L = L > 255u ? 255u : L; }                  // past the tile: halo count
+            st8[o] = 0; st8[o + 1] = (u8)xj; st8[o + 2] = (u8)L;
+            o += 3;
+        } else if ((Lit >> j) & 1u) {
+            st8[o] = (u8)xj;
+            o += 1;
+        }
+    }
+    __syncthreads();
+    const u64 end_b = G + Tt;
+    if (end_b > blk.out_cap) {
+        if (tid == 0) set_error(blk.err, SHAFA_LACK_OF_MEMORY);
+    } else {
+        const u32 nwords = (shift + Tt + 3) >> 2;
+        const u64 gw0 = G >> 2;
+        for (u32 ww = tid; ww < nwords; ww += RLE_THREADS) {
+            const u32 val = sh.stage[ww];
+            const u64 byte0 = (gw0 + ww) * 4;
+            if (byte0 >= G && byte0 + 4 <= end_b) {
+                ((u32 *)blk.out)[gw0 + ww] = val;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (byte0 + q >= G && byte0 + q < end_b) blk.out[byte0 + q] = (u8)(val >> (8 * q));
+            }
+        }
+    }
+    if (k == (int)blk.n_tiles - 1 && tid == 0) *blk.out_n = end_b;
+    return true;
+}
+
+__global__ __launch_bounds__(RLE_THREADS) void rle_encode_kernel(const RleBlk *__restrict__ blks, int nblk,
+                                                                 u64 *desc_run, u64 *desc_sum, u32 *tickets, u32 mode)
+{
+    __shared__ __attribute__((aligned(16))) RleShared sh;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x % nblk;
+    const RleBlk blk = blks[b];
+    if ((u32)(blockIdx.x / nblk) >= blk.n_tiles) return;
+    if (tid == 0) sh.tile = atomicAdd(tickets + blk.ticket, 1u);
+    __syncthreads();
+    const int k = (int)sh.tile;
+    u64 *drun = desc_run + blk.desc_base, *dsum = desc_sum + blk.desc_base;
+    if (mode == 0 && rle_tile_fast(sh, blk, k, drun, dsum)) return;
+    __syncthreads();
+    rle_tile_general(sh, blk, k, drun, dsum);
+}
+
 }  // namespace
 
 int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
@@ -342,7 +516,7 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
     if (max_tiles) {
         hipLaunchKernelGGL(rle_encode_kernel, dim3(max_tiles * (u32)nblocks), dim3(RLE_THREADS), 0, st,
                            (const RleBlk *)(ws + o_blk), nblocks, (u64 *)(ws + o_run), (u64 *)(ws + o_sum),
-                           (u32 *)(ws + o_tick));
+                           (u32 *)(ws + o_tick), getenv("SHAFA_RLE_GENERAL") ? 1u : 0u);
         HIP_TRY(hipGetLastError());
     }
     if (d_freq) {   // make_freq of the RLE bytes (f.c:310): sizes are on the device
