@@ -95,7 +95,11 @@ struct RleShared {
 };
 
 // General tile code: any input (runs of any length, ragged last tile).  Per element closed form.
-__device__ __forceinline__ void rle_tile_general(RleShared &sh, const RleBlk &blk, const int k, u64 *drun, u64 *dsum)
+// MODE 0: chained (look-backs over drun / dsum); 1: sizes only, carry Rin given, tile total to *Tout;
+// 2: emit, carry Rin and output offset Gin given.
+template <int MODE>
+__device__ __forceinline__ void rle_tile_general(RleShared &sh, const RleBlk &blk, const int k, u64 *drun, u64 *dsum,
+                                                 u64 Rin = 0, u64 Gin = 0, u32 *Tout = nullptr)
 {
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const u64 n = blk.n;
@@ -170,15 +174,17 @@ __device__ __forceinline__ void rle_tile_general(RleShared &sh, const RleBlk &bl
         const bool tile_cont = ftot.f != 0;                 // the whole tile is one run that continues
         const bool need_R = __shfl((int)eq0, 0, 64) != 0;   // first byte equals the byte before the tile
         u64 R = 0;
-        if (tid == 0) {
-            if (tile_cont) desc_store(drun + k, DESC_AGG, (u64)ftot.v | (1ull << RUN_C_BIT));
-            else desc_store(drun + k, DESC_PREFIX, (u64)ftot.v);
+        if (MODE == 0) {
+            if (tid == 0) {
+                if (tile_cont) desc_store(drun + k, DESC_AGG, (u64)ftot.v | (1ull << RUN_C_BIT));
+                else desc_store(drun + k, DESC_PREFIX, (u64)ftot.v);
+            }
+            if (need_R && k > 0) R = lookback_run(drun, k, blk.err);
+            if (tid == 0 && tile_cont) desc_store(drun + k, DESC_PREFIX, R + ftot.v);
+        } else {
+            R = (need_R && k > 0) ? Rin : 0;
         }
-        if (need_R && k > 0) R = lookback_run(drun, k, blk.err);
-        if (tid == 0) {
-            if (tile_cont) desc_store(drun + k, DESC_PREFIX, R + ftot.v);
-            sh.R = (u32)(R % 255u);
-        }
+        if (tid == 0) sh.R = (u32)(R % 255u);
     } else if (wv == 1) {
         u32 H = 0;
         if (tile_end < n && tile_end == tile_start + RLE_TILE) {
@@ -240,19 +246,25 @@ __device__ __forceinline__ void rle_tile_general(RleShared &sh, const RleBlk &bl
         run += sh.wsum[w];
     }
     const u32 T = run;
-    if (wv == 0) {
-        u64 G = 0;
-        if (k > 0) {
-            if (tid == 0) desc_store(dsum + k, DESC_AGG, T);
-            G = lookback_sum(dsum, k, blk.err);
-        }
-        if (tid == 0) {
-            desc_store(dsum + k, DESC_PREFIX, G + T);
-            sh.G = G;
-        }
+    if (MODE == 1) {
+        if (tid == 0) *Tout = T;
+        return;
     }
-    __syncthreads();
-    const u64 G = sh.G;
+    if (MODE == 0) {
+        if (wv == 0) {
+            u64 G = 0;
+            if (k > 0) {
+                if (tid == 0) desc_store(dsum + k, DESC_AGG, T);
+                G = lookback_sum(dsum, k, blk.err);
+            }
+            if (tid == 0) {
+                desc_store(dsum + k, DESC_PREFIX, G + T);
+                sh.G = G;
+            }
+        }
+        __syncthreads();
+    }
+    const u64 G = MODE == 0 ? sh.G : Gin;
     const u32 shift = (u32)G & 3;
 
     // ---- tokens into LDS (byte offset keeps the global 4-byte phase), then aligned word stores -----------
@@ -287,7 +299,7 @@ __device__ __forceinline__ void rle_tile_general(RleShared &sh, const RleBlk &bl
             }
         }
     }
-    if (k == (int)blk.n_tiles - 1 && tid == 0) *blk.out_n = end_b;
+    if (MODE == 0 && k == (int)blk.n_tiles - 1 && tid == 0) *blk.out_n = end_b;
 }
 
 
@@ -464,7 +476,282 @@ __global__ __launch_bounds__(RLE_THREADS) void rle_encode_kernel(const RleBlk *_
     u64 *drun = desc_run + blk.desc_base, *dsum = desc_sum + blk.desc_base;
     if (mode == 0 && rle_tile_fast(sh, blk, k, drun, dsum)) return;
     __syncthreads();
-    rle_tile_general(sh, blk, k, drun, dsum);
+    rle_tile_general<0>(sh, blk, k, drun, dsum);
+}
+
+
+// ================================================================================================
+// Three independent passes (no tickets, no look-backs; default): every workgroup of every pass is independent.
+//   rle3_summary : per tile {is the whole tile one run that continues the previous byte, trailing run length}
+//   rle3_carry   : per block, segmented scan -> run length that ends at the last byte before every tile
+//   rle3_pass<1> : per tile, emitted bytes          rle3_offsets : per block, exclusive scan + block size
+//   rle3_pass<2> : per tile, tokens -> LDS -> aligned stores
+// The passes use the mask-based tile code when every run around the tile is short enough that the 255-byte
+// segmentation cannot matter inside it, the per-element general code otherwise.
+// ================================================================================================
+struct Rle3Ctx {            // what a thread of the mask-based tile code knows after its loads
+    u32 w[4];
+    u32 E16, Z16;
+};
+
+// loads + masks; returns false when the tile has to take the general code (ragged end of the block).
+// sh.E / sh.lastb filled; barrier inside.
+__device__ __forceinline__ bool rle3_masks(RleShared &sh, const RleBlk &blk, const int k, Rle3Ctx &c, const bool lookahead)
+{
+    const int tid = threadIdx.x;
+    const u64 n = blk.n;
+    const u64 tile_start = (u64)k * RLE_TILE, tile_end = tile_start + RLE_TILE;
+    if (tile_end + (lookahead ? 4 : 0) > n) return false;                // uniform
+    const uint4 v = *(const uint4 *)(blk.in + tile_start + (u64)tid * 16);
+    c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
+    sh.lastb[tid + 1] = (u16)(c.w[3] >> 24);
+    if (tid == 0) {
+        u32 e0 = 0, lb = 0x100u;                       // first tile: nothing before it
+        if (k > 0) {
+            const u32 q = *(const u32 *)(blk.in + tile_start - 4);      // bytes -4 .. -1
+            e0 = (eqmask4(q, q << 8) >> 1) << 13;      // E of positions -3, -2, -1 in bits 13..15
+            lb = q >> 24;
+        }
+        sh.E[0] = (u16)e0;
+        sh.lastb[0] = (u16)lb;
+    }
+    if (tid == RLE_THREADS - 1) {
+        u32 e = 0;
+        if (lookahead) {
+            const u32 q = *(const u32 *)(blk.in + tile_end);            // bytes 4096 .. 4099 of the tile's frame
+            e = eqmask4(q, (q << 8) | (c.w[3] >> 24)) & 7u;
+        }
+        sh.E[RLE_THREADS + 1] = (u16)e;
+    }
+    __syncthreads();
+    const u32 pb = sh.lastb[tid];
+    u32 E16 = eqmask4(c.w[0], (c.w[0] << 8) | (pb & 0xFFu)) | (eqmask4(c.w[1], __builtin_amdgcn_alignbit(c.w[1], c.w[0], 24)) << 4) |
+              (eqmask4(c.w[2], __builtin_amdgcn_alignbit(c.w[2], c.w[1], 24)) << 8) |
+              (eqmask4(c.w[3], __builtin_amdgcn_alignbit(c.w[3], c.w[2], 24)) << 12);
+    if (pb > 0xFFu) E16 &= ~1u;
+    c.E16 = E16;
+    c.Z16 = eqmask4(c.w[0], 0) | (eqmask4(c.w[1], 0) << 4) | (eqmask4(c.w[2], 0) << 8) | (eqmask4(c.w[3], 0) << 12);
+    sh.E[tid + 1] = (u16)E16;
+    return true;
+}
+
+__global__ __launch_bounds__(RLE_THREADS) void rle3_summary(const RleBlk *__restrict__ blks, u32 *__restrict__ tsum)
+{
+    __shared__ __attribute__((aligned(16))) RleShared sh;
+    const RleBlk blk = blks[blockIdx.y];
+    const int k = (int)blockIdx.x, tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    if ((u32)k >= blk.n_tiles) return;
+    Rle3Ctx c;
+    if (!rle3_masks(sh, blk, k, c, false)) {           // ragged last tile: nothing follows that needs it
+        if (tid == 0) tsum[blk.desc_base + k] = 0;
+        return;
+    }
+    const u32 H16 = ~c.E16 & 0xFFFFu;
+    const u64 hm = __ballot(H16 != 0);
+    int last = -1;                                     // tile-local position of the wave's last run head
+    if (hm) {
+        const int l = 63 - __builtin_clzll((unsigned long long)hm);
+        const u32 hv = (u32)__shfl((int)H16, l, 64);
+        last = (wv * 64 + l) * 16 + (31 - __builtin_clz(hv));
+    }
+    if (lane == 0) sh.wsum[wv] = (u32)last;
+    __syncthreads();
+    if (tid == 0) {
+        int lp = -1;
+        for (int ww = 0; ww < 4; ++ww) if ((int)sh.wsum[ww] >= 0) lp = (int)sh.wsum[ww];
+        tsum[blk.desc_base + k] = lp < 0 ? (0x80000000u | (u32)RLE_TILE) : (u32)(RLE_TILE - lp);
+    }
+}
+
+// R[t] = length of the run that ends at the last byte of tile t - 1
+__global__ __launch_bounds__(RLE_THREADS) void rle3_carry(const RleBlk *__restrict__ blks, const u32 *__restrict__ tsum,
+                                                          u32 *__restrict__ R)
+{
+    __shared__ Seg wtot[4];
+    __shared__ Seg carry;
+    const RleBlk blk = blks[blockIdx.x];
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    if (tid == 0) carry = Seg{0u, 0u};
+    __syncthreads();
+    for (u32 t0 = 0; t0 < blk.n_tiles; t0 += RLE_THREADS) {
+        const u32 t = t0 + tid;
+        const u32 x = t < blk.n_tiles ? tsum[blk.desc_base + t] : 0u;
+        Seg f = Seg{x >> 31, x & 0x7FFFFFFFu};
+        const Seg own = f;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            Seg y = Seg{(u32)__shfl_up(f.f, d, 64), (u32)__shfl_up(f.v, d, 64)};
+            if (lane >= d) f = comb_f(y, f);
+        }
+        if (lane == 63) wtot[wv] = f;
+        __syncthreads();
+        Seg pre = carry;                                // everything before this wave
+        for (int ww = 0; ww < wv; ++ww) pre = comb_f(pre, wtot[ww]);
+        // exclusive value = run ending just before tile t
+        Seg ex = Seg{(u32)__shfl_up(f.f, 1, 64), (u32)__shfl_up(f.v, 1, 64)};
+        if (lane == 0) ex = Seg{1u, 0u};
+        const Seg before = comb_f(pre, ex);
+        (void)own;
+        if (t < blk.n_tiles) R[blk.desc_base + t] = before.v;
+        __syncthreads();
+        if (tid == 0) {
+            Seg c2 = carry;
+            for (int ww = 0; ww < 4; ++ww) c2 = comb_f(c2, wtot[ww]);
+            carry = c2;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(RLE_THREADS) void rle3_offsets(const RleBlk *__restrict__ blks, const u32 *__restrict__ T,
+                                                            u64 *__restrict__ G)
+{
+    __shared__ u64 wtot[4];
+    __shared__ u64 carry;
+    const RleBlk blk = blks[blockIdx.x];
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (u32 t0 = 0; t0 < blk.n_tiles; t0 += RLE_THREADS) {
+        const u32 t = t0 + tid;
+        const u64 cnt = t < blk.n_tiles ? (u64)T[blk.desc_base + t] : 0ull;
+        const u64 incl = wave_incl_scan_add<u64>(cnt);
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        u64 base = carry;
+        for (u32 ww = 0; ww < wv; ++ww) base += wtot[ww];
+        if (t < blk.n_tiles) G[blk.desc_base + t] = base + incl - cnt;
+        __syncthreads();
+        if (tid == 0) carry += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        __syncthreads();
+    }
+    if (tid == 0) *blk.out_n = carry;
+}
+
+template <int MODE>                                     // 1: sizes -> T, 2: emit at G
+__global__ __launch_bounds__(RLE_THREADS) void rle3_pass(const RleBlk *__restrict__ blks, const u32 *__restrict__ Rarr,
+                                                         u32 *__restrict__ Tarr, const u64 *__restrict__ Garr)
+{
+    __shared__ __attribute__((aligned(16))) RleShared sh;
+    const RleBlk blk = blks[blockIdx.y];
+    const int k = (int)blockIdx.x, tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    if ((u32)k >= blk.n_tiles) return;
+    const u32 Rin = Rarr[blk.desc_base + k];
+    const u64 Gin = MODE == 2 ? Garr[blk.desc_base + k] : 0ull;
+    Rle3Ctx c;
+    bool fast = rle3_masks(sh, blk, k, c, true);
+    if (fast) {
+        // mask code only when no run around the tile can reach 255 bytes inside it: at most 5 threads per wave lie
+        // wholly inside a run (<= 10 across a wave edge: 192 bytes with both ends) and the entering run is < 60 bytes
+        const u32 transparent = (u32)__builtin_popcountll((unsigned long long)__ballot(c.E16 == 0xFFFFu));
+        const bool enters = (sh.E[1] & 1u) != 0;
+        if (__syncthreads_or((transparent > 5) || (enters && Rin >= 60))) fast = false;
+    }
+    if (!fast) {
+        __syncthreads();
+        rle_tile_general<MODE>(sh, blk, k, nullptr, nullptr, Rin, Gin, Tarr + blk.desc_base + k);
+        return;
+    }
+    const u32 E16 = c.E16, Z16 = c.Z16, H16 = ~E16 & 0xFFFFu;
+    const u32 B = ((u32)sh.E[tid] >> 13) | (E16 << 3) | (((u32)sh.E[tid + 2] & 7u) << 19);   // positions -3 .. 18
+    const u32 Tm = B & (B >> 1) & (B >> 2);
+    const u32 LC = (((Tm >> 1) | Tm | (Tm << 1) | (Tm << 2)) >> 3) & 0xFFFFu;                 // bytes of runs of >= 4
+    const u32 Lit = ~Z16 & ~LC & 0xFFFFu;
+    const u32 T3 = H16 & (Z16 | LC);
+    const u32 tot = (u32)__builtin_popcount(Lit) + 3u * (u32)__builtin_popcount(T3);
+    const u32 incl = wave_incl_scan_add<u32>(tot);
+    if (lane == 63) sh.wsum[wv] = incl;
+    // distance from the end of this thread's bytes to the next run head (for the count of a run that leaves the thread)
+    u32 after = 0;
+    if (MODE == 2) {
+        const u64 hm = __ballot(H16 != 0);              // never 0: at most 5 threads of a wave have no head
+        const u64 above = lane == 63 ? 0ull : hm & ~((2ull << lane) - 1);
+        const int l2 = above ? __builtin_ctzll((unsigned long long)above) : 0;
+        const u32 hv = (u32)__shfl((int)H16, l2, 64);
+        if (above) after = 16u * (u32)(l2 - lane - 1) + (u32)__builtin_ctz(hv);
+        if (lane == 0) {
+            const int l0 = __builtin_ctzll((unsigned long long)hm);
+            sh.wf[wv].v = 16u * (u32)l0;                // + ctz of that lane's heads, added below
+        }
+        const int l0 = __builtin_ctzll((unsigned long long)hm);
+        const u32 h0 = (u32)__shfl((int)H16, l0, 64);
+        if (lane == 0) sh.wf[wv].v += (u32)__builtin_ctz(h0);          // first head of this wave, in bytes from its start
+        if (wv == 1) {                                  // halo: bytes after the tile equal to its last byte (<= 255)
+            const u64 n = blk.n, tile_end = (u64)(k + 1) * RLE_TILE;
+            const u32 lastb = sh.lastb[RLE_THREADS];
+            const u64 q = tile_end + (u64)lane * 4;
+            u32 cnt = 0;
+            bool go = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u32 cc = (q + j < n) ? (u32)blk.in[q + j] : 0x400u;
+                go &= (cc == lastb);
+                cnt += go ? 1u : 0u;
+            }
+            const u64 full = __ballot(cnt == 4);
+            const int f0 = (~full) ? (__ffsll((unsigned long long)~full) - 1) : 64;
+            const u32 c0 = (f0 < 64) ? (u32)__shfl((int)cnt, f0, 64) : 0u;
+            u32 H = (u32)f0 * 4 + c0;
+            if (H > 255) H = 255;
+            if (lane == 0) sh.H = H;
+        }
+        (void)above;
+    }
+    __syncthreads();
+    u32 run = 0, off = 0;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) {
+        if (ww == wv) off = run + incl - tot;
+        run += sh.wsum[ww];
+    }
+    const u32 Tt = run;
+    if (MODE == 1) {
+        if (tid == 0) Tarr[blk.desc_base + k] = Tt;
+        return;
+    }
+    if (MODE == 2) {
+        const u64 hm = __ballot(H16 != 0);
+        const bool has_above = lane != 63 && (hm & ~((2ull << lane) - 1)) != 0;
+        if (!has_above) after = 16u * (u32)(63 - lane) + (wv < 3 ? sh.wf[wv + 1].v : sh.H);
+    }
+    const u64 G = Gin;
+    const u32 shift = (u32)G & 3;
+    u8 *st8 = (u8 *)sh.stage;
+    u32 o = shift + off;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const u32 xj = (c.w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        if ((T3 >> j) & 1u) {
+            const u32 hn = H16 >> (j + 1);
+            u32 L;
+            if (j < 15 && hn) L = (u32)__builtin_ctz(hn) + 1;           // next head inside this thread
+            else { L = (16 - j) + after; L = L > 255u ? 255u : L; }
+            st8[o] = 0; st8[o + 1] = (u8)xj; st8[o + 2] = (u8)L;
+            o += 3;
+        } else if ((Lit >> j) & 1u) {
+            st8[o] = (u8)xj;
+            o += 1;
+        }
+    }
+    __syncthreads();
+    const u64 end_b = G + Tt;
+    if (end_b > blk.out_cap) {
+        if (tid == 0) set_error(blk.err, SHAFA_LACK_OF_MEMORY);
+    } else {
+        const u32 nwords = (shift + Tt + 3) >> 2;
+        const u64 gw0 = G >> 2;
+        for (u32 ww = tid; ww < nwords; ww += RLE_THREADS) {
+            const u32 val = sh.stage[ww];
+            const u64 byte0 = (gw0 + ww) * 4;
+            if (byte0 >= G && byte0 + 4 <= end_b) {
+                ((u32 *)blk.out)[gw0 + ww] = val;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (byte0 + q >= G && byte0 + q < end_b) blk.out[byte0 + q] = (u8)(val >> (8 * q));
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -489,7 +776,10 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
     const size_t o_sum = off; off += ndesc * 8;
     const size_t o_tick = off; off += (size_t)nblocks * 4; off = (off + 15) & ~(size_t)15;
     const size_t o_zero_end = off;
-    const size_t o_blk = off; off += (size_t)nblocks * sizeof(RleBlk);
+    const size_t o_blk = off; off += (size_t)nblocks * sizeof(RleBlk); off = (off + 15) & ~(size_t)15;
+    const size_t o_tsum = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;     // three-pass path
+    const size_t o_R = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;
+    const size_t o_T = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;
     int rc = batch_reserve(bt, off);
     if (rc) return rc;
     u8 *ws = (u8 *)bt->d_ws;
@@ -513,7 +803,20 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
     HIP_TRY(hipMemsetAsync(ws, 0, o_zero_end, st));
     HIP_TRY(hipMemsetAsync(d_out_n, 0, (size_t)nblocks * 8, st));      // empty blocks: size 0
     HIP_TRY(hipMemcpyAsync(ws + o_blk, hb, (size_t)nblocks * sizeof(RleBlk), hipMemcpyHostToDevice, st));
-    if (max_tiles) {
+    const char *venv = getenv("SHAFA_RLE_V");
+    const int rle_v = venv ? atoi(venv) : 3;               // 3 = three independent passes, 1 = single chained pass
+    if (max_tiles && rle_v == 3) {
+        const RleBlk *dblk = (const RleBlk *)(ws + o_blk);
+        const dim3 grid_t(max_tiles, (u32)nblocks), grid_b((u32)nblocks);
+        u32 *tsum = (u32 *)(ws + o_tsum), *Rr = (u32 *)(ws + o_R), *Tt = (u32 *)(ws + o_T);
+        u64 *Gg = (u64 *)(ws + o_sum);                     // the chained path's descriptor array doubles as G
+        hipLaunchKernelGGL(rle3_summary, grid_t, dim3(RLE_THREADS), 0, st, dblk, tsum);
+        hipLaunchKernelGGL(rle3_carry, grid_b, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)tsum, Rr);
+        hipLaunchKernelGGL(rle3_pass<1>, grid_t, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Rr, Tt, (const u64 *)Gg);
+        hipLaunchKernelGGL(rle3_offsets, grid_b, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Tt, Gg);
+        hipLaunchKernelGGL(rle3_pass<2>, grid_t, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Rr, Tt, (const u64 *)Gg);
+        HIP_TRY(hipGetLastError());
+    } else if (max_tiles) {
         hipLaunchKernelGGL(rle_encode_kernel, dim3(max_tiles * (u32)nblocks), dim3(RLE_THREADS), 0, st,
                            (const RleBlk *)(ws + o_blk), nblocks, (u64 *)(ws + o_run), (u64 *)(ws + o_sum),
                            (u32 *)(ws + o_tick), getenv("SHAFA_RLE_GENERAL") ? 1u : 0u);
