@@ -358,3 +358,34 @@ def test_sf_decode_codes_of_17_to_32_bits_fast_path(oracle, shafa):
         assert got.tobytes() == mix.tobytes(), f"dense rare n={n} lmax={lmax}: {first_diff(got, mix)}"
         rc, _ = shafa.sf_decode(enc[: enc.size // 3], to_shafa_table(shafa, otab), len(mix), raw_rc=True)
         assert rc == shafa.FILE_UNRECOGNIZABLE
+
+
+@pytest.mark.parametrize("env", [{"SHAFA_RLE_V": "1"}, {"SHAFA_RLE_V": "1", "SHAFA_RLE_GENERAL": "1"},
+                                 {"SHAFA_ENC_V": "1"}, {"SHAFA_ENC_V": "2"}, {"SHAFA_ENC_V": "4"},
+                                 {"SHAFA_DEC_NOPAIR": "1"}, {"SHAFA_DEC_NOMULTI": "1"}, {"SHAFA_DEC_NOFSM": "1"},
+                                 {"SHAFA_DEC_NOLONG": "1"}, {"SHAFA_DEC_GENERIC": "1"}])
+def test_alternative_kernel_paths_stay_bit_exact(oracle, shafa, env):
+    """The selectable variants (chained RLE encoder, single-pass / persistent SF encoders, the decoder's fallbacks) are
+    kept for comparison and as fallbacks: each must still produce the oracle's bytes."""
+    import golden.make_golden as mg
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        zt = shafa.zipf_table(1.2)
+        for n in (5000, 300001):
+            data = mg.runs_stream(900 + n, n, zt)
+            want = oracle.rle_encode(data)
+            got, freq = shafa.rle_encode(data, want_freq=True)
+            assert got.tobytes() == want.tobytes(), f"{env} rle n={n}: {first_diff(got, want)}"
+            for src in (want, oracle.gen_bytes(n, n, shafa.zipf_table(2.0))):        # Lmax <= 13 and 14..16
+                otab = oracle.sf_build(oracle.hist256(src))
+                rc, enc = oracle.sf_encode(src, otab)
+                t = to_shafa_table(shafa, otab)
+                assert shafa.sf_encode(src, t).tobytes() == enc.tobytes(), f"{env} sf_encode n={n}"
+                assert shafa.sf_decode(enc, t, len(src)).tobytes() == src.tobytes(), f"{env} sf_decode n={n}"
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
