@@ -174,10 +174,21 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);            // wave-uniform: keeps the wave selects scalar
     const EncBlk blk = blks[CHAINED ? blockIdx.x % (u32)nblk : blockIdx.y];   // CHAINED: blocks interleaved over the grid
     u32 tile = blockIdx.x;
+    uint4 cur[E3_ITEMS];
+    bool have = false;
     if (CHAINED) {
+        // the ticket decides the tile, but workgroups are dispatched in order in practice: load the tile the
+        // dispatch order suggests while the ticket's round trip is in flight, reload in the rare other case
         if (tid == 0) sh.tile = atomicAdd(tickets + blk.ticket, 1u);
+        const u32 guess = blockIdx.x / (u32)nblk;
+        if ((u64)(guess + 1) * E3_TILE <= blk.n) {
+#pragma unroll
+            for (int it = 0; it < E3_ITEMS; ++it)
+                cur[it] = gload<uint4>(blk.in + (u64)guess * E3_TILE + (u64)it * (E3_THREADS * 16) + (u64)tid * 16);
+        }
         __syncthreads();
         tile = sh.tile;
+        have = tile == guess && (u64)(guess + 1) * E3_TILE <= blk.n;
     }
     if (tile >= blk.n_tiles) return;
     const u64 base = (u64)tile * E3_TILE;
@@ -185,10 +196,10 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
 
     // everything this tile needs from memory is requested up front, nothing depends on anything else
     u64 B = CHAINED ? 0ull : tile_off[blk.desc_base + tile];
-    uint4 cur[E3_ITEMS];
 #pragma unroll
     for (int it = 0; it < E3_ITEMS; ++it) {
         const u64 idx = base + (u64)it * (E3_THREADS * 16) + (u64)tid * 16;
+        if (have) continue;
         if (full) cur[it] = gload<uint4>(blk.in + idx);
         else {
             u32 w[4] = {0, 0, 0, 0};
