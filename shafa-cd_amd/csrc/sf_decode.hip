@@ -1140,7 +1140,7 @@ template <bool MULTI, int SUBS, int LONG>
 __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *__restrict__ blks,
                                                                   const u8 *__restrict__ chunk_entry,
                                                                   const u16 *__restrict__ chunk_cnt,
-                                                                  const u64 *__restrict__ tile_off, u32 tpw, u32 dbg)
+                                                                  const u64 *__restrict__ tile_off, u32 tpw)
 {
     constexpr int TAB = MULTI ? (4 << SYM3_MAXK) : (2 << LEN_MAXK);
     __shared__ __attribute__((aligned(16))) u8 smem[SUBS * LDS_DATA + TAB + SUBS * 16 + 64 + (LONG == 1 ? LONG_BYTES : LONG == 2 ? LONG32_BYTES : 0)];
@@ -1185,7 +1185,6 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *
     const u64 nsym = blk.n_sym;
     u32 want = first >= nsym ? 0u : (nsym - first < (u64)cnt ? (u32)(nsym - first) : cnt);
     u8 *op = blk.out + first;
-    if (dbg & 2) op = (u8 *)((unsigned long long)op & ~15ull);          // timing experiment only
     const u32 cbase = tid * CH_BITS, sh = 32 - K1;
     u32 p = entry, na = 0;
     u64 acc = 0;
@@ -1212,7 +1211,7 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *
             want -= take;
             if (nb >= 8) {                              // sixteen symbols per store (any byte alignment)
                 if (have_pend) {
-                    if (!(dbg & 1) || acc == 0x123456789ull) gstore<uint4>(op, make_uint4((u32)pend, (u32)(pend >> 32), (u32)acc, (u32)(acc >> 32)));
+                    gstore<uint4>(op, make_uint4((u32)pend, (u32)(pend >> 32), (u32)acc, (u32)(acc >> 32)));
                     op += 16;
                 } else {
                     pend = acc;
@@ -1691,7 +1690,6 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const dim3 grid_w((u32)ceil_div_u64(max_tiles, tpw * WSUBS), (u32)nblocks);
     constexpr int CSUBS = 4;                           // 256-lane groups per workgroup of sfd_countfsm
     const dim3 grid_c((u32)ceil_div_u64(max_tiles, tpw * CSUBS), (u32)nblocks);
-    const u32 dbg = getenv("SHAFA_DEC_DBG") ? (u32)atoi(getenv("SHAFA_DEC_DBG")) : 0u;
     if (packed) {
         const size_t lds_count16 = lds_data + DEC_THREADS * 8 + lds_lut + 32 + DEC_THREADS + 64;
         if (need_tabs) hipLaunchKernelGGL(sfd_tables, grid_b, dim3(DEC_THREADS), 0, st, dblk);
@@ -1743,17 +1741,17 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
                        (u64 *)(ws + o_toff));
     if (mid32) {
         hipLaunchKernelGGL((sfd_write13<true, WSUBS, 2>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
-                           (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, dbg);
+                           (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw);
     } else if (fast13) {
         if (multi && long_all)
             hipLaunchKernelGGL((sfd_write13<true, WSUBS, 1>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
-                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, dbg);
+                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw);
         else if (multi)
             hipLaunchKernelGGL((sfd_write13<true, WSUBS, 0>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
-                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, dbg);
+                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw);
         else
             hipLaunchKernelGGL((sfd_write13<false, WSUBS, 0>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
-                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, dbg);
+                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw);
     } else {
         hipLaunchKernelGGL(sfd_write, grid_t, dim3(DEC_THREADS), lds_write, st, dblk, l2cap, (const u8 *)(ws + o_cent),
                            (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff));
