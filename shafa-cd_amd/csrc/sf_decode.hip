@@ -397,7 +397,9 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
 }
 
 // sfd_sync16: dynamic LDS: data | lenlut[2^13] u8 (PAIR: pairlut[2^14]) | cmap[256] u64 | wmb[64] u8
-template <bool PAIR, bool LONG>
+// K1T: the launch's common table width when every block has it (12 or 13: window offsets become constants, a
+// pair window that lies inside one stream word is then a single v_bfe), 0 = per block at run time.
+template <bool PAIR, bool LONG, int K1T = 0>
 __global__ __launch_bounds__(DEC_THREADS) void sfd_sync16(const DecBlk *__restrict__ blks,
                                                           u64 *__restrict__ chunkfn, u64 *__restrict__ tilefn, u32 tpw)
 {
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_sync16(const DecBlk *__restri
     u8 *wmb = (u8 *)(cmap + DEC_THREADS);
     const u16 *lt = (const u16 *)(wmb + 64);
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 K1 = blk.K1;
+    const u32 K1 = K1T ? (u32)K1T : blk.K1;
 
     if (LONG) {                                        // blocks of the launch without long codes: empty list
         if (blk.longtab) fill_lds16((void *)lt, blk.longtab, LONG_BYTES);
@@ -436,8 +438,12 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_sync16(const DecBlk *__restri
             u32 e[16];
 #pragma unroll
             for (int q = 15; q >= 0; --q) {
-                const u32 win = q ? __builtin_amdgcn_alignbit(w0, w1, 32 - 2 * q) : w0;
-                e[q] = lenlut[win >> sh];
+                if (K1T && 2 * q + K1T + 1 <= 32) {              // the K1+1-bit window lies inside w0: one bit-field extract
+                    e[q] = lenlut[__builtin_amdgcn_ubfe(w0, 32 - 2 * q - (K1T + 1), K1T + 1)];
+                } else {
+                    const u32 win = q ? __builtin_amdgcn_alignbit(w0, w1, 32 - 2 * q) : w0;
+                    e[q] = lenlut[win >> sh];
+                }
             }
 #pragma unroll
             for (int q = 15; q >= 0; --q) {
@@ -1693,7 +1699,16 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     if (packed) {
         const size_t lds_count16 = lds_data + DEC_THREADS * 8 + lds_lut + 32 + DEC_THREADS + 64;
         if (need_tabs) hipLaunchKernelGGL(sfd_tables, grid_b, dim3(DEC_THREADS), 0, st, dblk);
-        if (pair_all)
+        u32 k1_all = 0;                                // common K1 of the running blocks, 0 when they differ
+        for (int b = 0; b < nblocks; ++b)
+            if (ntiles[b]) k1_all = (k1_all == 0 || k1_all == tabs[b].K1) ? tabs[b].K1 : 0xFFFFFFFFu;
+        if (pair_all && k1_all == 12)
+            hipLaunchKernelGGL((sfd_sync16<true, false, 12>), grid_f, dim3(DEC_THREADS), 0, st, dblk,
+                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw);
+        else if (pair_all && k1_all == 13)
+            hipLaunchKernelGGL((sfd_sync16<true, false, 13>), grid_f, dim3(DEC_THREADS), 0, st, dblk,
+                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw);
+        else if (pair_all)
             hipLaunchKernelGGL((sfd_sync16<true, false>), grid_f, dim3(DEC_THREADS), 0, st, dblk,
                                (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw);
         else if (long_all)
