@@ -3,50 +3,119 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (config.workload): BASELINE config[3] weak-scaled to one GPU — Zipf(1.2) bytes in 64 MiB
-blocks (-b M), 8 GiB (128 blocks) per GPU by default; every rank owns its own shard of the global
-stream (rank r generates bytes [r*shard, (r+1)*shard) on-device), no data-path collective.
-One step = Module C over every resident block (SF bit-pack encode, tables from the block histograms
-via Module T, prepared before the timed region like the reference's .cod file) followed by Module D
-over every block (SF decode back to the bytes).  value = uncompressed GiB of all ranks / step time.
-Inputs are resident in HBM when the timed region starts; outputs stay in HBM.
+With N > 1 and no RANK in the environment the script starts the N ranks itself (torch.distributed.run, one
+process per GPU, rendezvous on 127.0.0.1) before anything touches the GPU; under the driver's own
+`python -m torch.distributed.run ... bench.py --gpus N` it is simply rank RANK of WORLD_SIZE.
 
-The JSON line also carries `roofline` (dominant kernel, HIP-event timed on the launch stream) and,
-at N=1, `cpu_baseline` (the reference binary oracle/_ref/shafa when present, else the oracle port,
-timed on the host cores on a bounded sample).
+Workload (config.workload): BASELINE config[3] weak-scaled to one GPU — the surveyed cfg-4 stream
+"Zipf(1.2) bytes mod 256" (Shannon-Fano output 0.812 n) in 64 MiB blocks (-b M), 8 GiB
+(128 blocks) per GPU by default; every rank owns its own shard of the global stream (rank r generates bytes
+[r*shard, (r+1)*shard) on-device), no data-path collective.  One step = Module C over every resident block
+(SF bit-pack encode, tables from the block histograms via Module T, prepared before the timed region like
+the reference's .cod file) followed by Module D over every block (SF decode back to the bytes).
+value = uncompressed GiB of all ranks / step time.  Inputs are resident in HBM when the timed region starts.
+
+The JSON line also carries `roofline` (dominant kernel sequence, HIP-event timed on the launch stream),
+`cpu_baseline` at N=1 (the reference binary oracle/_ref/shafa when present, else the oracle port, timed on
+the host cores on a bounded sample), `scatter_gather` at N>1 (X1/X2 over RCCL) and, with
+--pipeline, the F -> T -> C and D(SF+RLE) legs at -b M.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (8.0 TB/s)
 GIB = float(1 << 30)
+METRIC = "GiB/s Shannon-Fano encode+decode, 64 MiB blocks, 1/2/4/8 GPUs; bit-exact"
+SEED = 20260101
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--blocks", type=int, default=128, help="64 MiB blocks per GPU")
+    ap.add_argument("--blocks", type=int, default=128, help="blocks per GPU")
     ap.add_argument("--block-mib", type=int, default=64)
-    ap.add_argument("--dist", default="zipf", choices=["zipf", "uniform"])
+    ap.add_argument("--dist", default="zipfmod", choices=["zipfmod", "zipf", "uniform"],
+                    help="zipfmod = Zipf(s) over the integers mod 256 (surveyed cfg-4 stream); zipf = Zipf(s) truncated to 256 ranks")
+    ap.add_argument("--zipf-s", type=float, default=1.2)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-sample-blocks", type=int, default=16)
     ap.add_argument("--encode-only", action="store_true")
     ap.add_argument("--scatter-gather", action="store_true",
-                    help="also time X1 (root scatters whole blocks) + encode + X2 (root gathers the payloads); extra JSON field")
-    ap.add_argument("--zipf-s", type=float, default=1.2, help="Zipf exponent of the synthetic bytes (metric config: 1.2)")
-    return ap.parse_args()
+                    help="time X1 (root scatters whole blocks) + encode + X2 (root gathers the payloads) also at N=1")
+    ap.add_argument("--no-scatter-gather", action="store_true", help="skip the X1/X2 leg at N>1")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="extra object: F (RLE + histogram) -> T -> C and D (SF + RLE decode) at this block size on run-heavy data")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="test aid: allow more ranks than GPUs (ranks share devices, collectives over gloo); never a valid scaling number")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """Start the N ranks as children of this process (which has not touched the GPU and never will)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def csrc_hash():
+    """SHA-256 over the kernel sources: ties profiles/*_traffic.json to the code it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "shafa-cd_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".hpp")):
+            with open(os.path.join(d, fn), "rb") as f:
+                h.update(fn.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def measured_traffic(workload_key):
+    """HBM bytes per input byte from the newest profiles/r*_traffic.json whose csrc hash and workload match
+    this tree (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/gpu_traffic.sh); None otherwise, so a
+    stale constant is never reported."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for fn in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if fn.endswith("_traffic.json"):
+            try:
+                with open(os.path.join(pdir, fn)) as f:
+                    j = json.load(f)
+            except Exception:
+                continue
+            if j.get("csrc_sha256") == csrc_hash() and j.get("workload_key") == workload_key:
+                best = (fn, j)
+    return best
+
+
+def dist_table(pkg, args):
+    import golden.make_golden as mg
+    if args.dist == "zipfmod":
+        return mg.zipf_mod256_table(args.zipf_s)
+    if args.dist == "zipf":
+        return pkg.zipf_table(args.zipf_s)
+    return None
 
 
 def cpu_baseline(args, pkg, zt):
@@ -58,7 +127,7 @@ def cpu_baseline(args, pkg, zt):
     nblk = args.cpu_sample_blocks
     bs = args.block_mib << 20
     n = nblk * bs
-    data = orc.gen_bytes(20260101, n, zt if args.dist == "zipf" else None)
+    data = orc.gen_bytes(SEED, n, zt)
     cores = os.cpu_count() or 1
     ref = oracle_lib.REF_BIN
     shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
@@ -97,35 +166,145 @@ def cpu_baseline(args, pkg, zt):
             "encode_GiBs": n / GIB / (t1 - t0), "decode_GiBs": n / GIB / (t2 - t1)}
 
 
+class Comm:
+    """Barrier + max-reduce around the timed region.  RCCL (backend "nccl") with one GPU per rank; gloo only in
+    the --oversubscribe test mode where ranks share a device."""
+
+    def __init__(self, args, torch, dist):
+        self.dist, self.torch = dist, torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        ndev = torch.cuda.device_count()
+        if ndev < 1:
+            raise SystemExit("bench.py: no GPU visible (the HIP path has no CPU fallback)")
+        self.backend = "nccl"
+        if self.local >= ndev:
+            if not args.oversubscribe:
+                raise SystemExit(f"bench.py: rank {self.rank} needs GPU {self.local} but only {ndev} visible "
+                                 "(--oversubscribe shares devices for plumbing tests only)")
+            self.backend = "gloo"
+        self.device_index = self.local % ndev
+        self.oversubscribed = self.backend == "gloo"
+        if self.world > 1 or args.scatter_gather:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+        self.dev = torch.device("cuda", self.device_index)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.dist.is_initialized():
+            self.dist.destroy_process_group()
+
+
+def pipeline_leg(args, pkg, torch, dev, st, steps):
+    """F (RLE + histogram of the RLE bytes) -> T (host) -> C (SF encode of the RLE bytes), then D (SF decode + RLE
+    decode) on run-heavy data (Zipf symbols in geometric runs, cfg-2 shape); per-family HIP-event times and
+    algorithmic-byte rooflines."""
+    import numpy as np
+    import golden.make_golden as mg
+    nb = min(args.blocks, 32)
+    bs = args.block_mib << 20
+    blk = torch.from_numpy(mg.runs_stream(11, bs, pkg.zipf_table(1.2))).to(dev)
+    d_in = blk.repeat(nb)
+    bt = pkg.Batch(nb, 2 * bs + 64)
+    off, n = [b * bs for b in range(nb)], [bs] * nb
+    rcap = 2 * bs + 64
+    roff = [b * rcap for b in range(nb)]
+    d_rle = torch.empty(nb * rcap, dtype=torch.uint8, device=dev)
+    d_rle_n = torch.zeros(nb, dtype=torch.int64, device=dev)
+    d_freq = torch.zeros(nb * 256, dtype=torch.int64, device=dev)
+
+    def timed(fn):
+        fn()
+        bt.finish(st, nb)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(steps):
+            fn()
+        e1.record(st)
+        bt.finish(st, nb)
+        return e0.elapsed_time(e1) / steps * 1e-3
+
+    out = {"workload": f"{nb} x {args.block_mib} MiB blocks of Zipf(1.2) symbols in geometric runs (p=0.35)"}
+    t_h = timed(lambda: bt.hist256(st, d_in, off, n, d_freq))
+    t_f = timed(lambda: bt.rle_encode(st, d_in, off, n, d_rle, roff, [rcap] * nb, d_rle_n, d_freq))
+    rle_n = [int(x) for x in d_rle_n.cpu().numpy()]
+    freq = d_freq.cpu().numpy().astype(np.uint64).reshape(nb, 256)
+    t0 = time.perf_counter()
+    tables = bt._tables([pkg.sf_build_codes(freq[b]) for b in range(nb)])
+    t_t = time.perf_counter() - t0
+    lens = np.stack([tables[b].lens() for b in range(nb)]).astype(np.uint64)
+    enc_bytes = [int(x) for x in ((freq * lens).sum(axis=1) + 7) // 8]
+    cap = ((max(enc_bytes) + 4096 + 255) // 256) * 256
+    eoff = [b * cap for b in range(nb)]
+    d_enc = torch.empty(nb * cap, dtype=torch.uint8, device=dev)
+    d_enc_n = torch.zeros(nb, dtype=torch.int64, device=dev)
+    t_c = timed(lambda: bt.sf_encode(st, d_rle, roff, rle_n, tables, d_enc, eoff, [cap] * nb, d_enc_n))
+    assert [int(x) for x in d_enc_n.cpu().numpy()] == enc_bytes
+    d_sym = torch.empty(nb * rcap, dtype=torch.uint8, device=dev)
+    t_ds = timed(lambda: bt.sf_decode(st, d_enc, eoff, enc_bytes, tables, rle_n, d_sym, roff))
+    dcap = bs + 2048
+    doff = [b * dcap for b in range(nb)]
+    d_dec = torch.empty(nb * dcap, dtype=torch.uint8, device=dev)
+    d_dec_n = torch.zeros(nb, dtype=torch.int64, device=dev)
+    t_dr = timed(lambda: bt.rle_decode(st, d_sym, roff, rle_n, d_dec, doff, [bs + 1024] * nb, d_dec_n))
+    assert [int(x) for x in d_dec_n.cpu().numpy()] == n and torch.equal(d_dec[:bs], blk), "pipeline round trip differs"
+    tot, rle_tot, enc_tot = float(nb * bs), float(sum(rle_n)), float(sum(enc_bytes))
+
+    def fam(alg, t):
+        return {"ms": t * 1e3, "algorithmic_bytes": alg, "achieved_GBs": alg / t / 1e9, "frac": alg / t / 1e9 / HBM_PEAK_GBS,
+                "GiBs_of_original": tot / GIB / t}
+
+    out.update({"rle_ratio": rle_tot / tot, "sf_ratio_of_rle": enc_tot / rle_tot,
+                "K1_hist256": fam(tot, t_h), "K2_rle_encode_hist": fam(tot + rle_tot, t_f),
+                "T_host_ms": t_t * 1e3, "K3_sf_encode": fam(rle_tot + enc_tot, t_c),
+                "K4_sf_decode": fam(enc_tot + rle_tot, t_ds), "K5_rle_decode": fam(rle_tot + tot, t_dr),
+                "F_T_C_GiBs": tot / GIB / (t_f + t_t + t_c), "D_GiBs": tot / GIB / (t_ds + t_dr)})
+    bt.close()
+    return out
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))          # before importing torch / touching the GPU
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     import pkgload
     pkg = pkgload.load()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    pkg.lib().shafa_hip_init(local)
+    comm = Comm(args, torch, dist)
+    world, rank, dev = comm.world, comm.rank, comm.dev
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(dev)
+    pkg.lib().shafa_hip_init(comm.device_index)
 
     bs = args.block_mib << 20
     nb = args.blocks
     shard = nb * bs
-    zt = pkg.zipf_table(args.zipf_s)
+    zt = dist_table(pkg, args)
     st = torch.cuda.Stream(device=dev)
 
     # ---- resident inputs: this rank's shard of the global synthetic stream -----------------------
     d_in = torch.empty(shard, dtype=torch.uint8, device=dev)
-    d_map = torch.from_numpy(zt).to(dev) if args.dist == "zipf" else None
+    d_map = torch.from_numpy(zt).to(dev) if zt is not None else None
     with torch.cuda.stream(st):
-        pkg.gen_bytes(st, 20260101, rank * shard, d_in, shard, d_map)
+        pkg.gen_bytes(st, SEED, rank * shard, d_in, shard, d_map)
     bt = pkg.Batch(nb, bs)
     in_off = [b * bs for b in range(nb)]
     in_n = [bs] * nb
@@ -156,28 +335,19 @@ def main():
     encode()
     bt.finish(st, nb)
     got_n = d_enc_n.cpu().numpy().astype(np.uint64)
-    dbg = bool(os.environ.get("SHAFA_ENC_DBG"))          # timing experiments: outputs are wrong on purpose
-    if dbg:
-        have_decode = False
-        os.environ["SHAFA_BENCH_ORACLE_CHECK"] = "0"
-    assert dbg or (got_n == enc_bytes).all(), "encoded sizes differ from sum(freq*len)/8"
+    assert (got_n == enc_bytes).all(), "encoded sizes differ from sum(freq*len)/8"
     if have_decode:
-        try:
-            decode()
-            bt.finish(st, nb)
-            assert torch.equal(d_dec, d_in), "decode(encode(x)) != x"
-        except pkg.ShafaError as e:
-            if e.code != pkg.OUTSIDE_MODULE:
-                raise
-            have_decode = False
+        decode()
+        bt.finish(st, nb)
+        assert torch.equal(d_dec, d_in), "decode(encode(x)) != x"
     if rank == 0 and os.environ.get("SHAFA_BENCH_ORACLE_CHECK", "1") == "1":
+        import ctypes as C
         import oracle_lib
         orc = oracle_lib.load()
         blk = d_in[:min(bs, 4 << 20)].cpu().numpy()           # bounded oracle spot check of block 0's head
         otab = orc.sf_build(orc.hist256(blk))
         rc, want = orc.sf_encode(blk, otab)
         t = pkg.CodeTable()
-        import ctypes as C
         C.memmove(C.byref(t), C.byref(otab), C.sizeof(t))
         assert pkg.sf_encode(blk, t).tobytes() == want.tobytes(), "HIP encode differs from oracle"
 
@@ -191,8 +361,7 @@ def main():
     bt.finish(st, nb)
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * args.steps)]
-    if world > 1:
-        dist.barrier()
+    comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -204,16 +373,11 @@ def main():
         ev[3 * i + 2].record(st)
     st.synchronize()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    comm.barrier()
     t1 = time.perf_counter()
     rc, errs = bt.finish(st, nb)
     assert rc == 0
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = comm.max(t1 - t0)
 
     enc_ms = [ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(args.steps)]
     dec_ms = [ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(args.steps)]
@@ -225,64 +389,75 @@ def main():
     alg = total_in + total_enc
     enc_gbs = alg / enc_t / 1e9
     dec_gbs = alg / dec_t / 1e9 if have_decode else None
-    # HBM traffic per launch: measured offline with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes
-    # (tools/gpu_pmc_traffic.sh, gfx950 FETCH correction applied) on this workload; scaled by the launch's bytes.
+    # HBM traffic per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_traffic.sh,
+    # gfx950 FETCH correction applied) on this workload AND this csrc hash; null when no matching profile exists.
+    wkey = f"{args.dist}:{args.zipf_s:g}:{args.block_mib}"
     traffic = {"sf_encode": None, "sf_decode": None}
-    tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
-    if args.dist == "zipf" and args.zipf_s == 1.2 and args.block_mib == 64 and os.path.exists(tpath):
-        with open(tpath) as f:
-            per_byte = json.load(f)["bytes_per_input_byte"]
-        traffic = {k: per_byte[k] * total_in for k in traffic}
+    tsrc = None
+    m = measured_traffic(wkey)
+    if m:
+        per_byte = m[1]["bytes_per_input_byte"]
+        traffic = {k: (per_byte[k] * total_in if per_byte.get(k) is not None else None) for k in traffic}
+        tsrc = f"profiles/{m[0]} (rocprofv3 PMC, separate passes, csrc {m[1]['csrc_sha256'][:12]})"
     dominant = "sf_decode" if have_decode and dec_t > enc_t else "sf_encode"
     roof = {"bound": "hbm", "kernel": dominant,
             "achieved": dec_gbs if dominant == "sf_decode" else enc_gbs,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic[dominant],
-            "traffic_source": "profiles/r1_traffic.json (rocprofv3 PMC, separate run)" if traffic[dominant] else None}
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic[dominant], "traffic_source": tsrc}
     roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
 
-    # ---- optional: root-scatter-included encode: never part of `value` -------------
+    # ---- root-scatter-included encode: always at N>1, never part of `value` --------
     sg = None
-    if args.scatter_gather:
-        import pkgload as _pl
-        shd = _pl.load_submodule("sharding")
-        if world == 1 and not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29531")
-            dist.init_process_group("nccl", rank=0, world_size=1)
-        total_all = world * shard
+    if ((world > 1 and not args.no_scatter_gather) or args.scatter_gather) and not comm.oversubscribed:
+        shd = pkgload.load_submodule("sharding")
+        sg_nb = min(nb, 16)                               # bounded: the root holds world * sg_nb blocks
+        sg_shard = sg_nb * bs
+        total_all = world * sg_shard
         src = None
-        if rank == 0:                                    # the reader rank holds the whole stream
+        if rank == 0:                                     # the reader rank holds the whole stream
             src = torch.empty(total_all, dtype=torch.uint8, device=dev)
-            pkg.gen_bytes(None, 20260101, 0, src, total_all, d_map)
+            for r in range(world):                        # rank r's first sg_nb blocks, as resident on rank r
+                pkg.gen_bytes(None, SEED, r * shard, src[r * sg_shard:(r + 1) * sg_shard], sg_shard, d_map)
         torch.cuda.synchronize()
-        dist.barrier()
+        comm.barrier()
         t0 = time.perf_counter()
         local, first_blk, sizes = shd.scatter_blocks(src, total_all, bs, dev)              # X1
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        bt.sf_encode(st, local, in_off, in_n, tables, d_enc, out_off, out_cap, d_enc_n)     # same tables: same stream
-        bt.finish(st, nb)
+        bt.sf_encode(st, local, in_off[:sg_nb], in_n[:sg_nb], tables[:sg_nb], d_enc, out_off[:sg_nb], out_cap[:sg_nb],
+                     d_enc_n)                                            # same tables: same stream
+        bt.finish(st, sg_nb)
         t2 = time.perf_counter()
-        got = shd.gather_payloads(d_enc, out_off, [int(x) for x in enc_bytes], world * nb, dev)   # X2
+        got = shd.gather_payloads(d_enc, out_off[:sg_nb], [int(x) for x in enc_bytes[:sg_nb]], world * sg_nb, dev)   # X2
         torch.cuda.synchronize()
-        dist.barrier()
+        comm.barrier()
         t3 = time.perf_counter()
-        assert torch.equal(local, d_in), "scattered shard differs from the resident one"
+        assert torch.equal(local, d_in[:sg_shard]), "scattered shard differs from the resident one"
         if rank == 0:
-            assert len(got) == world * nb and all(g is not None for g in got)
-            sg = {"x1_scatter_ms": (t1 - t0) * 1e3, "encode_ms": (t2 - t1) * 1e3, "x2_gather_ms": (t3 - t2) * 1e3,
+            assert len(got) == world * sg_nb and all(g is not None for g in got)
+            sg = {"blocks_per_gpu": sg_nb, "backend": comm.backend,
+                  "x1_scatter_ms": (t1 - t0) * 1e3, "encode_ms": (t2 - t1) * 1e3, "x2_gather_ms": (t3 - t2) * 1e3,
+                  "encode_GiBs_resident_sharded": total_all / GIB / (t2 - t1),
                   "encode_GiBs_root_scatter_gather_included": total_all / GIB / (t3 - t0)}
-    dist_name = args.dist if args.zipf_s == 1.2 or args.dist != 'zipf' else 'zipf(s=%g)' % args.zipf_s
+        del src, local, got
+        encode()                                           # restore d_enc for anything that follows
+        bt.finish(st, nb)
+
+    pipe = None
+    if args.pipeline and rank == 0:
+        pipe = pipeline_leg(args, pkg, torch, dev, st, max(2, min(args.steps, 5)))
+
+    dist_name = {"zipfmod": f"Zipf({args.zipf_s:g}) mod 256", "zipf": f"Zipf({args.zipf_s:g}) truncated to 256 ranks",
+                 "uniform": "uniform"}[args.dist]
     if rank == 0:
         out = {
-            "metric": "GiB/s Shannon-Fano encode+decode, 64 MiB blocks, 1/2/4/8 GPUs; bit-exact",
+            "metric": METRIC,
             "value": world * total_in * args.steps / GIB / elapsed,
             "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"cfg4 shard: {nb} x {args.block_mib} MiB {dist_name} blocks per GPU "
-                                   f"(-b {'M' if args.block_mib == 64 else args.block_mib}), Module C encode + "
-                                   f"Module D decode" + ("" if have_decode else " [decode unavailable: encode only]"),
+                                   f"(-b {'M' if args.block_mib == 64 else 'm' if args.block_mib == 8 else args.block_mib}), Module C encode + "
+                                   f"Module D decode" + ("" if have_decode else " [encode only]"),
                        "blocks_per_gpu": nb, "block_bytes": bs, "parallelism": f"blocks sharded over {world} GPU(s)",
                        "compressed_ratio": total_enc / total_in},
             "encode_GiBs": world * total_in / GIB / enc_t,
@@ -296,13 +471,16 @@ def main():
                                  "frac": dec_gbs / HBM_PEAK_GBS, "traffic": traffic["sf_decode"],
                                  "algorithmic_bytes_per_launch": alg} if have_decode else None),
         }
+        if comm.oversubscribed:
+            out["invalid"] = "oversubscribed: ranks share GPUs (plumbing test only)"
         if sg:
             out["scatter_gather"] = sg
+        if pipe:
+            out["pipeline"] = pipe
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, pkg, zt)
-        print(json.dumps(out))
-    if dist.is_initialized():
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
+    comm.close()
 
 
 if __name__ == "__main__":

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SHAFA_HIP_ABI_VERSION 2
+#define SHAFA_HIP_ABI_VERSION 3
 
 /* utils/errors.h:5-16 (_modules_error), same numbers */
 enum shafa_error {
@@ -61,6 +61,12 @@ int shafa_hip_device_count(void);            /* 0 when no GPU is visible; never 
 int shafa_hip_init(int device);              /* select device, create the library's stream/workspace */
 void shafa_hip_shutdown(void);
 const char *shafa_hip_last_error(void);      /* text of the last SHAFA_DEVICE_ERROR */
+
+/* Tuning knobs (no reference counterpart).  Unknown names return SHAFA_OUTSIDE_MODULE.
+ *   "sf_encode_one_pass_min_blocks": a shafa_hipd_sf_encode launch with at least this many blocks of <= 16-bit
+ *       codes takes the one-pass encoder, smaller launches the count/scan/pack kernels (default 32).
+ * shafa_hip_init() reads the environment variable SHAFA_SF_ENCODE_ONE_PASS_MIN_BLOCKS once for the same knob. */
+int shafa_hip_set_option(const char *name, long value);
 
 /* ------------------------------------------------------------------ layer 1: host buffers, one block */
 

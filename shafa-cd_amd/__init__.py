@@ -84,6 +84,8 @@ def lib():
     L.shafa_hip_device_count.restype = C.c_int
     L.shafa_hip_init.argtypes = [C.c_int]
     L.shafa_hip_last_error.restype = C.c_char_p
+    L.shafa_hip_set_option.argtypes = [C.c_char_p, C.c_long]
+    L.shafa_hip_set_option.restype = C.c_int
     L.shafa_hip_hist256.argtypes = [u8p, C.c_size_t, u64p]
     L.shafa_hip_rle_encode.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, szp, u64p]
     L.shafa_hip_sf_encode.argtypes = [u8p, C.c_size_t, tp, u8p, C.c_size_t, szp]
@@ -117,6 +119,11 @@ def lib():
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
+
+
+def set_option(name, value):
+    """Tuning knobs of the library (include/shafa_hip.h: shafa_hip_set_option)."""
+    _check(lib().shafa_hip_set_option(name.encode(), int(value)), "set_option " + name)
 
 
 def _check(rc, what=""):

@@ -21,11 +21,11 @@ int shafa_set_hip_error(hipError_t e, const char *what)
 // ------------------------------------------------------------------------------------------------
 // batch context
 // ------------------------------------------------------------------------------------------------
-int batch_reserve(Batch *b, size_t bytes)
+int batch_reserve(Batch *b, hipStream_t st, size_t bytes)
 {
     if (bytes <= b->ws_bytes) return SHAFA_SUCCESS;
     if (b->d_ws) {
-        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipStreamSynchronize(st));          // kernels of earlier launches on this batch's stream
         HIP_TRY(hipFree(b->d_ws));
         b->d_ws = nullptr;
         b->ws_bytes = 0;
@@ -36,27 +36,64 @@ int batch_reserve(Batch *b, size_t bytes)
     return SHAFA_SUCCESS;
 }
 
+static void seg_release(StageSeg &s, bool wait)
+{
+    if (s.ev) {
+        if (wait && s.sealed) (void)hipEventSynchronize(s.ev);
+        (void)hipEventDestroy(s.ev);
+        s.ev = nullptr;
+    }
+}
+
 void *batch_stage(Batch *b, hipStream_t st, size_t bytes)
 {
     bytes = (bytes + 63) & ~(size_t)63;
-    if (bytes > b->stage_bytes) {          // grow: wait for copies that still read the old arena
-        if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
-        if (hipDeviceSynchronize() != hipSuccess) return nullptr;
-        if (b->h_stage) hipHostFree(b->h_stage);
+    if (!b->segs) b->segs = new std::vector<StageSeg>();
+    std::vector<StageSeg> &segs = *b->segs;
+    // seal the previous region: its copies were enqueued by the caller after it was handed out
+    if (!segs.empty() && !segs.back().sealed) {
+        if (hipEventRecord(segs.back().ev, segs.back().st) != hipSuccess) return nullptr;
+        segs.back().sealed = true;
+    }
+    if (bytes > b->stage_bytes) {          // grow: wait for the copies that still read the old arena (their events only)
+        for (StageSeg &s : segs) seg_release(s, true);
+        segs.clear();
+        if (b->h_stage) (void)hipHostFree(b->h_stage);
         b->h_stage = nullptr;
         b->stage_bytes = 0;
-        const size_t want = 2 * bytes + (1 << 20);
+        const size_t want = 4 * bytes + (1 << 20);
         if (hipHostMalloc((void **)&b->h_stage, want, hipHostMallocDefault) != hipSuccess) return nullptr;
         b->stage_bytes = want;
         b->stage_used = 0;
     }
-    if (b->stage_used + bytes > b->stage_bytes) {
-        if (hipDeviceSynchronize() != hipSuccess) return nullptr;
-        b->stage_used = 0;
+    size_t off = b->stage_used;
+    if (off + bytes > b->stage_bytes) off = 0;                 // wrap
+    // regions that overlap the new one must have been consumed: wait for exactly their events
+    for (size_t i = 0; i < segs.size();) {
+        StageSeg &s = segs[i];
+        if (s.off < off + bytes && off < s.off + s.bytes) {
+            seg_release(s, true);
+            segs.erase(segs.begin() + (long)i);
+        } else ++i;
     }
-    void *p = b->h_stage + b->stage_used;
-    b->stage_used += bytes;
-    return p;
+    StageSeg seg = {off, bytes, st, nullptr, false};
+    if (hipEventCreateWithFlags(&seg.ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    segs.push_back(seg);
+    b->stage_used = off + bytes;
+    return b->h_stage + off;
+}
+
+void batch_stage_retire(Batch *b, hipStream_t st)
+{
+    if (!b->segs) return;
+    std::vector<StageSeg> &segs = *b->segs;
+    for (size_t i = 0; i < segs.size();) {
+        if (segs[i].st == st) {
+            seg_release(segs[i], false);
+            segs.erase(segs.begin() + (long)i);
+        } else ++i;
+    }
+    if (segs.empty()) b->stage_used = 0;
 }
 
 extern "C" {
@@ -71,6 +108,15 @@ int shafa_hip_device_count(void)
 }
 
 const char *shafa_hip_last_error(void) { return g_last_error; }
+
+int shafa_hip_set_option(const char *name, long value)
+{
+    if (name && !strcmp(name, "sf_encode_one_pass_min_blocks")) {
+        sfenc_configure(value < 1 ? 1 : (value > (1 << 30) ? (1 << 30) : (int)value));
+        return SHAFA_SUCCESS;
+    }
+    return SHAFA_OUTSIDE_MODULE;
+}
 
 int shafa_hipd_batch_create(int max_blocks, size_t max_block_bytes, shafa_hipd_batch **out)
 {
@@ -100,6 +146,10 @@ void shafa_hipd_batch_destroy(shafa_hipd_batch *hb)
     if (!b) return;
     hipDeviceSynchronize();
     if (b->d_ws) hipFree(b->d_ws);
+    if (b->segs) {
+        for (StageSeg &sg : *b->segs) seg_release(sg, false);
+        delete b->segs;
+    }
     if (b->h_stage) hipHostFree(b->h_stage);
     if (b->d_err) hipFree(b->d_err);
     if (b->d_par_hist) hipFree(b->d_par_hist);
@@ -160,7 +210,7 @@ int shafa_hipd_finish(shafa_hipd_batch *hb, void *stream, int nblocks, int *h_bl
         HIP_TRY(hipMemsetAsync(b->d_err, 0, (size_t)nblocks * sizeof(int), st));
     }
     HIP_TRY(hipStreamSynchronize(st));
-    b->stage_used = 0;
+    batch_stage_retire(b, st);
     int first = SHAFA_SUCCESS;
     for (int i = 0; i < nblocks; ++i) {
         const int e = b->h_hosterr[i] ? b->h_hosterr[i] : b->h_err[i];
@@ -214,6 +264,7 @@ int shafa_hip_init(int device)
     }
     if (device < 0 || device >= n) return SHAFA_OUTSIDE_MODULE;
     HIP_TRY(hipSetDevice(device));
+    if (const char *e = getenv("SHAFA_SF_ENCODE_ONE_PASS_MIN_BLOCKS")) shafa_hip_set_option("sf_encode_one_pass_min_blocks", atol(e));
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     shafa_hipd_batch *bh = nullptr;
     int rc = shafa_hipd_batch_create(1, (size_t)1 << 27, &bh);
@@ -238,7 +289,6 @@ void shafa_hip_shutdown(void)
 }
 
 static int lazy_init(void) { return g.ready ? SHAFA_SUCCESS : shafa_hip_init(0); }
-int shafa_hip_lazy_init(void) { return lazy_init(); }     /* layer 3 (pipe.hip) */
 
 static int upload(const uint8_t *in, size_t n)
 {
@@ -337,3 +387,5 @@ int shafa_hip_rle_decode(const uint8_t *in, size_t in_n, uint8_t *out, size_t ou
 }
 
 }  // extern "C"
+
+int api_lazy_init() { return lazy_init(); }     // layer 3 (pipe.hip)

@@ -68,6 +68,19 @@ __device__ __forceinline__ T wave_reduce_add(T v)
 
 __device__ __forceinline__ u32 bswap32(u32 x) { return __builtin_bswap32(x); }
 
+// inclusive add-scan over the 64 lanes of a wave with DPP: four row_shr steps inside the 16-lane rows, then the row
+// totals are broadcast into the following rows (row_bcast:15 -> rows 1,3; row_bcast:31 -> rows 2,3)
+__device__ __forceinline__ u32 dpp_scan_add(u32 v)
+{
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
 // (hi:lo) >> sh, low 32 bits; sh in [0,31]
 __device__ __forceinline__ u32 funnel_r(u32 hi, u32 lo, u32 sh)
 {
@@ -115,6 +128,33 @@ __device__ __forceinline__ void gstore<uint4>(void *p, uint4 v)
     u32x4_t x;
     x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w;
     *(GLOBAL_AS u32x4_t *)(unsigned long long)p = x;
+#else
+    *(uint4 *)p = v;
+#endif
+}
+
+// streaming (non-temporal) forms for data that is touched once: the input symbols and the encoded output
+template <typename T>
+__device__ __forceinline__ T gload_nt(const void *p);
+template <>
+__device__ __forceinline__ uint4 gload_nt<uint4>(const void *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32x4_t v = __builtin_nontemporal_load((const GLOBAL_AS u32x4_t *)(unsigned long long)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *(const uint4 *)p;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void gstore_nt(void *p, T v);
+template <>
+__device__ __forceinline__ void gstore_nt<uint4>(void *p, uint4 v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32x4_t x;
+    x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w;
+    __builtin_nontemporal_store(x, (GLOBAL_AS u32x4_t *)(unsigned long long)p);
 #else
     *(uint4 *)p = v;
 #endif

@@ -6,15 +6,25 @@
 #include <string.h>
 #include <vector>
 
+// one region of the pinned staging ring: [off, off + bytes), read by copies enqueued on `st`; `ev` is recorded on
+// `st` when the next region is handed out (or at finish), i.e. after those copies
+struct StageSeg {
+    size_t off, bytes;
+    hipStream_t st;
+    hipEvent_t ev;
+    bool sealed;
+};
+
 // Reusable per-batch context behind the opaque shafa_hipd_batch handle.
 struct Batch {
     int max_blocks;
     size_t max_block_bytes;
     void *d_ws;            // device workspace (grow-only; grown outside timed regions by warm-up calls)
     size_t ws_bytes;
-    u8 *h_stage;           // pinned host staging for parameter blocks / tables (bump allocated,
-    size_t stage_bytes;    //   reset by shafa_hipd_finish, which synchronises the stream)
-    size_t stage_used;
+    u8 *h_stage;           // pinned host staging ring for parameter blocks / tables: every region handed out is
+    size_t stage_bytes;    //   fenced by an event recorded on the stream that copies from it; a region is reused only
+    size_t stage_used;     //   after ITS event (no device-wide synchronisation on the enqueue path)
+    std::vector<StageSeg> *segs;
     void *d_par_hist;      // max_blocks * 32 B of hist256 parameters (separate from d_ws: hist256 may
                            //   run right after another op that still owns the workspace)
     int *d_err;            // one error code per block (first error wins)
@@ -22,10 +32,12 @@ struct Batch {
     int *h_hosterr;        // errors found on the host while preparing a launch (malformed tables)
 };
 
-// make sure the device workspace holds `bytes`
-int batch_reserve(Batch *b, size_t bytes);
-// bump-allocate `bytes` of pinned staging (synchronises `st` and rewinds when the arena is full)
+// make sure the device workspace holds `bytes` (growing waits for `st`, the only stream that uses this batch's workspace)
+int batch_reserve(Batch *b, hipStream_t st, size_t bytes);
+// hand out `bytes` of the pinned staging ring for copies that the caller enqueues on `st`
 void *batch_stage(Batch *b, hipStream_t st, size_t bytes);
+// every copy enqueued on `st` so far has completed (the caller synchronised `st`): release its regions
+void batch_stage_retire(Batch *b, hipStream_t st);
 
 // ---- per-op parameter records (device arrays) --------------------------------------------------
 struct EncBlk {
@@ -58,4 +70,5 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
                   u64 *d_freq);
 int rledec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                   const u64 *h_in_n, u8 *d_out, const u64 *h_out_off, const u64 *h_out_cap, u64 *d_out_n);
+void sfenc_configure(int sfe4_min_blocks);
 int gen_launch(hipStream_t st, u64 seed, u64 first, const u8 *d_map, u8 *d_out, size_t n);

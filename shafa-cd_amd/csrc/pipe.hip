@@ -13,7 +13,7 @@
 #include <stdlib.h>
 
 int shafa_set_hip_error(hipError_t e, const char *what);
-extern "C" int shafa_hip_lazy_init(void);
+int api_lazy_init();      // api.hip: shafa_hip_init(0) unless a device was selected already
 
 namespace {
 
@@ -134,7 +134,7 @@ extern "C" {
 int shafa_pipe_create(int n_slots, shafa_pipe **out)
 {
     if (!out || n_slots <= 0 || n_slots > 64) return SHAFA_OUTSIDE_MODULE;
-    int rc = shafa_hip_lazy_init();
+    int rc = api_lazy_init();
     if (rc) return rc;
     shafa_pipe *p = (shafa_pipe *)calloc(1, sizeof(shafa_pipe));
     if (!p) return SHAFA_LACK_OF_MEMORY;

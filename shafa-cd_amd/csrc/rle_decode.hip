@@ -295,7 +295,7 @@ int rledec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
     const size_t o_tick = off; off += (size_t)nblocks * 4; off = (off + 15) & ~(size_t)15;
     const size_t o_zero_end = off;
     const size_t o_blk = off; off += (size_t)nblocks * sizeof(RldBlk);
-    int rc = batch_reserve(bt, off);
+    int rc = batch_reserve(bt, st, off);
     if (rc) return rc;
     u8 *ws = (u8 *)bt->d_ws;
     RldBlk *hb = (RldBlk *)batch_stage(bt, st, (size_t)nblocks * sizeof(RldBlk));

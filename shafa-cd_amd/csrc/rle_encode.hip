@@ -780,7 +780,7 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
     const size_t o_tsum = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;     // three-pass path
     const size_t o_R = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;
     const size_t o_T = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;
-    int rc = batch_reserve(bt, off);
+    int rc = batch_reserve(bt, st, off);
     if (rc) return rc;
     u8 *ws = (u8 *)bt->d_ws;
     RleBlk *hb = (RleBlk *)batch_stage(bt, st, (size_t)nblocks * sizeof(RleBlk));

@@ -1608,7 +1608,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const size_t o_fsm4 = off; off += need_tabs ? (size_t)nblocks * 16384 : 0;
     const size_t o_fsm1 = off; off += need_tabs ? (size_t)nblocks * 2048 : 0;
     const size_t o_cfn = off; off += packed ? (size_t)total_tiles * DEC_THREADS * 8 : (size_t)total_tiles * R * DEC_THREADS;
-    int rc = batch_reserve(bt, off);
+    int rc = batch_reserve(bt, st, off);
     if (rc) return rc;
     u8 *ws = (u8 *)bt->d_ws;
 

@@ -1,20 +1,14 @@
-// sf_encode.hip — Module C hot path: Shannon-Fano bit-pack encode on gfx950.
+// sf_encode.hip — Module C hot path: Shannon-Fano bit-pack encode on gfx950, host launcher + the generic kernel.
 //
 // Replaces compress_to_buffer + binary_coding (reference c.c:52-237): the block's code bit-strings
-// concatenated MSB-first, zero padded to a byte.  One launch handles many independent blocks.
-//
-// Design (single pass over the input, HBM-bound, no MFMA):
-//   * a workgroup takes one tile (8-16 KiB of symbols) of one block, in ticket order per block, so a
-//     tile's predecessors have always started (deadlock-free for any dispatch order);
-//   * every lane loads 16 contiguous symbols per item with one coalesced 16-byte load, looks their
-//     {code,len} up in an LDS table, and concatenates them into G-symbol groups of <= 64 bits;
-//   * item bit totals are scanned wave -> workgroup; the tile total is chained across tiles with a
-//     decoupled look-back on one 64-bit {status,value} word per tile (relaxed agent-scope atomics);
-//   * groups are OR-ed into a zeroed LDS bit-stream at tile-local bit offsets, then the stream is
-//     funnel-shifted by (global bit offset mod 32) and stored as whole words, coalesced.  A tile owns
-//     every output word that BEGINS inside it; the few leading bits of its first word that belong to
-//     the previous tile are re-encoded from the input (<= 31 bits), so no output word is written
-//     twice, there are no global atomics and no pre-zeroing of the output.
+// concatenated MSB-first, zero padded to a byte.  One launch handles many independent blocks; blocks are
+// classified by their longest code:
+//   class 1, Lmax <= 16 (every Shannon-Fano table of a real 64 MiB block with a flat enough histogram):
+//            sf_encode4.hip (one pass, chained scan; launches with >= SFE4_MIN_BLOCKS blocks) or
+//            sf_encode3.hip (count / scan / pack; few blocks per launch, where a chain would be too long);
+//   class 2, Lmax <= 32: sf_encode3.hip with 64-bit table entries;
+//   class 3, Lmax <= 255 (hand-made / foreign .cod tables): sf_encode_generic below, one symbol per lane and step,
+//            tiles chained by a decoupled look-back on one 64-bit {status,value} word per tile.
 //
 // Algorithmic HBM bytes per block: n read + ceil(sum(freq*len)/8) written.
 #include "common.hpp"
@@ -44,22 +38,7 @@ __device__ __forceinline__ void emit_group(u32 *stage, u32 wlo, u32 wcount, u64 
 }
 
 // ------------------------------------------------------------------------------------------------
-// table entry formats
-// ------------------------------------------------------------------------------------------------
-template <int G> struct Ent;
-template <> struct Ent<4> {                       // Lmax <= 16: code | len << 16
-    typedef u32 type;
-    static __device__ __forceinline__ u32 len(u32 e) { return (e >> 16) & 31u; }   // bit 31 = symbol absent
-    static __device__ __forceinline__ u32 code(u32 e) { return e & 0xFFFFu; }
-};
-template <> struct Ent<2> {                       // Lmax <= 32: code | len << 32
-    typedef u64 type;
-    static __device__ __forceinline__ u32 len(u64 e) { return (u32)(e >> 32); }
-    static __device__ __forceinline__ u32 code(u64 e) { return (u32)e; }
-};
-
-// ------------------------------------------------------------------------------------------------
-// shared tail of both kernels: chain the tile total, compute the lead bits, run the rounds.
+// tail of the generic kernel: chain the tile total, compute the lead bits, run the rounds.
 // EmitFn(stage, wlo, wcount) ORs this thread's bits of the window into the stage.
 // LeadFn(need) returns the last `need` bits (1..31) of the stream that precedes the tile.
 // ------------------------------------------------------------------------------------------------
@@ -71,11 +50,9 @@ struct EncShared {
     u64 prefix;
 };
 
-// dbg bits (timing experiments only, output is wrong when set; SHAFA_ENC_DBG env var):
-// 1 = no ticket, 2 = no look-back, 4 = no emission, 8 = no copy-out
 template <typename EmitFn, typename LeadFn>
 __device__ __forceinline__ void encode_tail(EncShared &sh, const EncBlk &blk, u64 *desc, int k,
-                                            u32 tile_bits, EmitFn emit, LeadFn lead_bits, u32 dbg = 0)
+                                            u32 tile_bits, EmitFn emit, LeadFn lead_bits)
 {
     const int tid = threadIdx.x;
     u64 *bdesc = desc + blk.desc_base;
@@ -83,11 +60,10 @@ __device__ __forceinline__ void encode_tail(EncShared &sh, const EncBlk &blk, u6
 
     if (wave_id() == 0) {
         u64 B = 0;
-        if (k > 0 && !(dbg & 2)) {
+        if (k > 0) {
             if (tid == 0) desc_store(bdesc + k, DESC_AGG, tile_bits);
             B = lookback_sum(bdesc, k, blk.err);
         }
-        if (dbg & 2) B = (u64)k * 87001ull;
         if (tid == 0) {
             desc_store(bdesc + k, DESC_PREFIX, B + tile_bits);
             sh.prefix = B;
@@ -119,10 +95,9 @@ __device__ __forceinline__ void encode_tail(EncShared &sh, const EncBlk &blk, u6
             if (tid == 0) sh.stage[0] = carry;
             __syncthreads();
         }
-        if (!(dbg & 4)) emit(sh.stage + 1, r0, (u32)ENC_STAGE_WORDS);
+        emit(sh.stage + 1, r0, (u32)ENC_STAGE_WORDS);
         __syncthreads();
         u32 jend = (OW < r0 + ENC_STAGE_WORDS) ? OW : r0 + ENC_STAGE_WORDS;
-        if (dbg & 8) jend = 0;
         for (u32 j = r0 + tid; j < jend; j += ENC_THREADS) {
             const u32 li = j - r0;
             const u32 w = funnel_r(sh.stage[li], sh.stage[li + 1], s);
@@ -138,127 +113,6 @@ __device__ __forceinline__ void encode_tail(EncShared &sh, const EncBlk &blk, u6
         }
     }
     if (last && tid == 0) *blk.out_n = total_bytes;
-}
-
-// ------------------------------------------------------------------------------------------------
-// fast kernel: Lmax <= 16 (G = 4, 16 KiB tiles) or Lmax <= 32 (G = 2, 8 KiB tiles)
-// ------------------------------------------------------------------------------------------------
-template <int G, int OCC>
-__global__ __launch_bounds__(ENC_THREADS, OCC) void sf_encode_fast(const EncBlk *__restrict__ blks, int nblk,
-                                                              u64 *desc, u32 *tickets, u32 dbg)
-{
-    typedef typename Ent<G>::type ent_t;
-    constexpr int ITEMS = G;                 // 16-byte items per thread
-    constexpr int NGRP = 16 / G;             // groups per item
-    constexpr int TILE = ENC_THREADS * 16 * ITEMS;
-
-    __shared__ __attribute__((aligned(16))) EncShared sh;
-    __shared__ __attribute__((aligned(16))) ent_t lut[256];
-
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x % nblk;
-    const EncBlk blk = blks[b];
-    if ((u32)(blockIdx.x / nblk) >= blk.n_tiles) return;
-
-    if (tid == 0) sh.tile = (dbg & 1) ? (u32)(blockIdx.x / nblk) : atomicAdd(tickets + blk.ticket, 1u);
-    lut[tid] = ((const ent_t *)blk.lut)[tid];
-    __syncthreads();
-    const int k = (int)sh.tile;
-    const u64 tile_start = (u64)k * TILE;
-
-    // ---- load + look up + group -----------------------------------------------------------------
-    u64 grp[ITEMS][NGRP];
-    u32 glen[ITEMS][NGRP];
-    u32 itot[ITEMS];
-    bool bad = false;
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        const u64 idx = tile_start + (u64)it * (ENC_THREADS * 16) + (u64)tid * 16;
-        u32 wds[4] = {0, 0, 0, 0};
-        int nvalid = 0;
-        if (idx + 16 <= blk.n) {
-            const uint4 v = *(const uint4 *)(blk.in + idx);
-            wds[0] = v.x; wds[1] = v.y; wds[2] = v.z; wds[3] = v.w;
-            nvalid = 16;
-        } else if (idx < blk.n) {
-            nvalid = (int)(blk.n - idx);
-#pragma unroll
-            for (int q = 0; q < 16; ++q)     // static indices: keeps wds[] in registers
-                if (q < nvalid) wds[q >> 2] |= (u32)blk.in[idx + q] << (8 * (q & 3));
-        }
-        ent_t e[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const u32 sym = (wds[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            ent_t x = lut[sym];
-            if (j >= nvalid) x = 0;
-            else if (Ent<G>::len(x) == 0) bad = true;
-            e[j] = x;
-        }
-        u32 tot = 0;
-#pragma unroll
-        for (int g = 0; g < NGRP; ++g) {
-            u64 acc = 0;
-            u32 L = 0;
-#pragma unroll
-            for (int j = 0; j < G; ++j) {
-                const ent_t x = e[g * G + j];
-                const u32 l = Ent<G>::len(x);
-                acc = (acc << l) | Ent<G>::code(x);
-                L += l;
-            }
-            grp[it][g] = acc;
-            glen[it][g] = L;
-            tot += L;
-        }
-        itot[it] = tot;
-    }
-    if (bad) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
-
-    // ---- scan item totals: wave scan, then 16 wave totals through LDS ---------------------------
-    u32 incl[ITEMS];
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) incl[it] = wave_incl_scan_add<u32>(itot[it]);
-    if (lane_id() == 63) {
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) sh.wtot[it * 4 + wave_id()] = incl[it];
-    }
-    __syncthreads();
-    u32 ioff[ITEMS];
-    u32 run = 0;
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            if (w == wave_id()) ioff[it] = run + incl[it] - itot[it];
-            run += sh.wtot[it * 4 + w];
-        }
-    }
-    const u32 tile_bits = run;
-
-    auto emit = [&](u32 *stage, u32 wlo, u32 wcount) {
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) {
-            u32 q = ioff[it];
-#pragma unroll
-            for (int g = 0; g < NGRP; ++g) {
-                emit_group(stage, wlo, wcount, grp[it][g], glen[it][g], q);
-                q += glen[it][g];
-            }
-        }
-    };
-    auto lead = [&](u32 need) -> u32 {   // last `need` bits of the stream before this tile
-        u64 acc = 0;
-        u32 got = 0;
-        for (u64 p = tile_start; p > 0 && got < need;) {
-            --p;
-            const ent_t x = lut[blk.in[p]];
-            acc |= (u64)Ent<G>::code(x) << got;
-            got += Ent<G>::len(x);
-        }
-        return (u32)acc & ((1u << need) - 1u);
-    };
-    encode_tail(sh, blk, desc, k, tile_bits, emit, lead, dbg);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -351,9 +205,20 @@ __global__ __launch_bounds__(ENC_THREADS) void sf_encode_generic(const EncBlk *_
 // ------------------------------------------------------------------------------------------------
 // host launcher
 // ------------------------------------------------------------------------------------------------
-void sfenc2_launch(hipStream_t st, const EncBlk *dblk, int count, u32 total_tiles, u64 *ddesc, u32 *dtick);
 void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 *d_tile_bits, u64 *d_tile_off, bool lut64);
-void sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u64 *d_desc, u32 *d_tickets);
+int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax);
+
+// A launch with at least this many class-1 blocks takes the one-pass encoder: every block is its own chain, and
+// with this many chains a tile's look-back stays within a few 64-entry windows (sf_encode4.hip).
+static int g_sfe4_min_blocks = 32;
+void sfenc_configure(int sfe4_min_blocks) { g_sfe4_min_blocks = sfe4_min_blocks; }
+
+static u32 code_value(const shafa_code_table &t, int s)
+{
+    u32 code = 0;
+    for (int q = 0; q < t.len[s]; ++q) code = (code << 1) | ((t.bits[s][q >> 3] >> (7 - (q & 7))) & 1u);
+    return code;
+}
 
 int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                  const u64 *h_in_n, const shafa_code_table *h_tables, u8 *d_out, const u64 *h_out_off,
@@ -362,44 +227,47 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     if (nblocks <= 0) return SHAFA_SUCCESS;
     if (nblocks > bt->max_blocks) return SHAFA_LACK_OF_MEMORY;
 
-    // classify blocks: 0 = nothing to launch (empty table or empty block), 1 = G4, 2 = G2, 3 = generic
+    // classify blocks: 0 = nothing to launch (empty table or empty block), 1 = Lmax <= 16, 2 = Lmax <= 32, 3 = generic
     int cls_count[4] = {0, 0, 0, 0};
     std::vector<int> cls(nblocks);
-    u64 total_tiles[4] = {0, 0, 0, 0};
-    u32 max_tiles[4] = {0, 0, 0, 0};
-    const char *v_env0 = getenv("SHAFA_ENC_V");
-    const int enc_v = v_env0 ? atoi(v_env0) : 3;           // 1 = one tile per workgroup, 2 = persistent, 3 = three kernels
-    const bool use_v1 = enc_v == 1;
-    const u64 tile_syms[4] = {1, enc_v == 1 ? 256u * 16 * 4 : 256u * 16 * 2, 256 * 16 * 2, GEN_TILE};
+    u32 lmax1 = 0;
     for (int b = 0; b < nblocks; ++b) {
         if ((h_in_off[b] & 15) || (h_out_off[b] & 15)) return SHAFA_OUTSIDE_MODULE;
-        const u64 n = h_in_n[b];
         int lmax = 0;
         for (int s = 0; s < 256; ++s) lmax = h_tables[b].len[s] > lmax ? h_tables[b].len[s] : lmax;
-        int c = (lmax == 0 || n == 0) ? 0 : (lmax <= 16 ? 1 : (lmax <= 32 ? 2 : 3));
+        const int c = (lmax == 0 || h_in_n[b] == 0) ? 0 : (lmax <= 16 ? 1 : (lmax <= 32 ? 2 : 3));
         cls[b] = c;
         cls_count[c]++;
-        if (c) {
-            const u64 t = ceil_div_u64(n, tile_syms[c]);
-            total_tiles[c] += t;
-            if (t > max_tiles[c]) max_tiles[c] = (u32)t;
-        }
+        if (c == 1 && (u32)lmax > lmax1) lmax1 = (u32)lmax;
+    }
+    const bool one_pass = cls_count[1] >= g_sfe4_min_blocks;
+    const u64 tile_syms[4] = {1, 256 * 16 * 2, 256 * 16 * 2, GEN_TILE};
+    u64 total_tiles[4] = {0, 0, 0, 0};
+    u32 max_tiles[4] = {0, 0, 0, 0};
+    for (int b = 0; b < nblocks; ++b) {
+        const int c = cls[b];
+        if (!c) continue;
+        const u64 t = ceil_div_u64(h_in_n[b], tile_syms[c]);
+        total_tiles[c] += t;
+        if (t > max_tiles[c]) max_tiles[c] = (u32)t;
     }
     const u64 ndesc = total_tiles[1] + total_tiles[2] + total_tiles[3];
+    if (ndesc >= 0xFFFFFFFFull) return SHAFA_LACK_OF_MEMORY;
 
-    // device workspace: [desc u64 * ndesc][tickets u32 * nblocks][EncBlk * nblocks][tables]
+    // device workspace: [desc u64 * ndesc][tickets u32 * nblocks] (zeroed) [tile bits u32 * ndesc][EncBlk * nblocks][tables]
+    const size_t tab1 = one_pass ? 2048 : 1024;
     size_t off = 0;
     const size_t o_desc = off; off += ndesc * 8;
     const size_t o_tick = off; off += (size_t)nblocks * 4; off = (off + 15) & ~(size_t)15;
     const size_t o_zero_end = off;
-    const size_t o_tbits = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;      // v3: tile bit totals
+    const size_t o_tbits = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;
     const size_t o_blk = off; off += (size_t)nblocks * sizeof(EncBlk); off = (off + 15) & ~(size_t)15;
     const size_t o_tab = off;
     size_t tab_bytes = 0;
     for (int b = 0; b < nblocks; ++b)
-        tab_bytes += cls[b] == 1 ? 1024 : cls[b] == 2 ? 2048 : cls[b] == 3 ? ((sizeof(shafa_code_table) + 15) & ~15ul) : 0;
+        tab_bytes += cls[b] == 1 ? tab1 : cls[b] == 2 ? 2048 : cls[b] == 3 ? ((sizeof(shafa_code_table) + 15) & ~15ul) : 0;
     off += tab_bytes;
-    int rc = batch_reserve(bt, off);
+    int rc = batch_reserve(bt, st, off);
     if (rc) return rc;
     u8 *ws = (u8 *)bt->d_ws;
 
@@ -429,24 +297,21 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
             e.desc_base = dbase;
             e.n_tiles = (u32)ceil_div_u64(n, tile_syms[c]);
             e.ticket = (u32)pos;
+            e.pad = 0;
             dbase += e.n_tiles;
             e.lut = ws + o_tab + tpos;
             const shafa_code_table &t = h_tables[b];
-            if (c == 1) {
-                u32 *l = (u32 *)(htab + tpos);
-                for (int s = 0; s < 256; ++s) {
-                    u32 code = 0;
-                    for (int q = 0; q < t.len[s]; ++q) code = (code << 1) | ((t.bits[s][q >> 3] >> (7 - (q & 7))) & 1u);
-                    l[s] = t.len[s] ? (code | ((u32)t.len[s] << 16)) : 0x80000000u;
-                }
-                tpos += 1024;
-            } else if (c == 2) {
+            if (c == 1 && one_pass) {                 // {code, len}; a symbol without a code: len = 1 << 16
                 u64 *l = (u64 *)(htab + tpos);
-                for (int s = 0; s < 256; ++s) {
-                    u64 code = 0;
-                    for (int q = 0; q < t.len[s]; ++q) code = (code << 1) | ((t.bits[s][q >> 3] >> (7 - (q & 7))) & 1u);
-                    l[s] = code | ((u64)t.len[s] << 32);
-                }
+                for (int s = 0; s < 256; ++s) l[s] = t.len[s] ? ((u64)code_value(t, s) | ((u64)t.len[s] << 32)) : (1ull << 48);
+                tpos += 2048;
+            } else if (c == 1) {                      // code | len << 16; bit 31: no code
+                u32 *l = (u32 *)(htab + tpos);
+                for (int s = 0; s < 256; ++s) l[s] = t.len[s] ? (code_value(t, s) | ((u32)t.len[s] << 16)) : 0x80000000u;
+                tpos += 1024;
+            } else if (c == 2) {                      // code | len << 32
+                u64 *l = (u64 *)(htab + tpos);
+                for (int s = 0; s < 256; ++s) l[s] = (u64)code_value(t, s) | ((u64)t.len[s] << 32);
                 tpos += 2048;
             } else {
                 memcpy(htab + tpos, &t, sizeof(t));
@@ -455,37 +320,21 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
             ++pos;
         }
     }
-    const bool need_desc = cls_count[2] || cls_count[3] || (cls_count[1] && enc_v != 3);
+    const bool need_desc = cls_count[3] || (cls_count[1] && one_pass);
     if (o_zero_end && need_desc) HIP_TRY(hipMemsetAsync(ws, 0, o_zero_end, st));
     HIP_TRY(hipMemcpyAsync(ws + o_blk, hs, stage_bytes, hipMemcpyHostToDevice, st));
     for (int b = 0; b < nblocks; ++b)
         if (cls[b] == 0) HIP_TRY(hipMemsetAsync(d_out_n + b, 0, 8, st));
 
-    const char *dbg_env = getenv("SHAFA_ENC_DBG");
-    const u32 dbg = dbg_env ? (u32)atoi(dbg_env) : 0u;
     const EncBlk *dblk = (const EncBlk *)(ws + o_blk);
     u64 *ddesc = (u64 *)(ws + o_desc);
     u32 *dtick = (u32 *)(ws + o_tick);
-    const char *occ_env = getenv("SHAFA_ENC_OCC");
-    const int occ = occ_env ? atoi(occ_env) : 1;
-#define LAUNCH_FAST(G, C)                                                                                     \
-    do {                                                                                                      \
-        const dim3 grid(max_tiles[C] * cls_count[C]);                                                         \
-        if (occ >= 6) hipLaunchKernelGGL((sf_encode_fast<G, 6>), grid, dim3(ENC_THREADS), 0, st, dblk + cls_first[C], cls_count[C], ddesc, dtick, dbg); \
-        else if (occ == 5) hipLaunchKernelGGL((sf_encode_fast<G, 5>), grid, dim3(ENC_THREADS), 0, st, dblk + cls_first[C], cls_count[C], ddesc, dtick, dbg); \
-        else if (occ == 4) hipLaunchKernelGGL((sf_encode_fast<G, 4>), grid, dim3(ENC_THREADS), 0, st, dblk + cls_first[C], cls_count[C], ddesc, dtick, dbg); \
-        else hipLaunchKernelGGL((sf_encode_fast<G, 1>), grid, dim3(ENC_THREADS), 0, st, dblk + cls_first[C], cls_count[C], ddesc, dtick, dbg); \
-    } while (0)
     if (cls_count[1]) {
-        if (use_v1) LAUNCH_FAST(4, 1);
-        else if (enc_v == 4) sfenc4_launch(st, dblk + cls_first[1], cls_count[1], max_tiles[1], ddesc, dtick);
-        else if (enc_v == 2) sfenc2_launch(st, dblk + cls_first[1], cls_count[1], (u32)total_tiles[1], ddesc, dtick);
-        else sfenc3_launch(st, dblk + cls_first[1], cls_count[1], max_tiles[1], (u32 *)(ws + o_tbits), ddesc, false);
+        if (one_pass) {
+            if ((rc = sfenc4_launch(st, dblk + cls_first[1], cls_count[1], ddesc, dtick, lmax1))) return rc;
+        } else sfenc3_launch(st, dblk + cls_first[1], cls_count[1], max_tiles[1], (u32 *)(ws + o_tbits), ddesc, false);
     }
-    if (cls_count[2]) {
-        if (enc_v == 3) sfenc3_launch(st, dblk + cls_first[2], cls_count[2], max_tiles[2], (u32 *)(ws + o_tbits), ddesc, true);
-        else LAUNCH_FAST(2, 2);
-    }
+    if (cls_count[2]) sfenc3_launch(st, dblk + cls_first[2], cls_count[2], max_tiles[2], (u32 *)(ws + o_tbits), ddesc, true);
     if (cls_count[3])
         hipLaunchKernelGGL(sf_encode_generic, dim3(max_tiles[3] * cls_count[3]), dim3(ENC_THREADS), 0, st,
                            dblk + cls_first[3], cls_count[3], ddesc, dtick);

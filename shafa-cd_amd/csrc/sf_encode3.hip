@@ -1,9 +1,8 @@
-// sf_encode3.hip — Shannon-Fano bit-pack encoder for codes <= 16 bits as three dependency-free kernels.
+// sf_encode3.hip — Shannon-Fano bit-pack encoder for codes <= 32 bits as three dependency-free kernels (the path for
+// launches with few blocks and for 17..32-bit codes; launches with many blocks of <= 16-bit codes: sf_encode4.hip).
 //
-// Same output as sf_encode_fast<4> (sf_encode.hip).  The single-pass chained-scan versions spend
-// most of their time waiting (ticket -> load -> look-back chain per workgroup, or a serial resolve
-// step per tile at 4 waves/SIMD); a calibration kernel that only loads, looks up and groups runs at
-// 4.5-5.3 TB/s of input on the same data (tools/microbench.py).  So the prefix problem is split off:
+// With few blocks per launch a chained scan has too few independent chains to hide its look-backs, so the prefix
+// problem is split off into its own kernels:
 //
 //   sfe3_count : per tile, sum of code lengths                    (reads n; byte LUT, no grouping)
 //   sfe3_scan  : per block, exclusive scan of the tile totals     (4096 tiles per 64 MiB block)
@@ -24,17 +23,6 @@ constexpr int E3_THREADS = 256;
 constexpr int E3_ITEMS = 2;                            // 16-byte items per lane and tile
 constexpr int E3_TILE = E3_THREADS * 16 * E3_ITEMS;    // 8 KiB of symbols
 constexpr int E3_SW64 = 1280;                          // LDS bit-stream window: 10 KiB; tiles that expand more take two rounds
-
-__device__ __forceinline__ u32 dpp_scan(u32 v)
-{
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
-    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
-    return v;
-}
 
 // ------------------------------------------------------------------------------------------------
 // count: tile_bits[tile] = sum of code lengths; grid = (tiles, blocks)
@@ -105,7 +93,7 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_count(const EncBlk *__restric
             }
         }
         absent |= tot >> 16;
-        const u32 s = dpp_scan(tot & 0xFFFFu);
+        const u32 s = dpp_scan_add(tot & 0xFFFFu);
         if (lane == 63) tile_bits[blk.desc_base + tile] = s;
 #pragma unroll
         for (int it = 0; it < CI; ++it) cur[it] = nxt[it];
@@ -152,8 +140,6 @@ struct Pack3Shared {
     u64 lut[256];                // LUT64: code | len << 32; else only the low halves are used: code | len << 16
     u32 wtot[4 * E3_ITEMS];
     u32 prev[16];
-    u64 prefix;                  // CHAINED: bits before the tile (from the look-back)
-    u32 tile;                    // CHAINED: ticket
 };
 
 __device__ __forceinline__ u64 bswap64(u64 x)
@@ -161,45 +147,24 @@ __device__ __forceinline__ u64 bswap64(u64 x)
     return ((u64)bswap32((u32)x) << 32) | bswap32((u32)(x >> 32));
 }
 
-// CHAINED = single pass: no count/scan kernels; the tile takes a ticket (tiles of a block start in order, so a
-// tile's predecessors are always running or done), publishes its bit total and gets the bits before it by a
-// decoupled look-back over the block's tile descriptors.  The input is read once (n + out bytes of traffic).
-template <bool CHAINED, bool LUT64>
-__global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict__ blks, int nblk,
-                                                        const u64 *__restrict__ tile_off, u64 *__restrict__ desc,
-                                                        u32 *__restrict__ tickets)
+template <bool LUT64>
+__global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict__ blks, const u64 *__restrict__ tile_off)
 {
     __shared__ __attribute__((aligned(16))) Pack3Shared sh;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);            // wave-uniform: keeps the wave selects scalar
-    const EncBlk blk = blks[CHAINED ? blockIdx.x % (u32)nblk : blockIdx.y];   // CHAINED: blocks interleaved over the grid
-    u32 tile = blockIdx.x;
+    const EncBlk blk = blks[blockIdx.y];
+    const u32 tile = blockIdx.x;
     uint4 cur[E3_ITEMS];
-    bool have = false;
-    if (CHAINED) {
-        // the ticket decides the tile, but workgroups are dispatched in order in practice: load the tile the
-        // dispatch order suggests while the ticket's round trip is in flight, reload in the rare other case
-        if (tid == 0) sh.tile = atomicAdd(tickets + blk.ticket, 1u);
-        const u32 guess = blockIdx.x / (u32)nblk;
-        if ((u64)(guess + 1) * E3_TILE <= blk.n) {
-#pragma unroll
-            for (int it = 0; it < E3_ITEMS; ++it)
-                cur[it] = gload<uint4>(blk.in + (u64)guess * E3_TILE + (u64)it * (E3_THREADS * 16) + (u64)tid * 16);
-        }
-        __syncthreads();
-        tile = sh.tile;
-        have = tile == guess && (u64)(guess + 1) * E3_TILE <= blk.n;
-    }
     if (tile >= blk.n_tiles) return;
     const u64 base = (u64)tile * E3_TILE;
     const bool full = base + E3_TILE <= blk.n;
 
     // everything this tile needs from memory is requested up front, nothing depends on anything else
-    u64 B = CHAINED ? 0ull : tile_off[blk.desc_base + tile];
+    const u64 B = tile_off[blk.desc_base + tile];
 #pragma unroll
     for (int it = 0; it < E3_ITEMS; ++it) {
         const u64 idx = base + (u64)it * (E3_THREADS * 16) + (u64)tid * 16;
-        if (have) continue;
         if (full) cur[it] = gload<uint4>(blk.in + idx);
         else {
             u32 w[4] = {0, 0, 0, 0};
@@ -291,7 +256,7 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
     }
     u32 incl[E3_ITEMS];
 #pragma unroll
-    for (int it = 0; it < E3_ITEMS; ++it) incl[it] = dpp_scan(itot[it]);
+    for (int it = 0; it < E3_ITEMS; ++it) incl[it] = dpp_scan_add(itot[it]);
     if (lane == 63) {
 #pragma unroll
         for (int it = 0; it < E3_ITEMS; ++it) sh.wtot[it * 4 + wv] = incl[it];
@@ -309,23 +274,6 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
     }
     const u32 T = run;                                 // tile bit total
     const bool last = (tile == blk.n_tiles - 1);
-    if (CHAINED) {
-        if (wv == 0) {
-            u64 *bdesc = desc + blk.desc_base;
-            u64 Bv = 0;
-            if (tile > 0) {
-                if (lane == 0) desc_store(bdesc + tile, DESC_AGG, T);
-                Bv = lookback_sum(bdesc, (int)tile, blk.err);
-            }
-            if (lane == 0) {
-                desc_store(bdesc + tile, DESC_PREFIX, Bv + T);
-                sh.prefix = Bv;
-                if (last) gstore<u64>(blk.out_n, (Bv + T + 7) >> 3);
-            }
-        }
-        __syncthreads();
-        B = sh.prefix;
-    }
     const u32 s = (u32)B & 63;                         // bit phase of the tile inside its first output u64
 #pragma unroll
     for (int it = 0; it < E3_ITEMS; ++it) ioff[it] += s;
@@ -419,14 +367,7 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
 
 }  // namespace
 
-// launched from sfenc_launch (sf_encode.hip) for the Lmax <= 16 class; ws3 = [tile_bits u32 * tiles][tile_off u64 * tiles]
-// single pass (SHAFA_ENC_V=4): desc/tickets zeroed by the caller
-void sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u64 *d_desc, u32 *d_tickets)
-{
-    hipLaunchKernelGGL((sfe3_pack<true, false>), dim3(max_tiles * (u32)count), dim3(E3_THREADS), 0, st, dblk, count,
-                       (const u64 *)nullptr, d_desc, d_tickets);
-}
-
+// launched from sfenc_launch (sf_encode.hip); d_tile_bits: u32 per tile, d_tile_off: u64 per tile;
 // lut64: the blocks' tables are 64-bit (codes of 17..32 bits somewhere in the launch)
 void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 *d_tile_bits, u64 *d_tile_off, bool lut64)
 {
@@ -434,10 +375,6 @@ void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles,
     if (lut64) hipLaunchKernelGGL(sfe3_count<true>, grid_c, dim3(E3_THREADS), 0, st, dblk, d_tile_bits);
     else hipLaunchKernelGGL(sfe3_count<false>, grid_c, dim3(E3_THREADS), 0, st, dblk, d_tile_bits);
     hipLaunchKernelGGL(sfe3_scan, dim3((u32)count), dim3(E3_THREADS), 0, st, dblk, (const u32 *)d_tile_bits, d_tile_off);
-    if (lut64)
-        hipLaunchKernelGGL((sfe3_pack<false, true>), grid, dim3(E3_THREADS), 0, st, dblk, count, (const u64 *)d_tile_off,
-                           (u64 *)nullptr, (u32 *)nullptr);
-    else
-        hipLaunchKernelGGL((sfe3_pack<false, false>), grid, dim3(E3_THREADS), 0, st, dblk, count, (const u64 *)d_tile_off,
-                           (u64 *)nullptr, (u32 *)nullptr);
+    if (lut64) hipLaunchKernelGGL(sfe3_pack<true>, grid, dim3(E3_THREADS), 0, st, dblk, (const u64 *)d_tile_off);
+    else hipLaunchKernelGGL(sfe3_pack<false>, grid, dim3(E3_THREADS), 0, st, dblk, (const u64 *)d_tile_off);
 }

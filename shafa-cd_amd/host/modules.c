@@ -183,12 +183,26 @@ static bool read_u64(text_t *t, uint64_t *v)
     return true;
 }
 
+/* bytes between the read position and the end of a regular file: a block size announced by a header can never
+ * exceed it (checked before a pinned buffer of that size is requested) */
+static uint64_t bytes_left(FILE *f)
+{
+    const long here = ftell(f);
+    if (here < 0 || fseek(f, 0, SEEK_END) != 0) return 0;
+    const long end = ftell(f);
+    if (fseek(f, here, SEEK_SET) != 0 || end < here) return 0;
+    return (uint64_t)(end - here);
+}
+
 /* "@<R|N>@<n>" (f.c:289,294; t.c:302) */
 static bool read_header(text_t *t, char *mode, uint64_t *n)
 {
     if (!eat(t, '@') || t->pos >= t->len) return false;
     *mode = t->buf[t->pos++];
-    return eat(t, '@') && read_u64(t, n);
+    if (!eat(t, '@') || !read_u64(t, n)) return false;
+    /* every block needs at least "@<digit>@" in the rest of the text: a count beyond that is a corrupt header
+     * (and would overflow the per-block size arrays the drivers allocate from it) */
+    return *n <= (uint64_t)(t->len - t->pos) / 3;
 }
 
 /* "@<size>@<payload up to the next '@'>" : payload is NUL-terminated in place, *next = char it replaced */
@@ -436,6 +450,7 @@ _modules_error shafa_compress(char **path)
             const int perr = shafa_cod_parse(codes, &tab);                       /* c.c:115-177 */
             t.buf[t.pos] = keep;
             const int slot = (int)(sub % depth);
+            if (size > bytes_left(in)) { err = SHAFA_FILE_STREAM_FAILED; break; }                     /* fread would come up short */
             uint8_t *buf = shafa_pipe_in(pipe, slot, size);
             if (!buf) { err = SHAFA_LACK_OF_MEMORY; break; }
             if (fread(buf, 1, size, in) != size) { err = SHAFA_FILE_STREAM_FAILED; break; }          /* c.c:392 */
@@ -537,6 +552,7 @@ _modules_error rle_decompress(char **path)
     while (!err && ret < n_blocks) {
         if (sub < n_blocks && sub - ret < depth) {
             const int slot = (int)(sub % depth);
+            if (sizes[sub] > bytes_left(in)) { err = SHAFA_FILE_STREAM_FAILED; break; }
             uint8_t *buf = shafa_pipe_in(pipe, slot, sizes[sub]);
             if (!buf) { err = SHAFA_LACK_OF_MEMORY; break; }
             if (fread(buf, 1, sizes[sub], in) != sizes[sub]) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* d.c:84 */
@@ -619,6 +635,7 @@ _modules_error shafa_decompress(char **path, bool decompress_rle)
             uint64_t sf_n = 0, n_sym = 0;
             if (!shaf_read_u64(in, '@', &sf_n, true)) { err = SHAFA_FILE_STREAM_FAILED; break; }     /* d.c:697 */
             const int slot = (int)(sub % depth);
+            if (sf_n > bytes_left(in)) { err = SHAFA_FILE_STREAM_FAILED; break; }
             uint8_t *payload = shafa_pipe_in(pipe, slot, sf_n);
             if (!payload) { err = SHAFA_LACK_OF_MEMORY; break; }
             if (fread(payload, 1, sf_n, in) != sf_n) { err = SHAFA_FILE_STREAM_FAILED; break; }       /* d.c:706 */

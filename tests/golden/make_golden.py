@@ -14,6 +14,7 @@ Every case directory gets a manifest.json:
 import hashlib
 import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -55,6 +56,26 @@ def zipf_table(s=1.2, nsym=256):
     table = np.zeros(65536, dtype=np.uint8)
     lo = 0
     for k in range(nsym):
+        table[lo:edges[k]] = k
+        lo = max(lo, edges[k])
+    return table
+
+
+def zipf_mod256_table(s=1.2):
+    """2^16-entry inverse CDF of "Zipf(s) over the positive integers, taken mod 256" (SURVEY.md §8(d) config 4):
+    P(byte b) = sum_j (b + 256 j)^-s / zeta(s).  Shannon-Fano output of such a 64 MiB block is 0.812 n."""
+    p = np.zeros(256, dtype=np.float64)
+    j = np.arange(0, 200000, dtype=np.float64)
+    for b in range(256):
+        k = (b if b else 256) + 256.0 * j
+        # tail of the series beyond the summed terms: integral of x^-s from the last term + 128
+        p[b] = np.sum(k ** (-s)) + (k[-1] + 128.0) ** (1.0 - s) / ((s - 1.0) * 256.0)
+    cdf = np.cumsum(p) / np.sum(p)
+    edges = np.minimum(np.floor(cdf * 65536.0 + 0.5).astype(np.int64), 65536)
+    edges[-1] = 65536
+    table = np.zeros(65536, dtype=np.uint8)
+    lo = 0
+    for k in range(256):
         table[lo:edges[k]] = k
         lo = max(lo, edges[k])
     return table
@@ -115,6 +136,17 @@ def textlike_stream(seed, n):
 
 
 # ---------------------------------------------------------------- running the reference
+BANNER_RE = re.compile(r"^[^\n]*,\s*a9\d{4},\s*MIEI/CD,[^\n]*\n", re.M)       # the authors' name lines (f.c:134-135 etc.)
+RUNTIME_RE = re.compile(r"^(Module runtime \((?:in )?milliseconds\): )[0-9.]+$", re.M)
+
+
+def mask_stdout(text):
+    """What is compared of a module's stdout summary (f.c:132-177, t.c:219-243, c.c:282-303, d.c:44-65):
+    everything except the two author-name lines each module prints first (dropped: our host does not
+    print them) and the measured runtime (replaced by <ms>)."""
+    return RUNTIME_RE.sub(r"\1<ms>", BANNER_RE.sub("", text))
+
+
 def sha(path):
     h = hashlib.sha256()
     with open(path, "rb") as f:
@@ -123,13 +155,36 @@ def sha(path):
     return h.hexdigest()
 
 
-def run_case(name, files_in, cmds, note="", store_inputs=True, expect_rc=None):
+def make_input(gen):
+    """Rebuild an input from its manifest entry {"kind": ..., "seed": ..., "n": ...} (used by the GPU tests
+    for inputs that are too large to store)."""
+    kind, n, seed = gen["kind"], gen["n"], gen.get("seed", 0)
+    if kind == "uniform":
+        return gen_bytes(seed, n)
+    if kind == "zipf":
+        return gen_bytes(seed, n, zipf_table(gen.get("s", 1.2)))
+    if kind == "zipfmod":
+        return gen_bytes(seed, n, zipf_mod256_table(gen.get("s", 1.2)))
+    if kind == "runs":
+        return runs_stream(seed, n, zipf_table(1.2))
+    if kind == "textlike":
+        return textlike_stream(seed, n)
+    if kind == "const":
+        return np.full(n, gen["byte"], dtype=np.uint8)
+    if kind == "alt01":
+        return (np.arange(n, dtype=np.uint32) & 1).astype(np.uint8)
+    raise ValueError(kind)
+
+
+def run_case(name, files_in, cmds, note="", store_inputs=True, expect_rc=None, generators=None):
     """files_in: {fname: bytes}; cmds: list of argv lists (without the binary), run in order in a
     scratch dir; files whose name starts with 'decoded__' are produced by copying after -m d."""
     out_dir = os.path.join(HERE, name)
     shutil.rmtree(out_dir, ignore_errors=True)
     os.makedirs(out_dir)
     man = {"note": note, "cmds": [], "files": {}, "inputs": sorted(files_in)}
+    if generators:
+        man["generators"] = generators
     with tempfile.TemporaryDirectory() as tmp:
         for fn, data in files_in.items():
             with open(os.path.join(tmp, fn), "wb") as f:
@@ -143,9 +198,10 @@ def run_case(name, files_in, cmds, note="", store_inputs=True, expect_rc=None):
                 os.remove(os.path.join(tmp, step[1]))
                 man["cmds"].append(step)
                 continue
-            r = subprocess.run([REF] + step, cwd=tmp, capture_output=True, timeout=300)
+            r = subprocess.run([REF] + step, cwd=tmp, capture_output=True, timeout=1800)
             man["cmds"].append({"argv": step, "rc": r.returncode,
-                                "stderr": r.stderr.decode("utf-8", "replace")})
+                                "stderr": r.stderr.decode("utf-8", "replace"),
+                                "stdout": mask_stdout(r.stdout.decode("utf-8", "replace"))})
         for fn in sorted(os.listdir(tmp)):
             p = os.path.join(tmp, fn)
             size = os.path.getsize(p)
@@ -254,6 +310,45 @@ def main():
         ["h.freq", "-m", "t"],
     ], note="Module T on hand-made histograms: single symbol (all codes empty), all ties, "
             "Fibonacci (deep tree), two symbols, geometric with a long tail of ones")
+
+    # 10. full-size blocks (hash-only; inputs are rebuilt on the GPU box from "generators"): SURVEY.md §4
+    MiB = 1 << 20
+
+    def big_case(name, fn, gen, cmds, note):
+        run_case(name, {fn: make_input(gen).tobytes()}, cmds, note=note, store_inputs=False, generators={fn: gen})
+
+    # cfg-1 shape: uniform bytes at -b m (8 MiB blocks), 2 blocks; F (RLE rejected) -> T -> C, then D
+    big_case("full_uniform_m", "u", {"kind": "uniform", "seed": 4201, "n": 16 * MiB}, [
+        ["u", "-b", "m"], ["__copy__", "u", "orig__u"], ["__rm__", "u"],
+        ["u.shaf"], ["__copy__", "u", "decoded__sf"],
+    ], "2 x 8 MiB uniform blocks, -b m: 8/9-bit codes")
+    # cfg-2/3 shape: 2 x 64 MiB Zipf blocks at -b M, full F -> T -> C -> D
+    big_case("full_zipf_M", "z", {"kind": "zipf", "seed": 4202, "n": 128 * MiB}, [
+        ["z", "-b", "M"], ["__copy__", "z", "orig__z"], ["__rm__", "z"],
+        ["z.shaf"], ["__copy__", "z", "decoded__sf"],
+    ], "2 x 64 MiB Zipf(1.2, 256 ranks) blocks, -b M")
+    # the surveyed cfg-4 stream (Zipf(1.2) mod 256), one 64 MiB block + a ragged 5 MiB + 77 B tail block, RLE forced
+    big_case("full_zipfmod_M_forced_rle", "y", {"kind": "zipfmod", "seed": 4203, "n": 69 * MiB + 77}, [
+        ["y", "-m", "f", "-c", "r", "-b", "M"], ["y.rle.freq", "-m", "t"], ["y.rle", "-m", "c"],
+        ["__copy__", "y", "orig__y"], ["__rm__", "y"],
+        ["y.rle.shaf"], ["__copy__", "y", "decoded__sf_rle"],
+    ], "64 MiB + ragged block of Zipf(1.2) mod 256, -c r forced RLE (expands), F -> T -> C -> D(SF+RLE)")
+    # one 64 MiB single-byte run: 263172 capped triples + remainder (f.c:38-52)
+    big_case("full_single_run_M", "r", {"kind": "const", "byte": 0x41, "n": 64 * MiB}, [
+        ["r", "-b", "M"], ["__copy__", "r", "orig__r"], ["__rm__", "r"],
+        ["r.rle.shaf"], ["__copy__", "r", "decoded__sf_rle"],
+    ], "64 MiB of 0x41: RLE gives 263172 {0,0x41,255} triples + {0,0x41,4}")
+    # 0/1 alternation: every zero becomes a triple, RLE output = 2n (the f.c:244 worst-case class), forced
+    big_case("full_alt01_M", "a", {"kind": "alt01", "n": 64 * MiB}, [
+        ["a", "-m", "f", "-c", "r", "-b", "M"], ["a.rle.freq", "-m", "t"], ["a.rle", "-m", "c"],
+        ["__copy__", "a", "orig__a"], ["__rm__", "a"],
+        ["a.rle.shaf"], ["__copy__", "a", "decoded__sf_rle"],
+    ], "64 MiB of 0,1,0,1,...: forced RLE doubles the block (128 MiB .rle)")
+    # long-tail text-like block: code lengths beyond 16 bits
+    big_case("full_longtail_M", "t", {"kind": "textlike", "seed": 4206, "n": 64 * MiB}, [
+        ["t", "-b", "M"], ["__copy__", "t", "orig__t"], ["__rm__", "t"],
+        ["t.shaf"], ["__copy__", "t", "decoded__sf"],
+    ], "64 MiB geometric symbol distribution with every byte present: Lmax 17-32")
 
     # 9. CLI behaviour samples (exit codes + stderr text)
     run_case("cli_errors", {"z": runs_stream(11, 5000, zt).tobytes()}, [

@@ -26,8 +26,25 @@ def test_library_exports_every_declared_symbol(shafa):
     L = ctypes.CDLL(shafa.LIB_PATH)
     missing = [s for s in syms if not hasattr(L, s)]
     assert not missing, f"declared in include/shafa_hip.h but not exported: {missing}"
-    assert L.shafa_hip_abi_version() == 2
+    assert L.shafa_hip_abi_version() == 3
     assert ctypes.sizeof(shafa.CodeTable) == 256 + 256 * 32
+
+
+def test_library_exports_nothing_but_the_declared_symbols(shafa):
+    """exported ⊆ declared: no experiment hooks or undeclared entry points in the product library (dynamic symbol
+    table of the .so; internal C++ helpers are allowed only with hidden/mangled names, i.e. not `shafa_*` C names)."""
+    import subprocess
+    declared = set(declared_symbols(os.path.join(ROOT, "include", "shafa_hip.h")))
+    out = subprocess.run(["nm", "-D", "--defined-only", shafa.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set()
+    for line in out.splitlines():
+        parts = line.split()
+        if len(parts) >= 3 and parts[1] in "TtWw" and parts[2].startswith("shafa_"):
+            exported.add(parts[2])
+    extra = sorted(exported - declared)
+    assert not extra, f"exported by libshafa_hip.so but not declared in include/shafa_hip.h: {extra}"
+    assert shafa.lib().shafa_hip_set_option(b"no_such_option", 1) == shafa.OUTSIDE_MODULE
+    assert shafa.lib().shafa_hip_set_option(b"sf_encode_one_pass_min_blocks", 32) == shafa.SUCCESS
 
 
 def test_no_gpu_is_reported_not_faked(shafa):

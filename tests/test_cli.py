@@ -81,32 +81,69 @@ def test_cli_module_t_alone_on_cpu(tmp_path):
 
 GPU_CASES = ["runs_default", "edges_forced_rle", "uniform_no_rle", "uniform_forced_both", "runs_force_freq",
              "textlike_m", "tiny_1024", "tiny_1023", "cli_errors", "cfg0_K_runs", "cfg0_K_uniform"]
+# full-size blocks (8 MiB / 64 MiB; inputs rebuilt from the manifest's generators, outputs pinned by SHA-256)
+FULL_CASES = ["full_uniform_m", "full_zipf_M", "full_zipfmod_M_forced_rle", "full_single_run_M", "full_alt01_M",
+              "full_longtail_M"]
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("case", GPU_CASES)
-def test_cli_replays_reference_session(case, tmp_path):
+def scratch_dir(tmp_path, case):
+    """Full-size cases write up to ~0.7 GiB: keep them in tmpfs when there is one."""
+    if case.startswith("full_") and os.path.isdir("/dev/shm"):
+        import tempfile
+        return tempfile.mkdtemp(prefix="shafa_" + case + "_", dir="/dev/shm")
+    return str(tmp_path)
+
+
+def replay(case, work):
+    """Replay the recorded reference session with our CLI: rc, stderr and the masked stdout summary of every
+    command, then every produced file (size + SHA-256)."""
+    import golden.make_golden as mg
     man = manifest(case)
     for fn in man["inputs"]:
         src = os.path.join(GOLD, case, fn)
+        dst = os.path.join(work, fn)
         if os.path.exists(src):
-            shutil.copyfile(src, tmp_path / fn)
-        else:                                           # big inputs are regenerated from their seed
-            import golden.make_golden as mg
-            zt = mg.zipf_table(1.2)
-            data = mg.runs_stream(7, 655360, zt) if case == "cfg0_K_runs" else mg.gen_bytes(8, 655360)
-            data.tofile(tmp_path / fn)
-            assert sha(tmp_path / fn) == man["files"][fn]["sha256"]
+            shutil.copyfile(src, dst)
+        else:                                           # big inputs are regenerated from their generator
+            if "generators" in man:
+                data = mg.make_input(man["generators"][fn])
+            else:
+                zt = mg.zipf_table(1.2)
+                data = mg.runs_stream(7, 655360, zt) if case == "cfg0_K_runs" else mg.gen_bytes(8, 655360)
+            data.tofile(dst)
+            assert sha(dst) == man["files"][fn]["sha256"], f"{case}: regenerated input {fn} differs"
     for cmd in man["cmds"]:
         if isinstance(cmd, list):
             if cmd[0] == "__copy__":
-                shutil.copyfile(tmp_path / cmd[1], tmp_path / cmd[2])
+                shutil.copyfile(os.path.join(work, cmd[1]), os.path.join(work, cmd[2]))
             elif cmd[0] == "__rm__":
-                os.remove(tmp_path / cmd[1])
+                os.remove(os.path.join(work, cmd[1]))
             continue
-        rc, err, out = run(cmd["argv"], tmp_path)
+        rc, err, out = run(cmd["argv"], work)
         assert rc == cmd["rc"], f"{case} {cmd['argv']}: rc {rc} stderr {err!r}"
         assert err == cmd["stderr"], f"{case} {cmd['argv']}"
+        # stdout summaries (f.c:132-177, t.c:219-243, c.c:282-303, d.c:44-65): identical except the measured
+        # runtime; the reference's two author-name lines per module are not printed by our host (DESIGN.md §7)
+        assert not mg.BANNER_RE.search(out), f"{case} {cmd['argv']}: unexpected author banner"
+        assert mg.mask_stdout(out) == cmd["stdout"], f"{case} {cmd['argv']}: stdout summary differs"
+    return man
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", GPU_CASES + FULL_CASES)
+def test_cli_replays_reference_session(case, tmp_path):
+    work = scratch_dir(tmp_path, case)
+    try:
+        _replay_and_check(case, work)
+    finally:
+        if work != str(tmp_path):
+            shutil.rmtree(work, ignore_errors=True)
+
+
+def _replay_and_check(case, tmp_path):
+    from pathlib import Path
+    tmp_path = Path(tmp_path)
+    man = replay(case, str(tmp_path))
     produced = sorted(os.listdir(tmp_path))
     assert produced == sorted(man["files"]), f"{case}: file set differs"
     for fn, meta in man["files"].items():

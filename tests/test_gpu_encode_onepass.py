@@ -1,0 +1,155 @@
+"""GPU parity of the one-pass Shannon-Fano encoder (sf_encode4.hip; compress_to_buffer + binary_coding,
+reference c.c:52-237): launches with many blocks, bit-exact against the oracle block by block.  The launch
+threshold is lowered / raised through shafa_hip_set_option so that both encoders see the same inputs."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import first_diff, long_code_case, to_shafa_table
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def one_pass(shafa):
+    shafa.lib().shafa_hip_init(0)
+    shafa.set_option("sf_encode_one_pass_min_blocks", 1)
+    yield
+    shafa.set_option("sf_encode_one_pass_min_blocks", 32)
+
+
+def run_batch(shafa, oracle, blocks, tables, caps=None, expect_err=None):
+    """blocks: list of uint8 arrays; tables: oracle tables.  Returns per-block encoded bytes (or checks errors)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    nb = len(blocks)
+    off, pos = [], 0
+    for b in blocks:
+        off.append(pos)
+        pos += (b.size + 15) // 16 * 16
+    host = np.zeros(max(pos, 16), dtype=np.uint8)
+    for o, b in zip(off, blocks):
+        host[o:o + b.size] = b
+    d_in = torch.from_numpy(host).to(dev)
+    want = []
+    for b, t in zip(blocks, tables):
+        rc, enc = oracle.sf_encode(b, t)
+        want.append((rc, enc))
+    if caps is None:
+        caps = [((w[1].size + 15) // 16 + 1) * 16 for w in want]
+    ooff, opos = [], 0
+    for c in caps:
+        ooff.append(opos)
+        opos += (c + 15) // 16 * 16 + 64
+    d_out = torch.full((opos + 64,), 0xEE, dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(nb, dtype=torch.int64, device=dev)
+    bt = shafa.Batch(nb, max(max(b.size for b in blocks), 16))
+    stabs = [to_shafa_table(shafa, t) for t in tables]
+    bt.sf_encode(st, d_in, off, [b.size for b in blocks], stabs, d_out, ooff, caps, d_n)
+    rc, errs = bt.finish(st, nb, raise_on_error=False)
+    out = d_out.cpu().numpy()
+    sizes = d_n.cpu().numpy()
+    bad = []
+    for i in range(nb):
+        exp = expect_err.get(i, 0) if expect_err else 0
+        if errs[i] != exp:
+            bad.append(f"block {i}: error {errs[i]} expected {exp}")
+            continue
+        if exp:
+            continue
+        got = out[ooff[i]:ooff[i] + int(sizes[i])]
+        if int(sizes[i]) != want[i][1].size or got.tobytes() != want[i][1].tobytes():
+            bad.append(f"block {i} (n={blocks[i].size}, lmax={tables[i].lens().max()}): size {sizes[i]} vs {want[i][1].size}; {first_diff(got, want[i][1])}")
+        # nothing written past the block's region (guard bytes stay 0xEE)
+        end = ooff[i] + (caps[i] + 15) // 16 * 16
+        if not (out[end:end + 64] == 0xEE).all():
+            bad.append(f"block {i}: wrote past its output region")
+    bt.close()
+    assert not bad, "\n".join(bad[:10])
+    return out, ooff, sizes
+
+
+def zipf_blocks(shafa, oracle, sizes, seed0=100):
+    zt = shafa.zipf_table(1.2)
+    blocks = [oracle.gen_bytes(seed0 + i, n, zt) for i, n in enumerate(sizes)]
+    tables = [oracle.sf_build(oracle.hist256(b)) for b in blocks]
+    return blocks, tables
+
+
+SIZES = [1, 2, 15, 16, 17, 31, 33, 255, 4095, 4096, 4097, 8191, 8192, 8193, 16383, 16384, 16385, 24576 + 1, 65536, 65536 + 5,
+         100000, 131072, 262144 + 5, 300000, 524288, 1048576 + 77, 2 * 1048576, 3 * 1048576 + 8191, 12345, 77777,
+         8192 * 5, 8192 * 7 + 1, 40, 41, 9000, 70000, 200000, 650000, 1 << 20, (1 << 20) + 8192]
+
+
+def test_one_pass_matches_oracle_ragged_sizes(shafa, oracle, one_pass):
+    blocks, tables = zipf_blocks(shafa, oracle, SIZES)
+    run_batch(shafa, oracle, blocks, tables)
+
+
+def test_one_pass_and_three_kernel_agree_on_a_big_launch(shafa, oracle):
+    """64 blocks of 1 MiB + ragged tails through the default dispatch (one pass: >= 32 blocks)."""
+    sizes = [(1 << 20) + 13 * i for i in range(64)]
+    blocks, tables = zipf_blocks(shafa, oracle, sizes, seed0=500)
+    shafa.lib().shafa_hip_init(0)
+    run_batch(shafa, oracle, blocks, tables)
+    shafa.set_option("sf_encode_one_pass_min_blocks", 1 << 20)       # force count / scan / pack
+    try:
+        run_batch(shafa, oracle, blocks, tables)
+    finally:
+        shafa.set_option("sf_encode_one_pass_min_blocks", 32)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "two", "few", "lmax16", "lmax13", "single_long_chain"])
+def test_one_pass_code_length_classes(shafa, oracle, one_pass, kind):
+    """NW = 3 (Lmax <= 8), 4 (<= 12), 5 (<= 15) and the Lmax == 16 variant; one block alone = the longest chain."""
+    blocks, tables = [], []
+    if kind == "uniform":          # 8/9-bit codes
+        for i, n in enumerate([70000, 8192, 500000, 33]):
+            b = oracle.gen_bytes(900 + i, n)
+            blocks.append(b)
+            tables.append(oracle.sf_build(oracle.hist256(oracle.gen_bytes(900 + i, 1 << 20))))
+    elif kind == "two":            # 1-bit codes: 8 symbols = 8 bits per oct
+        for i, n in enumerate([100000, 8191, 65536 + 3]):
+            b = (oracle.gen_bytes(910 + i, n) & 1).astype(np.uint8) * 200 + 3
+            blocks.append(b)
+            tables.append(oracle.sf_build(oracle.hist256(b)))
+    elif kind == "few":            # RLE-like: 5 symbols, Lmax <= 8
+        for i, n in enumerate([300000, 12345]):
+            b = (oracle.gen_bytes(920 + i, n) % 5).astype(np.uint8) * 50
+            blocks.append(b)
+            tables.append(oracle.sf_build(oracle.hist256(b)))
+    elif kind == "lmax16":
+        otab, _ = long_code_case(oracle, 1000, 17, 0.5, 3)
+        assert otab.lens().max() == 16
+        syms = np.nonzero(otab.lens())[0].astype(np.uint8)
+        rare = np.nonzero(otab.lens() >= 12)[0].astype(np.uint8)
+        blocks = [syms[oracle.gen_bytes(4, 200000) % syms.size], rare[oracle.gen_bytes(5, 70000) % rare.size],
+                  np.full(30000, np.nonzero(otab.lens() == 16)[0][0], dtype=np.uint8)]      # only 16-bit codes: 64-bit groups
+        tables = [otab] * 3
+    elif kind == "lmax13":
+        otab, data = long_code_case(oracle, 400000, 14, 0.5, 6)
+        assert 12 < otab.lens().max() <= 15, otab.lens().max()
+        blocks, tables = [data, data[:8193]], [otab, otab]
+    else:                          # one 4 MiB block: 512 tiles on one chain, every workgroup of the grid on it
+        zt = shafa.zipf_table(1.2)
+        b = oracle.gen_bytes(77, 4 << 20, zt)
+        blocks, tables = [b], [oracle.sf_build(oracle.hist256(b))]
+    run_batch(shafa, oracle, blocks, tables)
+
+
+def test_one_pass_error_semantics(shafa, oracle, one_pass):
+    """A data symbol without a code -> _FILE_UNRECOGNIZABLE for that block only; a too small output region ->
+    _LACK_OF_MEMORY for that block only, nothing written past it."""
+    blocks, tables = zipf_blocks(shafa, oracle, [50000] * 6, seed0=700)
+    # block 2: table built without symbol 250, which the data contains
+    f = oracle.hist256(blocks[2])
+    blocks[2] = blocks[2].copy()
+    blocks[2][12345] = 250
+    f[250] = 0
+    tables[2] = oracle.sf_build(f)
+    assert tables[2].lens()[250] == 0
+    caps = None
+    want_sizes = [oracle.sf_encode(b, t)[1].size for b, t in zip(blocks, tables)]
+    caps = [((w + 15) // 16 + 1) * 16 for w in want_sizes]
+    caps[4] = (want_sizes[4] // 2) // 16 * 16                      # half of what block 4 needs
+    run_batch(shafa, oracle, blocks, tables, caps=caps, expect_err={2: shafa.FILE_UNRECOGNIZABLE, 4: shafa.LACK_OF_MEMORY})
