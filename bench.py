@@ -227,6 +227,7 @@ def pipeline_leg(args, pkg, torch, dev, st, steps):
     d_freq = torch.zeros(nb * 256, dtype=torch.int64, device=dev)
 
     def timed(fn):
+        torch.cuda.synchronize()
         fn()
         bt.finish(st, nb)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -309,6 +310,7 @@ def main():
     in_off = [b * bs for b in range(nb)]
     in_n = [bs] * nb
     d_freq = torch.zeros(nb * 256, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()              # torch's fills run on its own stream: finish them before ours starts
     bt.hist256(st, d_in, in_off, in_n, d_freq)
     bt.finish(st, nb)
     freq = d_freq.cpu().numpy().astype(np.uint64).reshape(nb, 256)
@@ -322,6 +324,7 @@ def main():
     d_enc = torch.empty(nb * cap, dtype=torch.uint8, device=dev)
     d_enc_n = torch.zeros(nb, dtype=torch.int64, device=dev)
     d_dec = torch.empty(shard, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
 
     have_decode = not args.encode_only
 

@@ -220,7 +220,15 @@ class Batch:
 
     @staticmethod
     def _st(stream):
-        return C.c_void_p(stream.cuda_stream) if stream is not None else None
+        """hipStream_t of a torch stream.  The tensors handed to a launch were typically produced (allocated,
+        filled, copied) by torch on ITS current stream: order this launch after that work."""
+        if stream is None:
+            return None
+        import torch
+        cur = torch.cuda.current_stream(stream.device)
+        if cur.cuda_stream != stream.cuda_stream:
+            stream.wait_stream(cur)
+        return C.c_void_p(stream.cuda_stream)
 
     @staticmethod
     def _tables(tables):

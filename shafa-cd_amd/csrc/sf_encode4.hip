@@ -13,20 +13,21 @@
 //   * tiles of a block are handed out by a per-block ticket (atomicAdd), requested two iterations ahead: a tile's
 //     predecessors were always taken by workgroups that are running, so the chain cannot deadlock whatever part
 //     of the grid is resident (other kernels on other streams included);
-//   * iteration i looks up, groups and scans tile i and publishes its bit total (aggregate) at once; the tile's
-//     prefix is resolved in iteration i+1 from a descriptor window that was requested at the top of that
-//     iteration, i.e. >= one tile time after every predecessor of the chain published its aggregate.  The tile's
-//     bit strings stay in registers meanwhile and are placed and stored in iteration i+1.
+//   * iteration i looks up, groups and scans tile i, publishes its bit total (aggregate) and ORs its bit strings
+//     into an LDS window at tile-local offsets; the tile's prefix is resolved in iteration i+1 from a descriptor
+//     window that was requested at the top of that iteration, i.e. >= one tile time after every predecessor of
+//     the chain published its aggregate, and the window (double buffered) is stored then.
 //
 // Per tile (8 KiB of symbols, 256 lanes x two 16-byte items): every lane turns its 16 symbols into two "octs"
 // (8 symbols, <= 128 bits, right-aligned in four dwords) with a tree of shift-or steps on {code, len} pairs read
 // from a 2 KiB LDS table with ds_read_b64 (no unpacking); oct bit totals are scanned lane -> wave -> tile (DPP);
 // an oct that ENDS at window bit e is ORed into the LDS window with one v_alignbit_b32 + one ds_or_b32 per dword
-// (alignbit by e mod 32 needs no special case for 0).  The window is aligned to the global output (window
-// dword 0 = output dword 4 * (B >> 7), B = tile bit offset), so storing is a straight copy: byte-swapped 16-byte
-// coalesced stores.  A tile owns the output dwords [B >> 5, E >> 5); the B mod 32 leading bits of its first
-// dword are re-encoded from the up to 31 symbols before the tile (each code has >= 1 bit), so every output
-// dword is written exactly once: no global atomics, no pre-zeroed output.
+// (alignbit by e mod 32 needs no special case for 0).  On the way out every output dword is one more alignbit of
+// two neighbouring window dwords by (B mod 32), B = the tile's bit offset in the block: byte-swapped, 16-byte
+// aligned coalesced stores.  A tile owns the output dwords [B >> 5, E >> 5); the B mod 32 leading bits of its
+// first dword are re-encoded from the up to 31 symbols before the tile (each code has >= 1 bit) into the "lead
+// word" in front of the window, so every output dword is written exactly once: no global atomics, no pre-zeroed
+// output.
 #include "common.hpp"
 #include "internal.hpp"
 
@@ -146,13 +147,17 @@ __device__ __forceinline__ void load_tile(const EncBlk &blk, u32 tile, int tid, 
 }
 
 // NW: dwords an oct can touch (3: Lmax <= 8, 4: <= 12, 5: <= 16); L16: Lmax == 16
+//
+// One iteration of a workgroup = tile `cur` is looked up, grouped, scanned and ORed into its LDS window at TILE-LOCAL bit
+// offsets (the output position is not needed for that), while the tile of the previous iteration (`pending`), whose
+// window is the other buffer, gets its prefix from the descriptors, is funnel-shifted by (B mod 32) on the way out of
+// LDS and stored.  Two barriers per tile; the look-back runs in wave 0 beside the other waves' look-ups.
 template <int NW, bool L16>
-__global__ __launch_bounds__(E4_THREADS) void sfe4_kernel(const EncBlk *__restrict__ blks, int nblk, int nconc,
-                                                          u64 *__restrict__ desc, u32 *__restrict__ tickets)
+__global__ __launch_bounds__(E4_THREADS, 5) void sfe4_kernel(const EncBlk *__restrict__ blks, int nblk, int nconc,
+                                                             u64 *__restrict__ desc, u32 *__restrict__ tickets, u32 win_stride)
 {
     __shared__ E4Static sh;
-    extern __shared__ __attribute__((aligned(16))) u32 dynwin[];     // [E4_GUARD][window dwords]
-    u32 *win = dynwin + E4_GUARD;
+    extern __shared__ __attribute__((aligned(16))) u32 dynwin[];     // two buffers of [E4_GUARD][window dwords]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr bool R3 = NW >= 5;
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(E4_THREADS) void sfe4_kernel(const EncBlk *__restri
     for (int b = (int)(blockIdx.x % (u32)nconc); b < nblk; b += nconc) {
         const EncBlk blk = blks[b];
         u64 *bdesc = desc + blk.desc_base;
-        __syncthreads();                               // the previous block's table and window are no longer in use
+        __syncthreads();                               // the previous block's table and windows are no longer in use
         sh.lut[tid] = gload<u64>((const u64 *)blk.lut + tid);
         if (tid == 0) sh.tick = atomicAdd(tickets + blk.ticket, 2u);
         __syncthreads();
@@ -171,17 +176,16 @@ __global__ __launch_bounds__(E4_THREADS) void sfe4_kernel(const EncBlk *__restri
 
         bool have_pend = false;
         u32 p_tile = 0, p_T = 0, p_pv = 0;
-        Oct p_oct[2][2];
-        u32 p_ioff[2] = {0, 0};
-#pragma unroll
-        for (int it = 0; it < 2; ++it)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) p_oct[it][h] = Oct{0, 0, 0, 0, 0};
+        u32 dirty[2] = {win_stride - E4_GUARD, win_stride - E4_GUARD};   // dwords of each buffer that may be non-zero
+        u32 it_no = 0;
 
-        for (;;) {
+        for (;; ++it_no) {
             const bool cur_ok = cur < blk.n_tiles;
             if (!cur_ok && !have_pend) break;
             const bool nxt_ok = cur_ok && nxt < blk.n_tiles;
+            const u32 buf = it_no & 1u;
+            u32 *win = dynwin + buf * win_stride + E4_GUARD;               // this tile's window
+            u32 *pwin = dynwin + (buf ^ 1u) * win_stride + E4_GUARD;       // the pending tile's window
 
             // ---- requests that have a whole iteration to come back ------------------------------------------
             u32 nn = E4_NONE;
@@ -193,10 +197,12 @@ __global__ __launch_bounds__(E4_THREADS) void sfe4_kernel(const EncBlk *__restri
             }
             if (nxt_ok) load_tile(blk, nxt, tid, nin);
 
-            // ---- this tile: look up, group, scan --------------------------------------------------------------
+            // ---- this tile: zero its window, look up, group, scan ------------------------------------------------
             Oct c_oct[2][2];
-            u32 c_ioff[2] = {0, 0}, c_T = 0, incl[2] = {0, 0}, itot[2] = {0, 0};
+            u32 incl[2] = {0, 0}, itot[2] = {0, 0};
             if (cur_ok) {
+                for (u32 i = (u32)tid; i < ((dirty[buf] + 3u) >> 2) + 1u; i += E4_THREADS)
+                    ((uint4 *)win)[(int)i - 1] = make_uint4(0, 0, 0, 0);              // from dword -4: the lead word is win[-1]
                 const u64 base = (u64)cur * E4_TILE;
                 u32 absent = 0;
                 if (base + E4_TILE <= blk.n) {
@@ -229,14 +235,38 @@ __global__ __launch_bounds__(E4_THREADS) void sfe4_kernel(const EncBlk *__restri
                     sh.wtot[4 + wv] = incl[1];
                 }
             }
-            __syncthreads();                                                           // 1
+
+            // ---- wave 0: the pending tile's prefix (its descriptor window was requested at the top) and lead bits ----
+            if (have_pend && wv == 0) {
+                u64 B = 0;
+                if (p_tile > 0) {
+                    B = lookback_sum(bdesc, (int)p_tile, blk.err, true, first);
+                    if (lane == 0) {
+                        desc_store(bdesc + p_tile, DESC_PREFIX, B + p_T);
+                        if (p_tile == blk.n_tiles - 1) gstore<u64>(blk.out_n, (B + p_T + 7) >> 3);
+                    }
+                    const u32 r = (u32)B & 31u;
+                    if (r) {                           // the last r bits before the tile, right-aligned in the lead word pwin[-1]
+                        const u64 ent = lane < 32 ? sh.lut[p_pv & 0xFFu] : 0ull;
+                        const u32 code = (u32)ent, len = (u32)(ent >> 32) & 0xFFFFu;
+                        const u32 D = dpp_scan_add(len);               // bits from this symbol's first bit to the tile start
+                        if (len && D - len < r)
+                            __hip_atomic_fetch_or(pwin - 1, code << ((D - len) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                if (lane == 0) sh.prefix = B;
+            }
+            if (tid == 0) sh.tick = nn;
+            __syncthreads();                                                           // A
+            nn = sh.tick;
+            u32 c_T = 0;
             if (cur_ok) {
-                u32 run = 0;
+                u32 run = 0, ioff[2] = {0, 0};
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
-                        if (w == wv) c_ioff[it] = run + incl[it] - itot[it];
+                        if (w == wv) ioff[it] = run + incl[it] - itot[it];
                         run += sh.wtot[it * 4 + w];
                     }
                 }
@@ -247,96 +277,59 @@ __global__ __launch_bounds__(E4_THREADS) void sfe4_kernel(const EncBlk *__restri
                         if (blk.n_tiles == 1) gstore<u64>(blk.out_n, ((u64)c_T + 7) >> 3);
                     } else desc_store(bdesc + cur, DESC_AGG, c_T);
                 }
-            }
-
-            // ---- retire the pending tile: prefix, window, stores ------------------------------------------------
-            const u32 p_need = ((127u + p_T) >> 5) + 2u;                              // window dwords the tile can touch
-            if (have_pend) {
-                if (wv == 0) {
-                    u64 B = 0;
-                    if (p_tile > 0) {
-                        B = lookback_sum(bdesc, (int)p_tile, blk.err, true, first);
-                        if (lane == 0) {
-                            desc_store(bdesc + p_tile, DESC_PREFIX, B + p_T);
-                            if (p_tile == blk.n_tiles - 1) gstore<u64>(blk.out_n, (B + p_T + 7) >> 3);
-                        }
-                    }
-                    if (lane == 0) sh.prefix = B;
-                }
-                for (u32 i = (u32)tid; i < (p_need + 3u) >> 2; i += E4_THREADS) ((uint4 *)win)[i] = make_uint4(0, 0, 0, 0);
-            }
-            if (tid == 0) sh.tick = nn;
-            __syncthreads();                                                           // 2
-            nn = sh.tick;
-            u64 B = 0;
-            if (have_pend) {
-                B = sh.prefix;
-                const u32 s = (u32)B & 127u;
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
-                    const u32 e0 = s + p_ioff[it] + p_oct[it][0].ll;
-                    place<NW>(win, p_oct[it][0], e0);
-                    place<NW>(win, p_oct[it][1], e0 + p_oct[it][1].ll);
+                    const u32 e0 = ioff[it] + c_oct[it][0].ll;
+                    place<NW>(win, c_oct[it][0], e0);
+                    place<NW>(win, c_oct[it][1], e0 + c_oct[it][1].ll);
                 }
-                const u32 s5 = (u32)B & 31u;
-                if (wv == 0 && s5 && p_tile > 0) {     // lead bits of the first owned dword: the last s5 bits before the tile
-                    const u64 ent = lane < 32 ? sh.lut[p_pv & 0xFFu] : 0ull;
-                    const u32 code = (u32)ent, len = (u32)(ent >> 32) & 0xFFFFu;
-                    const u32 D = dpp_scan_add(len);   // bits from this symbol's first bit to the tile start
-                    if (len && D - len < s5) {
-                        const u32 e = s - D + len;     // > 32 * first owned dword
-                        const u32 ld0 = s >> 5;
-                        u32 *p = win + (e >> 5);
-                        __hip_atomic_fetch_or(p, __builtin_amdgcn_alignbit(code, 0u, e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if ((e >> 5) > ld0)
-                            __hip_atomic_fetch_or(p - 1, code >> (e & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
+                dirty[buf] = (c_T >> 5) + 2u;
             }
-            __syncthreads();                                                           // 3
+
+            // ---- the pending tile leaves LDS: out dword j = bits [32 j - r, 32 j - r + 32) of its window ----------
             if (have_pend) {
+                const u64 B = sh.prefix;
+                const u32 r = (u32)B & 31u;
                 const bool last = p_tile == blk.n_tiles - 1;
                 const u64 E = B + p_T;
                 const u64 total_bytes = (E + 7) >> 3;                                  // the block's size when this is its last tile
-                const u64 base128 = B >> 7;
-                const u32 ld0 = ((u32)B & 127u) >> 5;
-                const u32 ld1 = (u32)((last ? (total_bytes >> 2) : (E >> 5)) - 4 * base128);
+                const u64 gd0 = B >> 5;
+                const u32 count = (u32)((last ? (total_bytes >> 2) : (E >> 5)) - gd0);  // owned dwords
                 const u64 end_bytes = last ? total_bytes : 4 * (E >> 5);
                 if (end_bytes > blk.out_cap) {
                     if (tid == 0) set_error(blk.err, SHAFA_LACK_OF_MEMORY);
                 } else {
-                    u8 *outw = blk.out + 16 * base128;                                 // window dword 0
-                    const u32 u0 = (ld0 + 3u) >> 2, u1 = ld1 >> 2;
-                    for (u32 u = u0 + (u32)tid; u < u1; u += E4_THREADS) {
-                        const uint4 x = ((const uint4 *)win)[u];
-                        gstore_nt<uint4>(outw + 16 * (u64)u, make_uint4(bswap32(x.x), bswap32(x.y), bswap32(x.z), bswap32(x.w)));
+                    u8 *o = blk.out + 4 * gd0;                                         // owned dword 0
+                    u32 h = (u32)(0 - gd0) & 3u;                                       // dwords up to the first 16-byte boundary
+                    if (h > count) h = count;
+                    const u32 nq = (count - h) >> 2;                                   // aligned 16-byte pieces
+                    for (u32 q = (u32)tid; q < nq; q += E4_THREADS) {
+                        const u32 j = h + 4 * q;
+                        const u32 w0 = pwin[(int)j - 1], w1 = pwin[j], w2 = pwin[j + 1], w3 = pwin[j + 2], w4 = pwin[j + 3];
+                        gstore_nt<uint4>(o + 4 * (u64)j, make_uint4(bswap32(__builtin_amdgcn_alignbit(w0, w1, r)),
+                                                                   bswap32(__builtin_amdgcn_alignbit(w1, w2, r)),
+                                                                   bswap32(__builtin_amdgcn_alignbit(w2, w3, r)),
+                                                                   bswap32(__builtin_amdgcn_alignbit(w3, w4, r))));
                     }
-                    const u32 h_end = 4 * u0 < ld1 ? 4 * u0 : ld1;                     // head dwords [ld0, h_end), tail dwords [t0, ld1)
-                    const u32 t0 = 4 * u1 > h_end ? 4 * u1 : h_end;
-                    if ((u32)tid < 4) {
-                        const u32 d = ld0 + (u32)tid;
-                        if (d < h_end) gstore<u32>(outw + 4 * (u64)d, bswap32(win[d]));
-                    } else if ((u32)tid < 8) {
-                        const u32 d = t0 + (u32)tid - 4;
-                        if (d < ld1) gstore<u32>(outw + 4 * (u64)d, bswap32(win[d]));
+                    const u32 t0 = h + 4 * nq;                                         // tail dwords [t0, count)
+                    if ((u32)tid < 8) {
+                        const u32 j = (u32)tid < 4 ? (u32)tid : t0 + (u32)tid - 4;
+                        const bool ok = (u32)tid < 4 ? j < h : j < count;
+                        if (ok) gstore<u32>(o + 4 * (u64)j, bswap32(__builtin_amdgcn_alignbit(pwin[(int)j - 1], pwin[j], r)));
                     } else if (last && (u32)tid < 11) {                                // the block's final 1..3 bytes
                         const u32 q = (u32)tid - 8;
-                        if (q < (u32)(total_bytes & 3)) gstore<u8>(outw + 4 * (u64)ld1 + q, (u8)(win[ld1] >> (24 - 8 * q)));
+                        const u32 w = __builtin_amdgcn_alignbit(pwin[(int)count - 1], pwin[count], r);
+                        if (q < (u32)(total_bytes & 3)) gstore<u8>(o + 4 * (u64)count + q, (u8)(w >> (24 - 8 * q)));
                     }
                 }
             }
+            __syncthreads();                                                           // B
 
             // ---- rotate ------------------------------------------------------------------------------------------
             have_pend = cur_ok;
             p_tile = cur;
             p_T = c_T;
             p_pv = cin.pv;
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                p_ioff[it] = c_ioff[it];
-                p_oct[it][0] = c_oct[it][0];
-                p_oct[it][1] = c_oct[it][1];
-            }
             cur = nxt;
             cin = nin;
             nxt = nn;
@@ -348,14 +341,15 @@ template <int NW, bool L16>
 int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax)
 {
     static int wgs_per_cu = 0, cus = 0;
-    const size_t dyn = ((size_t)E4_GUARD + ((127u + (size_t)E4_TILE * lmax) >> 5) + 8) * 4;
+    const u32 win_stride = ((u32)E4_GUARD + (u32)(((size_t)E4_TILE * lmax) >> 5) + 8u + 3u) & ~3u;     // dwords per buffer
+    const size_t dyn = (size_t)win_stride * 2 * 4;
     if (!wgs_per_cu) {
         int dev = 0, occ = 0;
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         cus = prop.multiProcessorCount;
-        const size_t dyn_max = ((size_t)E4_GUARD + ((127u + (size_t)E4_TILE * 16) >> 5) + 8) * 4;
+        const size_t dyn_max = (((size_t)E4_GUARD + (((size_t)E4_TILE * 16) >> 5) + 8 + 3) & ~(size_t)3) * 2 * 4;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)sfe4_kernel<NW, L16>, E4_THREADS, dyn_max));
         wgs_per_cu = occ < 1 ? 1 : (occ > 6 ? 6 : occ);
     }
@@ -364,7 +358,8 @@ int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 
     int nconc = count < target ? count : target;
     int per = target / nconc;
     if (per < 1) per = 1;
-    hipLaunchKernelGGL((sfe4_kernel<NW, L16>), dim3((u32)(nconc * per)), dim3(E4_THREADS), dyn, st, dblk, count, nconc, d_desc, d_tickets);
+    hipLaunchKernelGGL((sfe4_kernel<NW, L16>), dim3((u32)(nconc * per)), dim3(E4_THREADS), dyn, st, dblk, count, nconc, d_desc, d_tickets,
+                       win_stride);
     return SHAFA_SUCCESS;
 }
 

@@ -45,6 +45,7 @@ def run_batch(shafa, oracle, blocks, tables, caps=None, expect_err=None):
     d_n = torch.zeros(nb, dtype=torch.int64, device=dev)
     bt = shafa.Batch(nb, max(max(b.size for b in blocks), 16))
     stabs = [to_shafa_table(shafa, t) for t in tables]
+    torch.cuda.synchronize()          # torch's fills run on its own stream: finish them before ours starts
     bt.sf_encode(st, d_in, off, [b.size for b in blocks], stabs, d_out, ooff, caps, d_n)
     rc, errs = bt.finish(st, nb, raise_on_error=False)
     out = d_out.cpu().numpy()

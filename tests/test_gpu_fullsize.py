@@ -104,6 +104,7 @@ def test_layer2_batches_reproduce_reference_files(case, shafa, oracle):
         d_rle = torch.empty(nb * rcap, dtype=torch.uint8, device=dev)
         d_rle_n = torch.zeros(nb, dtype=torch.int64, device=dev)
         d_freq = torch.zeros(nb * 256, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()      # torch's fills run on its own stream: finish them before ours starts
         bt.rle_encode(st, d_in, off, S.sizes, d_rle, roff, [rcap] * nb, d_rle_n, d_freq)
         bt.finish(st, nb)
         rle_n = [int(x) for x in d_rle_n.cpu().numpy()]
@@ -137,6 +138,7 @@ def test_layer2_batches_reproduce_reference_files(case, shafa, oracle):
         eoff = [b * cap for b in range(nb)]
         d_enc = torch.empty(nb * cap, dtype=torch.uint8, device=dev)
         d_enc_n = torch.zeros(nb, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
         bt.sf_encode(st, src, soff, ssz, tables, d_enc, eoff, [cap] * nb, d_enc_n)
         bt.finish(st, nb)
         assert [int(x) for x in d_enc_n.cpu().numpy()] == enc_bytes
@@ -166,6 +168,7 @@ def test_layer2_batches_reproduce_reference_files(case, shafa, oracle):
             doff = [b * dcap for b in range(nb)]
             d_dec = torch.empty(nb * dcap, dtype=torch.uint8, device=dev)
             d_dec_n = torch.zeros(nb, dtype=torch.int64, device=dev)
+            torch.cuda.synchronize()
             bt.rle_decode(st, d_sym, soff, ssz, d_dec, doff, [dcap] * nb, d_dec_n)
             bt.finish(st, nb)
             assert [int(x) for x in d_dec_n.cpu().numpy()] == S.sizes

@@ -39,6 +39,7 @@ def _worker(rank, world, port, total, bs, q):
     off = [b * bs for b in range(nb)]
     d_freq = torch.zeros(max(nb, 1) * 256, dtype=torch.int64, device=dev)
     got = None
+    torch.cuda.synchronize()
     if nb:
         bt.hist256(st, local, off, sizes, d_freq)
         bt.finish(st, nb)
@@ -50,6 +51,7 @@ def _worker(rank, world, port, total, bs, q):
     eoff = [b * cap for b in range(nb)]
     d_enc = torch.empty(max(nb, 1) * cap, dtype=torch.uint8, device=dev)
     d_enc_n = torch.zeros(max(nb, 1), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
     if nb:
         bt.sf_encode(st, local, off, sizes, tables, d_enc, eoff, [cap] * nb, d_enc_n)
         bt.finish(st, nb)
