@@ -146,6 +146,27 @@ __device__ __forceinline__ uint4 gload_nt<uint4>(const void *p)
     return *(const uint4 *)p;
 #endif
 }
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+template <>
+__device__ __forceinline__ uint2 gload_nt<uint2>(const void *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32x2_t v = __builtin_nontemporal_load((const GLOBAL_AS u32x2_t *)(unsigned long long)p);
+    return make_uint2(v.x, v.y);
+#else
+    return *(const uint2 *)p;
+#endif
+}
+template <>
+__device__ __forceinline__ uint2 gload<uint2>(const void *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32x2_t v = *(const GLOBAL_AS u32x2_t *)(unsigned long long)p;
+    return make_uint2(v.x, v.y);
+#else
+    return *(const uint2 *)p;
+#endif
+}
 template <typename T>
 __device__ __forceinline__ void gstore_nt(void *p, T v);
 template <>
@@ -159,6 +180,16 @@ __device__ __forceinline__ void gstore_nt<uint4>(void *p, uint4 v)
     *(uint4 *)p = v;
 #endif
 }
+
+// uniform base pointer + 32-bit lane offset: lets the compiler use the SGPR-base addressing form (no 64-bit VGPR address)
+template <typename T>
+__device__ __forceinline__ T gload_off(const void *base, u32 off) { return gload<T>((const u8 *)base + off); }
+template <typename T>
+__device__ __forceinline__ T gload_nt_off(const void *base, u32 off) { return gload_nt<T>((const u8 *)base + off); }
+template <typename T>
+__device__ __forceinline__ void gstore_off(void *base, u32 off, T v) { gstore<T>((u8 *)base + off, v); }
+template <typename T>
+__device__ __forceinline__ void gstore_nt_off(void *base, u32 off, T v) { gstore_nt<T>((u8 *)base + off, v); }
 
 // first error wins per block (codes are small positive ints; keep the first non-zero)
 __device__ __forceinline__ void set_error(int *err, int code)
@@ -202,6 +233,50 @@ __device__ __forceinline__ u64 lookback_sum(const u64 *desc, int k, int *err, bo
             break;
         }
         excl += wave_reduce_add<u64>(val);
+        j -= 64;
+    }
+    return excl;
+}
+
+// Same look-back for aggregates below 2^32 per 64-tile window (tile bit totals), without the LDS-routed shuffles of
+// wave_reduce_add: the window's aggregates are summed with a DPP scan of their low dwords, the one inclusive prefix that
+// ends the walk is read with v_readlane.  `first` = descriptors of tiles k-1-lane, loaded by the caller well ahead.
+__device__ __forceinline__ u64 lookback_sum_dpp(const u64 *desc, int k, int *err, u64 first)
+{
+    const int lane = lane_id();
+    u64 excl = 0;
+    int j = k - 1;
+    bool have_first = true;
+    for (;;) {
+        const int idx = j - lane;
+        u64 d = 0;
+        u32 spins = 0;
+        for (;;) {
+            if (have_first) d = first;
+            else d = (idx >= 0) ? desc_load(desc + idx) : (DESC_PREFIX << 62);
+            have_first = false;
+            const u64 pm = __ballot((d >> 62) == DESC_PREFIX);
+            const u64 em = __ballot((d >> 62) == DESC_EMPTY);
+            // entries behind the nearest inclusive prefix are not needed
+            const u64 need = pm ? ((pm & (0 - pm)) - 1) : ~0ull;       // lanes in front of the first prefix lane
+            if (!(em & need)) break;
+            if (++spins > SPIN_LIMIT) {          // lost predecessor: flag instead of hanging
+                if (lane == 0) set_error(err, SHAFA_DEVICE_ERROR);
+                if ((d >> 62) == DESC_EMPTY) d = (DESC_PREFIX << 62);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const u64 pmask = __ballot((d >> 62) == DESC_PREFIX);
+        const int pl = pmask ? __ffsll((unsigned long long)pmask) - 1 : 64;
+        const u32 agg = lane < pl ? (u32)d : 0u;                       // aggregates in front of the prefix lane
+        excl += (u32)__builtin_amdgcn_readlane((int)dpp_scan_add(agg), 63);
+        if (pmask) {
+            const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)d, pl);
+            const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(d >> 32), pl);
+            excl += (((u64)hi << 32) | lo) & DESC_VALUE_MASK;
+            break;
+        }
         j -= 64;
     }
     return excl;

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(ENC_THREADS) void sf_encode_generic(const EncBlk *_
 // host launcher
 // ------------------------------------------------------------------------------------------------
 void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 *d_tile_bits, u64 *d_tile_off, bool lut64);
-int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax);
+int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool any_ragged);
 
 // A launch with at least this many class-1 blocks takes the one-pass encoder: every block is its own chain, and
 // with this many chains a tile's look-back stays within a few 64-entry windows (sf_encode4.hip).
@@ -331,7 +331,9 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     u32 *dtick = (u32 *)(ws + o_tick);
     if (cls_count[1]) {
         if (one_pass) {
-            if ((rc = sfenc4_launch(st, dblk + cls_first[1], cls_count[1], ddesc, dtick, lmax1))) return rc;
+            bool any_ragged = false;
+            for (int b = 0; b < nblocks; ++b) any_ragged = any_ragged || (cls[b] == 1 && (h_in_n[b] & 8191));
+            if ((rc = sfenc4_launch(st, dblk + cls_first[1], cls_count[1], ddesc, dtick, lmax1, any_ragged))) return rc;
         } else sfenc3_launch(st, dblk + cls_first[1], cls_count[1], max_tiles[1], (u32 *)(ws + o_tbits), ddesc, false);
     }
     if (cls_count[2]) sfenc3_launch(st, dblk + cls_first[2], cls_count[2], max_tiles[2], (u32 *)(ws + o_tbits), ddesc, true);

@@ -10,16 +10,16 @@
 //   * workgroups are persistent and stick to one block at a time (block = blockIdx % nconc, then + nconc): the
 //     block's look-up table is loaded once, and with >= 32 blocks per launch every block is a separate chain with
 //     only a handful of tiles in flight, so a look-back is one 64-entry window;
-//   * tiles of a block are handed out by a per-block ticket (atomicAdd), requested two iterations ahead: a tile's
+//   * tiles of a block are handed out by a per-block ticket (atomicAdd), requested three iterations ahead: a tile's
 //     predecessors were always taken by workgroups that are running, so the chain cannot deadlock whatever part
 //     of the grid is resident (other kernels on other streams included);
 //   * iteration i looks up, groups and scans tile i, publishes its bit total (aggregate) and ORs its bit strings
-//     into an LDS window at tile-local offsets; the tile's prefix is resolved in iteration i+1 from a descriptor
-//     window that was requested at the top of that iteration, i.e. >= one tile time after every predecessor of
-//     the chain published its aggregate, and the window (double buffered) is stored then.
+//     into an LDS window at tile-local offsets; the descriptor window of the tile is requested in iteration i+1 (its
+//     predecessors hold earlier tickets and have had a whole tile time to publish) and consumed in iteration i+2
+//     (a whole tile time to arrive), when the tile's LDS window - one of three - is stored.
 //
-// Per tile (8 KiB of symbols, 256 lanes x two 16-byte items): every lane turns its 16 symbols into two "octs"
-// (8 symbols, <= 128 bits, right-aligned in four dwords) with a tree of shift-or steps on {code, len} pairs read
+// Per tile (8 KiB of symbols = four rows of 256 lanes x 8 bytes): every lane turns the 8 symbols of a row into an "oct"
+// (<= 128 bits, right-aligned in four dwords) with a tree of shift-or steps on {code, len} pairs read
 // from a 2 KiB LDS table with ds_read_b64 (no unpacking); oct bit totals are scanned lane -> wave -> tile (DPP);
 // an oct that ENDS at window bit e is ORed into the LDS window with one v_alignbit_b32 + one ds_or_b32 per dword
 // (alignbit by e mod 32 needs no special case for 0).  On the way out every output dword is one more alignbit of
@@ -37,10 +37,25 @@ constexpr int E4_THREADS = 256;
 constexpr int E4_TILE = 8192;                          // symbols per tile
 constexpr int E4_GUARD = 8;                            // dwords in front of the window: an oct writes up to 4 dwords before its last one
 constexpr u32 E4_NONE = 0xFFFFFFFFu;
+#ifndef E4_WPS
+#define E4_WPS 4                                       // waves per SIMD the register allocation aims at
+#endif
+
+#ifdef E4_STAMPS
+// diagnostic build only (tools/dbg): per-wave cycle totals of the phases of an iteration
+__device__ unsigned long long e4_stamp_buf[2048 * 4 * 8];
+#define E4_T0() unsigned long long _t_prev = __builtin_amdgcn_s_memtime(), _t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define E4_T(ph) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); _t_acc[ph] += _t - _t_prev; _t_prev = _t; } while (0)
+#define E4_TEND() do { if (lane == 0) for (int _q = 0; _q < 8; ++_q) e4_stamp_buf[((blockIdx.x & 2047) * 4 + wv) * 8 + _q] = _t_acc[_q]; } while (0)
+#else
+#define E4_T0()
+#define E4_T(ph)
+#define E4_TEND()
+#endif
 
 struct E4Static {
     u64 lut[256];                // {code (low dword), len (high dword)}; a symbol without a code: len = 1 << 16
-    u32 wtot[8];                 // [item][wave] bit totals
+    u32 wtot[16];                // [row][wave] bit totals, i.e. in stream order
     u64 prefix;                  // bits before the pending tile
     u32 tick;                    // next ticket of the block (broadcast)
     u32 pad;
@@ -50,17 +65,9 @@ struct Oct {                     // 8 symbols: right-aligned 128-bit string r3:r
     u32 r0, r1, r2, r3, ll;
 };
 
-// four symbols of one input dword -> right-aligned group g of L bits (L <= 64)
-template <bool SAFE>
-__device__ __forceinline__ void quad(const u64 *lut, u32 w, u32 drop4, u64 &g, u32 &L)
+// four {code, len} entries -> right-aligned group g of L bits (L <= 64)
+__device__ __forceinline__ void quad(u64 e0, u64 e1, u64 e2, u64 e3, u64 &g, u32 &L)
 {
-    u64 e0 = lut[w & 0xFFu], e1 = lut[(w >> 8) & 0xFFu], e2 = lut[(w >> 16) & 0xFFu], e3 = lut[w >> 24];
-    if (SAFE) {                                        // ragged last tile: symbols past the block encode as nothing
-        if (drop4 & 1u) e0 = 0;
-        if (drop4 & 2u) e1 = 0;
-        if (drop4 & 4u) e2 = 0;
-        if (drop4 & 8u) e3 = 0;
-    }
     const u32 c0 = (u32)e0, c1 = (u32)e1, c2 = (u32)e2, c3 = (u32)e3;
     const u32 l0 = (u32)(e0 >> 32), l1 = (u32)(e1 >> 32), l2 = (u32)(e2 >> 32), l3 = (u32)(e3 >> 32);
     const u32 a = (c0 << (l1 & 31u)) | c1;             // <= 32 bits
@@ -70,14 +77,26 @@ __device__ __forceinline__ void quad(const u64 *lut, u32 w, u32 drop4, u64 &g, u
     L = l0 + l1 + lb;
 }
 
-// SAFE: lengths may be 0 (dropped symbols); L16: a group may be exactly 64 bits (four 16-bit codes)
+// The 8 symbols of two input dwords -> oct.  All eight look-ups are issued before the first is used.
+// SAFE: lengths may be 0 (symbols past the block encode as nothing); L16: a group may be exactly 64 bits (four 16-bit codes)
 template <bool SAFE, bool L16, bool HAVE_R3>
 __device__ __forceinline__ Oct make_oct(const u64 *lut, u32 w0, u32 w1, u32 drop8)
 {
+    u64 e[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        e[j] = lut[(w0 >> (8 * j)) & 0xFFu];
+        e[4 + j] = lut[(w1 >> (8 * j)) & 0xFFu];
+    }
+    if (SAFE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if ((drop8 >> ((j & 3) + 4 * (j >> 2) )) & 1u) e[j] = 0;
+    }
     u64 g0, g1;
     u32 L0, L1;
-    quad<SAFE>(lut, w0, drop8 & 15u, g0, L0);
-    quad<SAFE>(lut, w1, drop8 >> 4, g1, L1);
+    quad(e[0], e[1], e[2], e[3], g0, L0);
+    quad(e[4], e[5], e[6], e[7], g1, L1);
     const u32 s = L1 & 0xFFFFu;
     u64 lo = g0 << (s & 63u);                          // s in [4, 60] on the plain path
     u64 hi = g0 >> ((64u - s) & 63u);
@@ -117,242 +136,331 @@ __device__ __forceinline__ void place(u32 *win, const Oct &o, u32 e)
 }
 
 struct TileIn {
-    uint4 v[2];
-    u32 pv;                      // lanes 0..31 of wave 0: the symbol (tile start - 1 - lane)
+    uint2 v[4];                  // row k of the tile = bytes [2048 k, 2048 k + 2048): lane t holds bytes 8 t .. 8 t + 7 of it (one oct)
 };
 
-__device__ __forceinline__ void load_tile(const EncBlk &blk, u32 tile, int tid, TileIn &t)
+// A FULL tile.  8 bytes per lane and row: in the instruction that places "the oct of row k" neighbouring lanes hold
+// neighbouring octs, so a 32-lane LDS group spans ~1.6 dwords per lane instead of ~3.3 with 16 bytes per lane.
+// Uniform base + 32-bit lane offset: the loads take the SGPR-base form, no 64-bit address registers.
+__device__ __forceinline__ void load_tile(const u8 *in, u32 tile, int tid, TileIn &t)
 {
-    const u64 base = (u64)tile * E4_TILE;
-    if (base + E4_TILE <= blk.n) {
+    const u8 *tb = in + (u64)tile * E4_TILE;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) t.v[it] = gload_nt<uint4>(blk.in + base + (u64)it * 4096 + (u64)tid * 16);
-    } else {
+    for (int k = 0; k < 4; ++k) t.v[k] = gload_nt_off<uint2>(tb, (u32)k * 2048u + (u32)tid * 8u);
+}
+
+// one tile's look-ups, groups and lane scans; returns the packed inclusive lane prefixes of rows (0,1) and (2,3)
+template <bool SAFE, int NW, bool L16>
+__device__ __forceinline__ void tile_octs(const u64 *lut, const TileIn &in, u32 keep_base, int tid, Oct (&oct)[4], u32 (&incl)[2],
+                                          u32 &absent)
+{
+    constexpr bool R3 = NW >= 5;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const u64 idx = base + (u64)it * 4096 + (u64)tid * 16;
-            u32 w[4] = {0, 0, 0, 0};
-            if (idx + 16 <= blk.n) {
-                const uint4 x = gload<uint4>(blk.in + idx);
-                w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w;
-            } else if (idx < blk.n) {
-                const int nv = (int)(blk.n - idx);
-                for (int q = 0; q < nv; ++q) w[q >> 2] |= (u32)gload<u8>(blk.in + idx + q) << (8 * (q & 3));
-            }
-            t.v[it] = make_uint4(w[0], w[1], w[2], w[3]);
+    for (int k = 0; k < 4; ++k) {
+        u32 drop = 0;
+        if (SAFE) {                                    // keep_base = symbols of the tile that exist
+            const u32 idx = (u32)k * 2048u + (u32)tid * 8u;
+            const u32 keep = idx >= keep_base ? 0u : (keep_base - idx >= 8u ? 8u : keep_base - idx);
+            drop = (0xFFu << keep) & 0xFFu;
         }
+        oct[k] = make_oct<SAFE, L16, R3>(lut, in.v[k].x, in.v[k].y, drop);
     }
-    t.pv = 0;
-    if (tid < 32 && tile > 0) t.pv = gload<u8>(blk.in + base - 1 - (u64)tid);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        absent |= oct[k].ll >> 16;
+        oct[k].ll &= 0xFFFFu;                          // <= 128 bits; a wave's row total <= 8192 < 2^16
+    }
+    incl[0] = dpp_scan_add(oct[0].ll | (oct[1].ll << 16));
+    incl[1] = dpp_scan_add(oct[2].ll | (oct[3].ll << 16));
+}
+
+// the 16 (row, wave) totals in stream order -> this wave's four row offsets and the tile total: one 16-lane DPP scan
+__device__ __forceinline__ u32 tile_offsets(const u32 *wtot, int lane, int wv, u32 (&roff)[4])
+{
+    const u32 tot = wtot[lane & 15];
+    u32 sc = tot;
+    sc += (u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x111, 0xf, 0xf, false);   // row_shr:1
+    sc += (u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x112, 0xf, 0xf, false);   // row_shr:2
+    sc += (u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x114, 0xf, 0xf, false);   // row_shr:4
+    sc += (u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x118, 0xf, 0xf, false);   // row_shr:8
+    const u32 ex = sc - tot;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) roff[k] = (u32)__builtin_amdgcn_readlane((int)ex, k * 4 + wv);
+    return (u32)__builtin_amdgcn_readlane((int)sc, 15);
+}
+
+// lead bits of a tile that starts at bit B of its block: the last r = B mod 32 bits before it, right-aligned, ORed into
+// the lead word pwin[-1] (wave 0, all lanes; pv = symbol (tile start - 1 - lane) in lanes 0..31)
+__device__ __forceinline__ void lead_bits(const u64 *lut, u32 *pwin, u32 pv, u32 r, int lane)
+{
+    const u64 ent = lane < 32 ? lut[pv & 0xFFu] : 0ull;
+    const u32 code = (u32)ent, len = (u32)(ent >> 32) & 0xFFFFu;
+    const u32 D = dpp_scan_add(len);                   // bits from this symbol's first bit to the tile start
+    if (len && D - len < r)
+        __hip_atomic_fetch_or(pwin - 1, code << ((D - len) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// A tile leaves LDS: output dword j of the tile = bits [32 j - r, 32 j - r + 32) of its window (r = B mod 32; the bits
+// in front of the window come from the lead word pwin[-1]).  The tile owns the output dwords [B >> 5, E >> 5), the
+// block's last tile also the final partial dword's bytes.
+__device__ __forceinline__ void store_window(const u32 *pwin, u8 *out, u64 out_cap, int *err, u64 B, u32 T, bool last, int tid,
+                                             u32 nthreads)
+{
+    const u32 r = (u32)B & 31u;
+    const u64 E = B + T;
+    const u64 total_bytes = (E + 7) >> 3;              // the block's size when this is its last tile
+    const u64 gd0 = B >> 5;
+    const u32 count = (u32)((last ? (total_bytes >> 2) : (E >> 5)) - gd0);      // owned dwords
+    const u64 end_bytes = last ? total_bytes : 4 * (E >> 5);
+    if (end_bytes > out_cap) {
+        if (tid == 0) set_error(err, SHAFA_LACK_OF_MEMORY);
+        return;
+    }
+    u8 *o = out + 4 * gd0;                             // owned dword 0
+    u32 h = (u32)(0 - gd0) & 3u;                       // dwords up to the first 16-byte boundary
+    if (h > count) h = count;
+    const u32 nq = (count - h) >> 2;                   // aligned 16-byte pieces
+    for (u32 q = (u32)tid; q < nq; q += nthreads) {
+        const u32 j = h + 4 * q;
+        const u32 w0 = pwin[(int)j - 1], w1 = pwin[j], w2 = pwin[j + 1], w3 = pwin[j + 2], w4 = pwin[j + 3];
+        gstore_nt_off<uint4>(o, 4 * j, make_uint4(bswap32(__builtin_amdgcn_alignbit(w0, w1, r)),
+                                                  bswap32(__builtin_amdgcn_alignbit(w1, w2, r)),
+                                                  bswap32(__builtin_amdgcn_alignbit(w2, w3, r)),
+                                                  bswap32(__builtin_amdgcn_alignbit(w3, w4, r))));
+    }
+    const u32 t0 = h + 4 * nq;                         // tail dwords [t0, count)
+    if ((u32)tid < 8) {
+        const u32 j = (u32)tid < 4 ? (u32)tid : t0 + (u32)tid - 4;
+        const bool ok = (u32)tid < 4 ? j < h : j < count;
+        if (ok) gstore_off<u32>(o, 4 * j, bswap32(__builtin_amdgcn_alignbit(pwin[(int)j - 1], pwin[j], r)));
+    } else if (last && (u32)tid < 11) {                // the block's final 1..3 bytes
+        const u32 q = (u32)tid - 8;
+        const u32 w = __builtin_amdgcn_alignbit(pwin[(int)count - 1], pwin[count], r);
+        if (q < (u32)(total_bytes & 3)) gstore_off<u8>(o, 4 * count + q, (u8)(w >> (24 - 8 * q)));
+    }
 }
 
 // NW: dwords an oct can touch (3: Lmax <= 8, 4: <= 12, 5: <= 16); L16: Lmax == 16
 //
-// One iteration of a workgroup = tile `cur` is looked up, grouped, scanned and ORed into its LDS window at TILE-LOCAL bit
-// offsets (the output position is not needed for that), while the tile of the previous iteration (`pending`), whose
-// window is the other buffer, gets its prefix from the descriptors, is funnel-shifted by (B mod 32) on the way out of
-// LDS and stored.  Two barriers per tile; the look-back runs in wave 0 beside the other waves' look-ups.
+// The FULL tiles of every block.  A three-stage software pipeline per workgroup, one LDS window buffer per stage:
+//   iteration i, all waves: tile i is looked up, grouped, scanned and ORed into its window at TILE-LOCAL bit offsets (the
+//     output position is not needed for that); tile i-2, whose prefix B is known by now, is funnel-shifted by (B mod 32)
+//     on the way out of LDS and stored.
+//   wave 0 also runs the chain, and never waits for a round trip doing so: at the top of iteration i it hands over the
+//     ticket that was requested in iteration i-1 and requests the next; it resolves the prefix of tile i-2 from the
+//     descriptor window it requested in iteration i-1 — a full iteration after that tile's aggregate went out, so its
+//     predecessors (earlier tickets) have published theirs unless they lag a whole tile time behind; after barrier A it
+//     publishes tile i's aggregate and requests the window of tile i-1.
+// Two barriers per tile.  A block's ragged remainder (< 8192 symbols) is left to sfe4_tail_kernel.
 template <int NW, bool L16>
-__global__ __launch_bounds__(E4_THREADS, 5) void sfe4_kernel(const EncBlk *__restrict__ blks, int nblk, int nconc,
+__global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *__restrict__ blks, int nblk, int nconc,
                                                              u64 *__restrict__ desc, u32 *__restrict__ tickets, u32 win_stride)
 {
     __shared__ E4Static sh;
-    extern __shared__ __attribute__((aligned(16))) u32 dynwin[];     // two buffers of [E4_GUARD][window dwords]
+    extern __shared__ __attribute__((aligned(16))) u32 dynwin[];     // three buffers of [E4_GUARD][window dwords]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr bool R3 = NW >= 5;
+    E4_T0();
 
     for (int b = (int)(blockIdx.x % (u32)nconc); b < nblk; b += nconc) {
-        const EncBlk blk = blks[b];
-        u64 *bdesc = desc + blk.desc_base;
+        const EncBlk *bp = blks + b;
+        const u8 *in = bp->in;
+        const u32 nfull = (u32)(bp->n >> 13);          // full tiles; the tile count of the whole block is bp->n_tiles
+        const bool ragged = (bp->n & (E4_TILE - 1)) != 0;
+        u64 *bdesc = desc + bp->desc_base;
+        u32 *tick = tickets + bp->ticket;
         __syncthreads();                               // the previous block's table and windows are no longer in use
-        sh.lut[tid] = gload<u64>((const u64 *)blk.lut + tid);
-        if (tid == 0) sh.tick = atomicAdd(tickets + blk.ticket, 2u);
+        sh.lut[tid] = gload<u64>((const u64 *)bp->lut + tid);
+        if (tid == 0) sh.tick = atomicAdd(tick, 3u);
         __syncthreads();
-        u32 cur = sh.tick, nxt = cur + 1;
-        if (cur >= blk.n_tiles) continue;
+        // tickets are four deep so that no atomic's round trip is ever waited for: `cur` is processed, `nxt` is being
+        // loaded, `nn` is known, and thread 0 holds the request issued one iteration ago (req)
+        u32 cur = sh.tick, nxt = cur + 1, nn = cur + 2;
+        if (cur >= nfull) continue;
+        u32 req = E4_NONE;
+        if (tid == 0) req = atomicAdd(tick, 1u);
         TileIn cin, nin;
-        load_tile(blk, cur, tid, cin);
+        load_tile(in, cur, tid, cin);
+        // wave 0: descriptor windows and the 32 symbols in front of the tiles in the pipeline (q = one iteration old, p = two)
+        u64 first_q = 0, first_p = 0;
+        u32 c_pv = 0, q_pv = 0, p_pv = 0;
 
-        bool have_pend = false;
-        u32 p_tile = 0, p_T = 0, p_pv = 0;
-        u32 dirty[2] = {win_stride - E4_GUARD, win_stride - E4_GUARD};   // dwords of each buffer that may be non-zero
-        u32 it_no = 0;
+        u32 q_tile = E4_NONE, q_T = 0;                 // computed in the previous iteration: aggregate out, window requested now
+        u32 p_tile = E4_NONE, p_T = 0;                 // computed two iterations ago: resolved and stored now
+        u32 dirty[3] = {win_stride - E4_GUARD, win_stride - E4_GUARD, win_stride - E4_GUARD};   // dwords that may be non-zero
+        u32 buf = 0;                                   // window buffer of `cur`; q: buf - 1, p: buf - 2 (mod 3)
 
-        for (;; ++it_no) {
-            const bool cur_ok = cur < blk.n_tiles;
-            if (!cur_ok && !have_pend) break;
-            const bool nxt_ok = cur_ok && nxt < blk.n_tiles;
-            const u32 buf = it_no & 1u;
+        for (;;) {
+            const bool cur_ok = cur < nfull;
+            const bool have_q = q_tile != E4_NONE, have_p = p_tile != E4_NONE;
+            if (!cur_ok && !have_q && !have_p) break;
+            const bool nxt_ok = cur_ok && nxt < nfull;
+            const u32 pbuf = buf >= 2 ? buf - 2 : buf + 1;
             u32 *win = dynwin + buf * win_stride + E4_GUARD;               // this tile's window
-            u32 *pwin = dynwin + (buf ^ 1u) * win_stride + E4_GUARD;       // the pending tile's window
+            u32 *pwin = dynwin + pbuf * win_stride + E4_GUARD;             // the window that is stored in this iteration
+            Oct c_oct[4];
+            u32 incl[2] = {0, 0};                      // rows (0,1) and (2,3): two 16-bit running sums per dword, one DPP scan each
 
-            // ---- requests that have a whole iteration to come back ------------------------------------------
-            u32 nn = E4_NONE;
-            if (nxt_ok && tid == 0) nn = atomicAdd(tickets + blk.ticket, 1u);          // ticket after next
-            u64 first = 0;
-            if (have_pend && wv == 0 && p_tile > 0) {                                  // descriptor window of the pending tile
-                const int idx = (int)p_tile - 1 - lane;
-                first = idx >= 0 ? desc_load(bdesc + idx) : (DESC_PREFIX << 62);
+            E4_T(7);
+            // ---- wave 0, before it issues anything new: everything it consumes here was requested at least half an
+            //      iteration ago (its youngest outstanding memory operation is the descriptor request after barrier A; it
+            //      takes no part in the window stores below), so these waits are short --------------------------------
+            if (wv == 0) {
+                if (lane == 0) sh.tick = req;          // last iteration's ticket request
+                E4_T(2);
+                if (have_p) {                          // prefix and lead bits of the tile that is stored in this iteration
+                    u64 B = 0;
+                    if (p_tile > 0) {
+                        B = lookback_sum_dpp(bdesc, (int)p_tile, bp->err, first_p);
+                        E4_T(0);
+                        if (lane == 0) {
+                            desc_store(bdesc + p_tile, DESC_PREFIX, B + p_T);
+                            if (!ragged && p_tile == nfull - 1) gstore<u64>(bp->out_n, (B + p_T + 7) >> 3);
+                        }
+                        const u32 r = (u32)B & 31u;
+                        if (r) lead_bits(sh.lut, pwin, p_pv, r, lane);
+                    }
+                    if (lane == 0) sh.prefix = B;
+                }
+                // unconditional (a few tickets past the block's end are harmless): the returned value is not touched
+                // before the next iteration, so the atomic's round trip is never waited for
+                if (lane == 0) req = atomicAdd(tick, 1u);
+                if (cur_ok && cur > 0 && lane < 32) c_pv = gload_off<u8>(in + (u64)cur * E4_TILE - 32, 31u - (u32)lane);
             }
-            if (nxt_ok) load_tile(blk, nxt, tid, nin);
+            E4_T(7);
+            if (nxt_ok) load_tile(in, nxt, tid, nin);
 
             // ---- this tile: zero its window, look up, group, scan ------------------------------------------------
-            Oct c_oct[2][2];
-            u32 incl[2] = {0, 0}, itot[2] = {0, 0};
             if (cur_ok) {
                 for (u32 i = (u32)tid; i < ((dirty[buf] + 3u) >> 2) + 1u; i += E4_THREADS)
                     ((uint4 *)win)[(int)i - 1] = make_uint4(0, 0, 0, 0);              // from dword -4: the lead word is win[-1]
-                const u64 base = (u64)cur * E4_TILE;
                 u32 absent = 0;
-                if (base + E4_TILE <= blk.n) {
-#pragma unroll
-                    for (int it = 0; it < 2; ++it) {
-                        c_oct[it][0] = make_oct<false, L16, R3>(sh.lut, cin.v[it].x, cin.v[it].y, 0u);
-                        c_oct[it][1] = make_oct<false, L16, R3>(sh.lut, cin.v[it].z, cin.v[it].w, 0u);
-                    }
-                } else {
-#pragma unroll
-                    for (int it = 0; it < 2; ++it) {
-                        const u64 idx = base + (u64)it * 4096 + (u64)tid * 16;
-                        const u32 keep = idx >= blk.n ? 0u : (blk.n - idx >= 16 ? 16u : (u32)(blk.n - idx));
-                        const u32 drop = (0xFFFFu << keep) & 0xFFFFu;
-                        c_oct[it][0] = make_oct<true, L16, R3>(sh.lut, cin.v[it].x, cin.v[it].y, drop & 0xFFu);
-                        c_oct[it][1] = make_oct<true, L16, R3>(sh.lut, cin.v[it].z, cin.v[it].w, drop >> 8);
-                    }
-                }
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    absent |= (c_oct[it][0].ll | c_oct[it][1].ll) >> 16;
-                    c_oct[it][0].ll &= 0xFFFFu;
-                    c_oct[it][1].ll &= 0xFFFFu;
-                    itot[it] = c_oct[it][0].ll + c_oct[it][1].ll;
-                    incl[it] = dpp_scan_add(itot[it]);
-                }
-                if (absent) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);   // data symbol without a code (output undefined, in bounds)
+                tile_octs<false, NW, L16>(sh.lut, cin, 0u, tid, c_oct, incl, absent);
+                if (absent) set_error(bp->err, SHAFA_FILE_UNRECOGNIZABLE);   // data symbol without a code (output undefined, in bounds)
                 if (lane == 63) {
-                    sh.wtot[wv] = incl[0];
-                    sh.wtot[4 + wv] = incl[1];
+                    sh.wtot[wv] = incl[0] & 0xFFFFu;
+                    sh.wtot[4 + wv] = incl[0] >> 16;
+                    sh.wtot[8 + wv] = incl[1] & 0xFFFFu;
+                    sh.wtot[12 + wv] = incl[1] >> 16;
                 }
             }
-
-            // ---- wave 0: the pending tile's prefix (its descriptor window was requested at the top) and lead bits ----
-            if (have_pend && wv == 0) {
-                u64 B = 0;
-                if (p_tile > 0) {
-                    B = lookback_sum(bdesc, (int)p_tile, blk.err, true, first);
-                    if (lane == 0) {
-                        desc_store(bdesc + p_tile, DESC_PREFIX, B + p_T);
-                        if (p_tile == blk.n_tiles - 1) gstore<u64>(blk.out_n, (B + p_T + 7) >> 3);
-                    }
-                    const u32 r = (u32)B & 31u;
-                    if (r) {                           // the last r bits before the tile, right-aligned in the lead word pwin[-1]
-                        const u64 ent = lane < 32 ? sh.lut[p_pv & 0xFFu] : 0ull;
-                        const u32 code = (u32)ent, len = (u32)(ent >> 32) & 0xFFFFu;
-                        const u32 D = dpp_scan_add(len);               // bits from this symbol's first bit to the tile start
-                        if (len && D - len < r)
-                            __hip_atomic_fetch_or(pwin - 1, code << ((D - len) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
-                if (lane == 0) sh.prefix = B;
-            }
-            if (tid == 0) sh.tick = nn;
+            E4_T(1);
             __syncthreads();                                                           // A
-            nn = sh.tick;
+            E4_T(3);
+            const u32 n3 = sh.tick;
             u32 c_T = 0;
             if (cur_ok) {
-                u32 run = 0, ioff[2] = {0, 0};
-#pragma unroll
-                for (int it = 0; it < 2; ++it) {
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        if (w == wv) ioff[it] = run + incl[it] - itot[it];
-                        run += sh.wtot[it * 4 + w];
-                    }
-                }
-                c_T = run;
+                u32 roff[4];
+                c_T = tile_offsets(sh.wtot, lane, wv, roff);
                 if (tid == 0) {
                     if (cur == 0) {
                         desc_store(bdesc, DESC_PREFIX, c_T);
-                        if (blk.n_tiles == 1) gstore<u64>(blk.out_n, ((u64)c_T + 7) >> 3);
+                        if (!ragged && nfull == 1) gstore<u64>(bp->out_n, ((u64)c_T + 7) >> 3);
                     } else desc_store(bdesc + cur, DESC_AGG, c_T);
                 }
 #pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const u32 e0 = ioff[it] + c_oct[it][0].ll;
-                    place<NW>(win, c_oct[it][0], e0);
-                    place<NW>(win, c_oct[it][1], e0 + c_oct[it][1].ll);
-                }
+                for (int k = 0; k < 4; ++k)            // the oct ends at: row offset of the wave + inclusive lane prefix
+                    place<NW>(win, c_oct[k], roff[k] + ((incl[k >> 1] >> (16 * (k & 1))) & 0xFFFFu));
                 dirty[buf] = (c_T >> 5) + 2u;
             }
-
-            // ---- the pending tile leaves LDS: out dword j = bits [32 j - r, 32 j - r + 32) of its window ----------
-            if (have_pend) {
-                const u64 B = sh.prefix;
-                const u32 r = (u32)B & 31u;
-                const bool last = p_tile == blk.n_tiles - 1;
-                const u64 E = B + p_T;
-                const u64 total_bytes = (E + 7) >> 3;                                  // the block's size when this is its last tile
-                const u64 gd0 = B >> 5;
-                const u32 count = (u32)((last ? (total_bytes >> 2) : (E >> 5)) - gd0);  // owned dwords
-                const u64 end_bytes = last ? total_bytes : 4 * (E >> 5);
-                if (end_bytes > blk.out_cap) {
-                    if (tid == 0) set_error(blk.err, SHAFA_LACK_OF_MEMORY);
-                } else {
-                    u8 *o = blk.out + 4 * gd0;                                         // owned dword 0
-                    u32 h = (u32)(0 - gd0) & 3u;                                       // dwords up to the first 16-byte boundary
-                    if (h > count) h = count;
-                    const u32 nq = (count - h) >> 2;                                   // aligned 16-byte pieces
-                    for (u32 q = (u32)tid; q < nq; q += E4_THREADS) {
-                        const u32 j = h + 4 * q;
-                        const u32 w0 = pwin[(int)j - 1], w1 = pwin[j], w2 = pwin[j + 1], w3 = pwin[j + 2], w4 = pwin[j + 3];
-                        gstore_nt<uint4>(o + 4 * (u64)j, make_uint4(bswap32(__builtin_amdgcn_alignbit(w0, w1, r)),
-                                                                   bswap32(__builtin_amdgcn_alignbit(w1, w2, r)),
-                                                                   bswap32(__builtin_amdgcn_alignbit(w2, w3, r)),
-                                                                   bswap32(__builtin_amdgcn_alignbit(w3, w4, r))));
-                    }
-                    const u32 t0 = h + 4 * nq;                                         // tail dwords [t0, count)
-                    if ((u32)tid < 8) {
-                        const u32 j = (u32)tid < 4 ? (u32)tid : t0 + (u32)tid - 4;
-                        const bool ok = (u32)tid < 4 ? j < h : j < count;
-                        if (ok) gstore<u32>(o + 4 * (u64)j, bswap32(__builtin_amdgcn_alignbit(pwin[(int)j - 1], pwin[j], r)));
-                    } else if (last && (u32)tid < 11) {                                // the block's final 1..3 bytes
-                        const u32 q = (u32)tid - 8;
-                        const u32 w = __builtin_amdgcn_alignbit(pwin[(int)count - 1], pwin[count], r);
-                        if (q < (u32)(total_bytes & 3)) gstore<u8>(o + 4 * (u64)count + q, (u8)(w >> (24 - 8 * q)));
-                    }
+            E4_T(4);
+            if (wv == 0) {
+                if (have_q && q_tile > 0) {            // the descriptor window of the tile computed one iteration ago
+                    const int idx = (int)q_tile - 1 - lane;
+                    first_q = idx >= 0 ? desc_load(bdesc + idx) : (DESC_PREFIX << 62);
                 }
+            } else if (have_p) {                       // waves 1..3 store the resolved tile's window
+                store_window(pwin, bp->out, bp->out_cap, bp->err, sh.prefix, p_T, !ragged && p_tile == nfull - 1, tid - 64,
+                             E4_THREADS - 64);
             }
+            E4_T(5);
             __syncthreads();                                                           // B
+            E4_T(6);
 
             // ---- rotate ------------------------------------------------------------------------------------------
-            have_pend = cur_ok;
-            p_tile = cur;
-            p_T = c_T;
-            p_pv = cin.pv;
+            p_tile = q_tile; p_T = q_T; p_pv = q_pv; first_p = first_q;
+            q_tile = cur_ok ? cur : E4_NONE; q_T = c_T; q_pv = c_pv;
+            buf = buf == 2 ? 0 : buf + 1;
             cur = nxt;
             cin = nin;
             nxt = nn;
+            nn = n3;
         }
     }
+    E4_TEND();
+}
+
+// The ragged remainder (< 8192 symbols) of every block whose size is not a multiple of the tile: one workgroup per block,
+// launched after sfe4_kernel, so the prefix of the last full tile is final.
+template <int NW, bool L16>
+__global__ __launch_bounds__(E4_THREADS) void sfe4_tail_kernel(const EncBlk *__restrict__ blks, const u64 *__restrict__ desc,
+                                                               u32 win_stride)
+{
+    __shared__ E4Static sh;
+    extern __shared__ __attribute__((aligned(16))) u32 dynwin[];
+    u32 *win = dynwin + E4_GUARD;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const EncBlk blk = blks[blockIdx.x];
+    const u32 rem = (u32)(blk.n & (E4_TILE - 1));
+    if (!rem) return;
+    const u32 nfull = (u32)(blk.n >> 13);
+    const u8 *tb = blk.in + (u64)nfull * E4_TILE;
+    sh.lut[tid] = gload<u64>((const u64 *)blk.lut + tid);
+    for (u32 i = (u32)tid; i < win_stride / 4; i += E4_THREADS) ((uint4 *)dynwin)[i] = make_uint4(0, 0, 0, 0);
+    TileIn in;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32 idx = (u32)k * 2048u + (u32)tid * 8u;
+        u32 w[2] = {0, 0};
+        if (idx + 8 <= rem) {
+            const uint2 x = gload<uint2>(tb + idx);
+            w[0] = x.x; w[1] = x.y;
+        } else if (idx < rem) {
+            const int nv = (int)(rem - idx);
+            for (int q = 0; q < nv; ++q) w[q >> 2] |= (u32)gload<u8>(tb + idx + q) << (8 * (q & 3));
+        }
+        in.v[k] = make_uint2(w[0], w[1]);
+    }
+    const u32 pv = (tid < 32 && nfull > 0) ? (u32)gload<u8>(tb - 1 - tid) : 0u;
+    const u64 B = nfull ? (desc_load(desc + blk.desc_base + nfull - 1) & DESC_VALUE_MASK) : 0ull;   // inclusive prefix of the last full tile
+    __syncthreads();
+    Oct oct[4];
+    u32 incl[2], absent = 0, roff[4];
+    tile_octs<true, NW, L16>(sh.lut, in, rem, tid, oct, incl, absent);
+    if (absent) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
+    if (lane == 63) {
+        sh.wtot[wv] = incl[0] & 0xFFFFu;
+        sh.wtot[4 + wv] = incl[0] >> 16;
+        sh.wtot[8 + wv] = incl[1] & 0xFFFFu;
+        sh.wtot[12 + wv] = incl[1] >> 16;
+    }
+    if (wv == 0 && ((u32)B & 31u) && nfull > 0) lead_bits(sh.lut, win, pv, (u32)B & 31u, lane);
+    __syncthreads();
+    const u32 T = tile_offsets(sh.wtot, lane, wv, roff);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) place<NW>(win, oct[k], roff[k] + ((incl[k >> 1] >> (16 * (k & 1))) & 0xFFFFu));
+    __syncthreads();
+    store_window(win, blk.out, blk.out_cap, blk.err, B, T, true, tid, E4_THREADS);
+    if (tid == 0) gstore<u64>(blk.out_n, (B + T + 7) >> 3);
 }
 
 template <int NW, bool L16>
-int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax)
+int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool any_ragged)
 {
-    static int wgs_per_cu = 0, cus = 0;
+    static int wgs_by_lmax[17], cus = 0;
     const u32 win_stride = ((u32)E4_GUARD + (u32)(((size_t)E4_TILE * lmax) >> 5) + 8u + 3u) & ~3u;     // dwords per buffer
-    const size_t dyn = (size_t)win_stride * 2 * 4;
-    if (!wgs_per_cu) {
+    const size_t dyn = (size_t)win_stride * 3 * 4;
+    if (!wgs_by_lmax[lmax]) {
         int dev = 0, occ = 0;
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         cus = prop.multiProcessorCount;
-        const size_t dyn_max = (((size_t)E4_GUARD + (((size_t)E4_TILE * 16) >> 5) + 8 + 3) & ~(size_t)3) * 2 * 4;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)sfe4_kernel<NW, L16>, E4_THREADS, dyn_max));
-        wgs_per_cu = occ < 1 ? 1 : (occ > 6 ? 6 : occ);
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)sfe4_kernel<NW, L16>, E4_THREADS, dyn));
+        wgs_by_lmax[lmax] = occ < 1 ? 1 : (occ > 6 ? 6 : occ);   // residency is a matter of speed only (tickets), 6 = what the registers allow
     }
+    const int wgs_per_cu = wgs_by_lmax[lmax];
     // the grid is a multiple of the number of concurrently served blocks, so a workgroup stays with one block
     int target = cus * wgs_per_cu;
     int nconc = count < target ? count : target;
@@ -360,18 +468,28 @@ int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 
     if (per < 1) per = 1;
     hipLaunchKernelGGL((sfe4_kernel<NW, L16>), dim3((u32)(nconc * per)), dim3(E4_THREADS), dyn, st, dblk, count, nconc, d_desc, d_tickets,
                        win_stride);
+    if (any_ragged)
+        hipLaunchKernelGGL((sfe4_tail_kernel<NW, L16>), dim3((u32)count), dim3(E4_THREADS), (size_t)win_stride * 4, st, dblk,
+                           (const u64 *)d_desc, win_stride);
     return SHAFA_SUCCESS;
 }
 
 }  // namespace
 
+#ifdef E4_STAMPS
+extern "C" int shafa_e4_read_stamps(unsigned long long *dst, int n)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(e4_stamp_buf), (size_t)n * 8) == hipSuccess ? 0 : 9;
+}
+#endif
+
 // launched from sfenc_launch (sf_encode.hip) for blocks whose codes are <= 16 bits when the launch holds enough blocks
 // to keep every chain short; desc (one u64 per tile) and tickets (one u32 per block) are zeroed by the caller;
 // tables are 256 x u64 {code, len}
-int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax)
+int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool any_ragged)
 {
-    if (lmax <= 8) return e4_launch_t<3, false>(st, dblk, count, d_desc, d_tickets, lmax);
-    if (lmax <= 12) return e4_launch_t<4, false>(st, dblk, count, d_desc, d_tickets, lmax);
-    if (lmax <= 15) return e4_launch_t<5, false>(st, dblk, count, d_desc, d_tickets, lmax);
-    return e4_launch_t<5, true>(st, dblk, count, d_desc, d_tickets, lmax);
+    if (lmax <= 8) return e4_launch_t<3, false>(st, dblk, count, d_desc, d_tickets, lmax, any_ragged);
+    if (lmax <= 12) return e4_launch_t<4, false>(st, dblk, count, d_desc, d_tickets, lmax, any_ragged);
+    if (lmax <= 15) return e4_launch_t<5, false>(st, dblk, count, d_desc, d_tickets, lmax, any_ragged);
+    return e4_launch_t<5, true>(st, dblk, count, d_desc, d_tickets, lmax, any_ragged);
 }
