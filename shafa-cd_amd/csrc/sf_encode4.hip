@@ -220,13 +220,22 @@ __device__ __forceinline__ void store_window(const u32 *pwin, u8 *out, u64 out_c
     u32 h = (u32)(0 - gd0) & 3u;                       // dwords up to the first 16-byte boundary
     if (h > count) h = count;
     const u32 nq = (count - h) >> 2;                   // aligned 16-byte pieces
+    // A 16-byte piece needs the five window dwords j-1 .. j+3, j = h + 4 q: every lane reads the two 16-byte aligned
+    // LDS pieces that hold them (conflict-free ds_read_b128; five ds_read_b32 at a 16-byte lane stride would be 4-way
+    // bank conflicts) and picks its five dwords by the uniform phase (h - 1) mod 4.
+    const u32 ph = (h + 3u) & 3u;                      // (j - 1) mod 4, the same for every piece of the tile
+    const uint4 *p4 = (const uint4 *)(pwin - 4) + ((h + 3u) >> 2);     // 16-byte piece that holds dword h - 1
     for (u32 q = (u32)tid; q < nq; q += nthreads) {
-        const u32 j = h + 4 * q;
-        const u32 w0 = pwin[(int)j - 1], w1 = pwin[j], w2 = pwin[j + 1], w3 = pwin[j + 2], w4 = pwin[j + 3];
-        gstore_nt_off<uint4>(o, 4 * j, make_uint4(bswap32(__builtin_amdgcn_alignbit(w0, w1, r)),
-                                                  bswap32(__builtin_amdgcn_alignbit(w1, w2, r)),
-                                                  bswap32(__builtin_amdgcn_alignbit(w2, w3, r)),
-                                                  bswap32(__builtin_amdgcn_alignbit(w3, w4, r))));
+        const uint4 a = p4[q], c = p4[q + 1];
+        u32 w0, w1, w2, w3, w4;
+        if (ph == 0) { w0 = a.x; w1 = a.y; w2 = a.z; w3 = a.w; w4 = c.x; }
+        else if (ph == 1) { w0 = a.y; w1 = a.z; w2 = a.w; w3 = c.x; w4 = c.y; }
+        else if (ph == 2) { w0 = a.z; w1 = a.w; w2 = c.x; w3 = c.y; w4 = c.z; }
+        else { w0 = a.w; w1 = c.x; w2 = c.y; w3 = c.z; w4 = c.w; }
+        gstore_nt_off<uint4>(o, 4 * (h + 4 * q), make_uint4(bswap32(__builtin_amdgcn_alignbit(w0, w1, r)),
+                                                            bswap32(__builtin_amdgcn_alignbit(w1, w2, r)),
+                                                            bswap32(__builtin_amdgcn_alignbit(w2, w3, r)),
+                                                            bswap32(__builtin_amdgcn_alignbit(w3, w4, r))));
     }
     const u32 t0 = h + 4 * nq;                         // tail dwords [t0, count)
     if ((u32)tid < 8) {
