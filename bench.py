@@ -179,9 +179,9 @@ class Comm:
         if ndev < 1:
             raise SystemExit("bench.py: no GPU visible (the HIP path has no CPU fallback)")
         self.backend = "nccl"
-        if self.local >= ndev:
+        if self.world > ndev:                  # decided from WORLD_SIZE, i.e. the same on every rank
             if not args.oversubscribe:
-                raise SystemExit(f"bench.py: rank {self.rank} needs GPU {self.local} but only {ndev} visible "
+                raise SystemExit(f"bench.py: {self.world} ranks but only {ndev} GPU(s) visible "
                                  "(--oversubscribe shares devices for plumbing tests only)")
             self.backend = "gloo"
         self.device_index = self.local % ndev

@@ -91,7 +91,7 @@ def test_scatter_hip_encode_gather_over_rccl(total, bs):
     assert q.get(timeout=5) is True
 
 
-def _bench(argv, timeout=600):
+def _bench(argv, timeout=240):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
