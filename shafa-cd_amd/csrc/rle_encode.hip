@@ -462,26 +462,8 @@ __device__ __forceinline__ bool rle_tile_fast(RleShared &sh, const RleBlk &blk, 
     return true;
 }
 
-__global__ __launch_bounds__(RLE_THREADS) void rle_encode_kernel(const RleBlk *__restrict__ blks, int nblk,
-                                                                 u64 *desc_run, u64 *desc_sum, u32 *tickets, u32 mode)
-{
-    __shared__ __attribute__((aligned(16))) RleShared sh;
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x % nblk;
-    const RleBlk blk = blks[b];
-    if ((u32)(blockIdx.x / nblk) >= blk.n_tiles) return;
-    if (tid == 0) sh.tile = atomicAdd(tickets + blk.ticket, 1u);
-    __syncthreads();
-    const int k = (int)sh.tile;
-    u64 *drun = desc_run + blk.desc_base, *dsum = desc_sum + blk.desc_base;
-    if (mode == 0 && rle_tile_fast(sh, blk, k, drun, dsum)) return;
-    __syncthreads();
-    rle_tile_general<0>(sh, blk, k, drun, dsum);
-}
-
-
 // ================================================================================================
-// Three independent passes (no tickets, no look-backs; default): every workgroup of every pass is independent.
+// Three independent passes (no tickets, no look-backs): every workgroup of every pass is independent.
 //   rle3_summary : per tile {is the whole tile one run that continues the previous byte, trailing run length}
 //   rle3_carry   : per block, segmented scan -> run length that ends at the last byte before every tile
 //   rle3_pass<1> : per tile, emitted bytes          rle3_offsets : per block, exclusive scan + block size
@@ -803,9 +785,7 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
     HIP_TRY(hipMemsetAsync(ws, 0, o_zero_end, st));
     HIP_TRY(hipMemsetAsync(d_out_n, 0, (size_t)nblocks * 8, st));      // empty blocks: size 0
     HIP_TRY(hipMemcpyAsync(ws + o_blk, hb, (size_t)nblocks * sizeof(RleBlk), hipMemcpyHostToDevice, st));
-    const char *venv = getenv("SHAFA_RLE_V");
-    const int rle_v = venv ? atoi(venv) : 3;               // 3 = three independent passes, 1 = single chained pass
-    if (max_tiles && rle_v == 3) {
+    if (max_tiles) {
         const RleBlk *dblk = (const RleBlk *)(ws + o_blk);
         const dim3 grid_t(max_tiles, (u32)nblocks), grid_b((u32)nblocks);
         u32 *tsum = (u32 *)(ws + o_tsum), *Rr = (u32 *)(ws + o_R), *Tt = (u32 *)(ws + o_T);
@@ -815,11 +795,6 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
         hipLaunchKernelGGL(rle3_pass<1>, grid_t, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Rr, Tt, (const u64 *)Gg);
         hipLaunchKernelGGL(rle3_offsets, grid_b, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Tt, Gg);
         hipLaunchKernelGGL(rle3_pass<2>, grid_t, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Rr, Tt, (const u64 *)Gg);
-        HIP_TRY(hipGetLastError());
-    } else if (max_tiles) {
-        hipLaunchKernelGGL(rle_encode_kernel, dim3(max_tiles * (u32)nblocks), dim3(RLE_THREADS), 0, st,
-                           (const RleBlk *)(ws + o_blk), nblocks, (u64 *)(ws + o_run), (u64 *)(ws + o_sum),
-                           (u32 *)(ws + o_tick), getenv("SHAFA_RLE_GENERAL") ? 1u : 0u);
         HIP_TRY(hipGetLastError());
     }
     if (d_freq) {   // make_freq of the RLE bytes (f.c:310): sizes are on the device

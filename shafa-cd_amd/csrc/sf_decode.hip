@@ -1552,9 +1552,9 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     u64 total_tiles = 0;
     size_t tab_bytes = 0;
     std::vector<u32> ntiles(nblocks, 0);
-    bool pair_all = !getenv("SHAFA_DEC_NOPAIR");
-    bool c16_all = !getenv("SHAFA_DEC_NOLONG");
-    bool c32_all = !getenv("SHAFA_DEC_NOLONG");
+    bool pair_all = true;
+    bool c16_all = true;
+    bool c32_all = true;
     for (int b = 0; b < nblocks; ++b) {
         if ((h_in_off[b] & 15) || (h_out_off[b] & 15)) return SHAFA_OUTSIDE_MODULE;
         build_host_tab(h_tables[b], tabs[b]);
@@ -1596,11 +1596,11 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const size_t o_ccnt = off; off += (size_t)total_tiles * DEC_THREADS * 2; off = (off + 15) & ~(size_t)15;
     const bool packed = (R == 16);
     // 13 < Lmax <= 16, complete codes: same kernels, the rare long codes resolved from a small LDS table
-    const bool long_all = packed && !pair_all && c16_all && lmax_all > (u32)LEN_MAXK && !getenv("SHAFA_DEC_GENERIC");
-    const bool fast13 = (lmax_all <= (u32)LEN_MAXK || long_all) && !getenv("SHAFA_DEC_GENERIC");   // LUT symbol passes
-    const bool multi = fast13 && (pair_all || long_all) && !getenv("SHAFA_DEC_NOMULTI");            // three codes per lookup
+    const bool long_all = packed && !pair_all && c16_all && lmax_all > (u32)LEN_MAXK;
+    const bool fast13 = (lmax_all <= (u32)LEN_MAXK || long_all);   // LUT symbol passes
+    const bool multi = fast13 && (pair_all || long_all);            // three codes per lookup
     // 16 < Lmax <= 32, complete codes: 32-entry byte maps with the fast DP / automaton / three-code passes
-    const bool mid32 = !packed && R == 32 && c32_all && !getenv("SHAFA_DEC_GENERIC");
+    const bool mid32 = !packed && R == 32 && c32_all;
     const bool need_tabs = pair_all || long_all || mid32;
     const size_t o_pair = off; off += pair_all ? (size_t)nblocks * (2u << LEN_MAXK) : 0;
     const size_t o_cnt3 = off; off += need_tabs ? (size_t)nblocks * (2u << LEN_MAXK) : 0;
@@ -1689,7 +1689,6 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const u32 l2cap = (max_l2 + 8) & ~7u;             // level-2 LDS entries reserved after level 1
     const dim3 grid_t(max_tiles, (u32)nblocks), grid_b((u32)nblocks);
     u32 tpw = 4;                                       // tiles per workgroup of the fast kernels (one table load)
-    if (const char *e = getenv("SHAFA_DEC_TPW")) tpw = (u32)atoi(e) > 0 ? (u32)atoi(e) : 1u;
     while (tpw > 1 && (u64)ceil_div_u64(max_tiles, tpw) * nblocks < 2048) tpw >>= 1;     // keep the chip full
     const dim3 grid_f((u32)ceil_div_u64(max_tiles, tpw), (u32)nblocks);
     constexpr int WSUBS = 2;                           // 256-lane groups per workgroup of sfd_write13
@@ -1720,12 +1719,8 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         hipLaunchKernelGGL(sfd_tiles16, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u64 *)(ws + o_tilefn),
                            ws + o_tent);
         if (fast13) {
-            if (multi && (long_all || !getenv("SHAFA_DEC_NOFSM")))
+            if (multi)
                 hipLaunchKernelGGL((sfd_countfsm<CSUBS>), grid_c, dim3(DEC_THREADS * CSUBS), 0, st, dblk,
-                                   (const u64 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
-                                   (u32 *)(ws + o_tcnt), tpw);
-            else if (multi)
-                hipLaunchKernelGGL(sfd_count13<true>, grid_f, dim3(DEC_THREADS), 0, st, dblk,
                                    (const u64 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
                                    (u32 *)(ws + o_tcnt), tpw);
             else
