@@ -46,28 +46,6 @@ __device__ __forceinline__ u64 desc_load(const u64 *p)
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 
-template <typename T>
-__device__ __forceinline__ T wave_incl_scan_add(T v)
-{
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        T t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
-
-template <typename T>
-__device__ __forceinline__ T wave_reduce_add(T v)
-{
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-
-__device__ __forceinline__ u32 bswap32(u32 x) { return __builtin_bswap32(x); }
-
 // inclusive add-scan over the 64 lanes of a wave with DPP: four row_shr steps inside the 16-lane rows, then the row
 // totals are broadcast into the following rows (row_bcast:15 -> rows 1,3; row_bcast:31 -> rows 2,3)
 __device__ __forceinline__ u32 dpp_scan_add(u32 v)
@@ -80,6 +58,32 @@ __device__ __forceinline__ u32 dpp_scan_add(u32 v)
     v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
     return v;
 }
+
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan_add(T v)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// 32-bit sums: six DPP adds instead of six LDS-routed shuffles
+template <>
+__device__ __forceinline__ u32 wave_incl_scan_add<u32>(u32 v) { return dpp_scan_add(v); }
+
+template <typename T>
+__device__ __forceinline__ T wave_reduce_add(T v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ u32 bswap32(u32 x) { return __builtin_bswap32(x); }
 
 // (hi:lo) >> sh, low 32 bits; sh in [0,31]
 __device__ __forceinline__ u32 funnel_r(u32 hi, u32 lo, u32 sh)

@@ -208,9 +208,11 @@ __global__ __launch_bounds__(ENC_THREADS) void sf_encode_generic(const EncBlk *_
 void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 *d_tile_bits, u64 *d_tile_off, bool lut64);
 int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool any_ragged);
 
-// A launch with at least this many class-1 blocks takes the one-pass encoder: every block is its own chain, and
-// with this many chains a tile's look-back stays within a few 64-entry windows (sf_encode4.hip).
-static int g_sfe4_min_blocks = 32;
+// A launch with at least this many class-1 blocks takes the one-pass encoder: every block is its own chain, and with this
+// many chains (<= ~10 workgroups per block) a tile's look-back stays inside one 64-entry descriptor window.  Measured
+// on 64 MiB Zipf blocks, GiB/s one-pass vs count/scan/pack: 16 blocks 588 / 1240, 32: 1112 / 1298, 64: 1407 / 1457,
+// 128: 1900 / 1632 (sf_encode4.hip).
+static int g_sfe4_min_blocks = 96;
 void sfenc_configure(int sfe4_min_blocks) { g_sfe4_min_blocks = sfe4_min_blocks; }
 
 static u32 code_value(const shafa_code_table &t, int s)

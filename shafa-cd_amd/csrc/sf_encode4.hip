@@ -8,7 +8,7 @@
 // here with a chained scan whose waiting never reaches the critical path:
 //
 //   * workgroups are persistent and stick to one block at a time (block = blockIdx % nconc, then + nconc): the
-//     block's look-up table is loaded once, and with >= 32 blocks per launch every block is a separate chain with
+//     block's look-up table is loaded once, and with >= 96 blocks per launch every block is a separate chain with
 //     only a handful of tiles in flight, so a look-back is one 64-entry window;
 //   * tiles of a block are handed out by a per-block ticket (atomicAdd), requested three iterations ahead: a tile's
 //     predecessors were always taken by workgroups that are running, so the chain cannot deadlock whatever part
