@@ -59,6 +59,12 @@ typedef struct shafa_code_table {
 int shafa_hip_abi_version(void);
 int shafa_hip_device_count(void);            /* 0 when no GPU is visible; never fails */
 int shafa_hip_init(int device);              /* select device, create the library's stream/workspace */
+/* Select the devices of the block pipeline (layer 3): slot i of every pipe created afterwards lives on
+ * devices[i % n_devices] (its stream, buffers and kernels), so the blocks of one file are spread over the GPUs of the
+ * node while the caller still retires them in order (multithread.c:70-87).  Layers 1 and 2 use devices[0].
+ * n_devices == 0 selects every visible device.  Returns SHAFA_OUTSIDE_MODULE for an invalid device number. */
+int shafa_hip_init_devices(const int *devices, int n_devices);
+int shafa_hip_devices(void);                 /* number of devices selected for layer 3 (1 until shafa_hip_init_devices) */
 void shafa_hip_shutdown(void);
 const char *shafa_hip_last_error(void);      /* text of the last SHAFA_DEVICE_ERROR */
 
@@ -181,6 +187,7 @@ typedef struct shafa_pipe_result {
 int shafa_pipe_create(int n_slots, shafa_pipe **out);
 void shafa_pipe_destroy(shafa_pipe *p);
 int shafa_pipe_slots(const shafa_pipe *p);
+int shafa_pipe_slot_device(const shafa_pipe *p, int slot);      /* the device the slot's work runs on */
 
 /* Pinned input buffer of an idle slot, grown to hold `bytes`; NULL if the slot is busy or on failure. */
 uint8_t *shafa_pipe_in(shafa_pipe *p, int slot, size_t bytes);

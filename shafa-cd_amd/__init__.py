@@ -105,6 +105,11 @@ def lib():
     L.shafa_pipe_destroy.argtypes = [vp]
     L.shafa_pipe_destroy.restype = None
     L.shafa_pipe_slots.argtypes = [vp]
+    L.shafa_pipe_slot_device.argtypes = [vp, C.c_int]
+    L.shafa_pipe_slot_device.restype = C.c_int
+    L.shafa_hip_init_devices.argtypes = [C.POINTER(C.c_int), C.c_int]
+    L.shafa_hip_init_devices.restype = C.c_int
+    L.shafa_hip_devices.restype = C.c_int
     L.shafa_pipe_in.argtypes = [vp, C.c_int, C.c_size_t]
     L.shafa_pipe_in.restype = C.c_void_p
     L.shafa_pipe_submit.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, tp, C.c_size_t, C.c_size_t, C.c_int]
@@ -119,6 +124,16 @@ def lib():
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
+
+
+def init_devices(devices=None):
+    """Select the GPUs of the layer-3 pipeline (None: every visible device); include/shafa_hip.h: shafa_hip_init_devices."""
+    if devices:
+        arr = (C.c_int * len(devices))(*devices)
+        _check(lib().shafa_hip_init_devices(arr, len(devices)), "init_devices")
+    else:
+        _check(lib().shafa_hip_init_devices(None, 0), "init_devices")
+    return lib().shafa_hip_devices()
 
 
 def set_option(name, value):
@@ -282,6 +297,7 @@ class Pipe:
         self._h = C.c_void_p()
         _check(lib().shafa_pipe_create(n_slots, C.byref(self._h)), "pipe_create")
         self.n_slots = lib().shafa_pipe_slots(self._h)
+        self.devices = [lib().shafa_pipe_slot_device(self._h, i) for i in range(self.n_slots)]
 
     def close(self):
         if self._h:

@@ -242,6 +242,9 @@ static struct {
     u64 *d_small;                // 256 u64 histogram + 1 u64 size
 } g;
 
+static int g_devs[64];
+static int g_ndevs = 0;                     // 0: layer 3 uses the layer-1 device only
+
 static int ensure_dev(u8 **p, size_t *cap, size_t bytes)
 {
     if (bytes <= *cap) return SHAFA_SUCCESS;
@@ -286,7 +289,29 @@ void shafa_hip_shutdown(void)
     if (g.d_small) hipFree(g.d_small);
     hipStreamDestroy(g.stream);
     memset(&g, 0, sizeof(g));
+    g_ndevs = 0;
 }
+
+
+int shafa_hip_init_devices(const int *devices, int n_devices)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        snprintf(g_last_error, sizeof(g_last_error), "no HIP device visible");
+        return SHAFA_DEVICE_ERROR;
+    }
+    if (n_devices < 0 || n_devices > 64 || (n_devices && !devices)) return SHAFA_OUTSIDE_MODULE;
+    int list[64], m = 0;
+    if (n_devices == 0) { for (; m < n && m < 64; ++m) list[m] = m; }
+    else for (; m < n_devices; ++m) { if (devices[m] < 0 || devices[m] >= n) return SHAFA_OUTSIDE_MODULE; list[m] = devices[m]; }
+    int rc = shafa_hip_init(list[0]);
+    if (rc) return rc;
+    memcpy(g_devs, list, sizeof(int) * (size_t)m);
+    g_ndevs = m;
+    return SHAFA_SUCCESS;
+}
+
+int shafa_hip_devices(void) { return g_ndevs ? g_ndevs : 1; }
 
 static int lazy_init(void) { return g.ready ? SHAFA_SUCCESS : shafa_hip_init(0); }
 
@@ -389,3 +414,4 @@ int shafa_hip_rle_decode(const uint8_t *in, size_t in_n, uint8_t *out, size_t ou
 }  // extern "C"
 
 int api_lazy_init() { return lazy_init(); }     // layer 3 (pipe.hip)
+int api_pipe_device(int slot) { return g_ndevs ? g_devs[slot % g_ndevs] : g.device; }

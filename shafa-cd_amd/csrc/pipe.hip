@@ -14,10 +14,12 @@
 
 int shafa_set_hip_error(hipError_t e, const char *what);
 int api_lazy_init();      // api.hip: shafa_hip_init(0) unless a device was selected already
+int api_pipe_device(int slot);     // api.hip: device of pipe slot `slot` (shafa_hip_init_devices), else the layer-1 device
 
 namespace {
 
 struct Slot {
+    int device;                // the slot's stream, buffers and kernels live here
     hipStream_t st;
     Batch *batch;
     u8 *h_in, *h_out;          // pinned
@@ -46,7 +48,7 @@ int grow_pinned(u8 **p, size_t *cap, size_t need)
     if (need <= *cap) return SHAFA_SUCCESS;
     if (*p) { HIP_TRY(hipHostFree(*p)); *p = nullptr; *cap = 0; }
     const size_t want = (need + 4095) & ~(size_t)4095;
-    HIP_TRY(hipHostMalloc((void **)p, want, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)p, want, hipHostMallocPortable));       // pinned for every device of the pipe
     *cap = want;
     return SHAFA_SUCCESS;
 }
@@ -64,6 +66,7 @@ int grow_dev(u8 **p, size_t *cap, size_t need)
 int slot_submit(Slot &s, const shafa_code_table *table)
 {
     int rc;
+    HIP_TRY(hipSetDevice(s.device));
     const u64 off0[1] = {0}, in_n[1] = {s.in_n};
     if ((rc = grow_dev(&s.d_in, &s.d_in_cap, s.in_n))) return rc;
     if (s.in_n) HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, s.in_n, hipMemcpyHostToDevice, s.st));
@@ -144,13 +147,16 @@ int shafa_pipe_create(int n_slots, shafa_pipe **out)
     for (int i = 0; i < n_slots; ++i) {
         Slot &s = p->slots[i];
         shafa_hipd_batch *bh = nullptr;
-        hipError_t e = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking);
+        s.device = api_pipe_device(i);
+        hipError_t e = hipSetDevice(s.device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc((void **)&s.d_small, 514 * sizeof(u64));
-        if (e == hipSuccess) e = hipHostMalloc((void **)&s.h_small, 514 * sizeof(u64), hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s.h_small, 514 * sizeof(u64), hipHostMallocPortable);
         if (e != hipSuccess) { shafa_pipe_destroy(p); return shafa_set_hip_error(e, "shafa_pipe_create"); }
         if ((rc = shafa_hipd_batch_create(1, (size_t)1 << 27, &bh))) { shafa_pipe_destroy(p); return rc; }
         s.batch = (Batch *)bh;
     }
+    (void)hipSetDevice(api_pipe_device(0));
     *out = p;
     return SHAFA_SUCCESS;
 }
@@ -158,9 +164,10 @@ int shafa_pipe_create(int n_slots, shafa_pipe **out)
 void shafa_pipe_destroy(shafa_pipe *p)
 {
     if (!p) return;
-    hipDeviceSynchronize();
     for (int i = 0; i < p->n_slots; ++i) {
         Slot &s = p->slots[i];
+        (void)hipSetDevice(s.device);
+        if (s.st) (void)hipStreamSynchronize(s.st);
         if (s.batch) shafa_hipd_batch_destroy((shafa_hipd_batch *)s.batch);
         if (s.h_in) hipHostFree(s.h_in);
         if (s.h_out) hipHostFree(s.h_out);
@@ -171,11 +178,13 @@ void shafa_pipe_destroy(shafa_pipe *p)
         if (s.h_small) hipHostFree(s.h_small);
         if (s.st) hipStreamDestroy(s.st);
     }
+    (void)hipSetDevice(api_pipe_device(0));
     free(p->slots);
     free(p);
 }
 
 int shafa_pipe_slots(const shafa_pipe *p) { return p ? p->n_slots : 0; }
+int shafa_pipe_slot_device(const shafa_pipe *p, int slot) { return (p && slot >= 0 && slot < p->n_slots) ? p->slots[slot].device : -1; }
 
 uint8_t *shafa_pipe_in(shafa_pipe *p, int slot, size_t bytes)
 {
@@ -208,6 +217,7 @@ int shafa_pipe_wait(shafa_pipe *p, int slot, shafa_pipe_result *res)
     if (!s.busy) return SHAFA_OUTSIDE_MODULE;
     s.busy = false;
     memset(res, 0, sizeof(*res));
+    HIP_TRY(hipSetDevice(s.device));
     int rc = shafa_hipd_finish((shafa_hipd_batch *)s.batch, s.st, 1, nullptr);   // synchronises the slot's stream
     if (s.rc) return s.rc;
     if (rc) return rc;

@@ -39,8 +39,15 @@ static void trace(const char *what, double t0)
     if (on) fprintf(stderr, "[trace] %-28s %9.2f ms\n", what, ts.tv_sec * 1e3 + ts.tv_nsec / 1e6 - t0);
 }
 
-enum { PIPE_SLOTS = 3 };
-static int pipe_depth(void) { return NO_MULTITHREAD ? 1 : PIPE_SLOTS; }
+enum { PIPE_SLOTS_PER_DEVICE = 3, PIPE_SLOTS = 64 };        /* PIPE_SLOTS: upper bound (ticket arrays) */
+/* three blocks in flight per selected GPU (shafa_hip_init_devices): slot i works on device i mod n, results are retired
+ * in submission order by the one writer thread as before */
+static int pipe_depth(void)
+{
+    if (NO_MULTITHREAD) return 1;
+    const int d = PIPE_SLOTS_PER_DEVICE * shafa_hip_devices();
+    return d > PIPE_SLOTS ? PIPE_SLOTS : d;
+}
 
 /* ------------------------------------------------------------------ ordered writer
  * The reference's write callbacks run in block order on the worker threads (multithread.c:75-86).

@@ -143,6 +143,20 @@ int main(int argc, char *const argv[])
     }
     if (!o.block_size) o.block_size = SHAFA_64KiB;  /* shafa.c:304-305 */
 
+    /* The reference's -m f/c/d start one thread per block on the host's cores; here the blocks of a file go to every
+     * GPU of the node (three in flight per GPU, retired in order).  SHAFA_DEVICES="0,2,3" restricts the set. */
+    {
+        int devs[64], nd = 0;
+        const char *e = getenv("SHAFA_DEVICES");
+        for (const char *q = e; q && *q && nd < 64;) {
+            char *end = NULL;
+            const long v = strtol(q, &end, 10);
+            if (end == q) break;
+            devs[nd++] = (int)v;
+            q = (*end == ',') ? end + 1 : end;
+        }
+        if (nd > 0 || shafa_hip_device_count() > 1) (void)shafa_hip_init_devices(devs, nd);    /* errors surface in the modules */
+    }
     const int err = run_modules(&o, &file);
     free(file);
     shafa_hip_shutdown();

@@ -113,3 +113,31 @@ def test_pipe_errors_surface_at_wait_in_block_order(oracle, shafa):
     rc, _, _ = pipe.wait(0, raw_rc=True)
     assert rc == shafa.OUTSIDE_MODULE
     pipe.close()
+
+
+def test_pipe_slots_spread_over_the_selected_devices(oracle, shafa):
+    """shafa_hip_init_devices: slot i of a pipe lives on devices[i % n] (SURVEY.md §8(b) "init(device list)").  On a
+    one-GPU box the list names device 0 twice, which still takes the per-slot device path; results stay bit-exact and
+    in submission order."""
+    import torch
+    n = torch.cuda.device_count()
+    devs = list(range(n)) if n > 1 else [0, 0]
+    assert shafa.init_devices(devs) == len(devs)
+    try:
+        pipe = shafa.Pipe(3 * len(devs))
+        assert pipe.devices == [devs[i % len(devs)] for i in range(pipe.n_slots)]
+        blocks = blocks_of(oracle, shafa, 2 * pipe.n_slots + 1, 200000)
+        sub = ret = 0
+        while ret < len(blocks):
+            if sub < len(blocks) and sub - ret < pipe.n_slots:
+                pipe.submit(sub % pipe.n_slots, shafa.OP_RLE_ENCODE, blocks[sub])
+                sub += 1
+            else:
+                rc, out, r = pipe.wait(ret % pipe.n_slots)
+                want = oracle.rle_encode(blocks[ret])
+                assert out == want.tobytes() and list(r.freq) == list(oracle.hist256(want)), f"block {ret}"
+                ret += 1
+        pipe.close()
+    finally:
+        shafa.init_devices([0])
+    assert shafa.lib().shafa_hip_init_devices((__import__("ctypes").c_int * 1)(99), 1) == shafa.OUTSIDE_MODULE
