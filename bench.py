@@ -394,7 +394,7 @@ def main():
     dec_gbs = alg / dec_t / 1e9 if have_decode else None
     # HBM traffic per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_traffic.sh,
     # gfx950 FETCH correction applied) on this workload AND this csrc hash; null when no matching profile exists.
-    wkey = f"{args.dist}:{args.zipf_s:g}:{args.block_mib}"
+    wkey = f"{args.dist}:{args.zipf_s:g}:{args.block_mib}:{args.blocks}"
     traffic = {"sf_encode": None, "sf_decode": None}
     tsrc = None
     m = measured_traffic(wkey)

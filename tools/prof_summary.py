@@ -101,13 +101,14 @@ if total_in:
     dec = sum(r + w for k, (r, w) in per.items() if k.startswith("sfd"))
     ratio = bench["config"]["compressed_ratio"]
     print(f"\n## bytes per input byte: sf_encode {enc / total_in:.3f}  sf_decode {dec / total_in:.3f}  (algorithmic {1 + ratio:.3f})")
-    a = {"--dist": "zipfmod", "--zipf-s": "1.2", "--block-mib": "64"}
+    a = {"--dist": "zipfmod", "--zipf-s": "1.2", "--block-mib": "64", "--blocks": "128"}
     for i, x in enumerate(args):
         if x in a and i + 1 < len(args):
             a[x] = args[i + 1]
     j = {"what": "HBM traffic from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, tools/gpu_prof.sh); "
                  "FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes",
-         "workload_key": f"{a['--dist']}:{float(a['--zipf-s']):g}:{a['--block-mib']}", "bench_args": args, "csrc_sha256": csrc_hash(),
+         "workload_key": f"{a['--dist']}:{float(a['--zipf-s']):g}:{a['--block-mib']}:{a['--blocks']}" + (":pipeline" if "--pipeline" in args else ""),
+         "bench_args": args, "csrc_sha256": csrc_hash(),
          "bytes_per_input_byte": {"sf_encode": enc / total_in if enc else None, "sf_decode": dec / total_in if dec else None},
          "algorithmic_bytes_per_input_byte": 1 + ratio,
          "per_kernel_bytes": {k: {"read": r, "written": w} for k, (r, w) in per.items() if r + w > 1e6}}
