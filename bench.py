@@ -186,11 +186,12 @@ class Comm:
             self.backend = "gloo"
         self.device_index = self.local % ndev
         self.oversubscribed = self.backend == "gloo"
+        self.dev = torch.device("cuda", self.device_index)
+        torch.cuda.set_device(self.dev)               # before the process group: RCCL binds to the current device
         if self.world > 1 or args.scatter_gather:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
             dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
-        self.dev = torch.device("cuda", self.device_index)
 
     def barrier(self):
         if self.world > 1:
@@ -411,37 +412,42 @@ def main():
     # ---- root-scatter-included encode: always at N>1, never part of `value` --------
     sg = None
     if ((world > 1 and not args.no_scatter_gather) or args.scatter_gather) and not comm.oversubscribed:
-        shd = pkgload.load_submodule("sharding")
-        sg_nb = min(nb, 16)                               # bounded: the root holds world * sg_nb blocks
-        sg_shard = sg_nb * bs
-        total_all = world * sg_shard
-        src = None
-        if rank == 0:                                     # the reader rank holds the whole stream
-            src = torch.empty(total_all, dtype=torch.uint8, device=dev)
-            for r in range(world):                        # rank r's first sg_nb blocks, as resident on rank r
-                pkg.gen_bytes(None, SEED, r * shard, src[r * sg_shard:(r + 1) * sg_shard], sg_shard, d_map)
-        torch.cuda.synchronize()
-        comm.barrier()
-        t0 = time.perf_counter()
-        local, first_blk, sizes = shd.scatter_blocks(src, total_all, bs, dev)              # X1
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        bt.sf_encode(st, local, in_off[:sg_nb], in_n[:sg_nb], tables[:sg_nb], d_enc, out_off[:sg_nb], out_cap[:sg_nb],
-                     d_enc_n)                                            # same tables: same stream
-        bt.finish(st, sg_nb)
-        t2 = time.perf_counter()
-        got = shd.gather_payloads(d_enc, out_off[:sg_nb], [int(x) for x in enc_bytes[:sg_nb]], world * sg_nb, dev)   # X2
-        torch.cuda.synchronize()
-        comm.barrier()
-        t3 = time.perf_counter()
-        assert torch.equal(local, d_in[:sg_shard]), "scattered shard differs from the resident one"
-        if rank == 0:
+        def scatter_gather_leg():
+            shd = pkgload.load_submodule("sharding")
+            sg_nb = min(nb, 16)                               # bounded: the root holds world * sg_nb blocks
+            sg_shard = sg_nb * bs
+            total_all = world * sg_shard
+            src = None
+            if rank == 0:                                     # the reader rank holds the whole stream
+                src = torch.empty(total_all, dtype=torch.uint8, device=dev)
+                for r in range(world):                        # rank r's first sg_nb blocks, as resident on rank r
+                    pkg.gen_bytes(None, SEED, r * shard, src[r * sg_shard:(r + 1) * sg_shard], sg_shard, d_map)
+            torch.cuda.synchronize()
+            comm.barrier()
+            t0 = time.perf_counter()
+            local, first_blk, sizes = shd.scatter_blocks(src, total_all, bs, dev)              # X1
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            bt.sf_encode(st, local, in_off[:sg_nb], in_n[:sg_nb], tables[:sg_nb], d_enc, out_off[:sg_nb], out_cap[:sg_nb],
+                         d_enc_n)                                            # same tables: same stream
+            bt.finish(st, sg_nb)
+            t2 = time.perf_counter()
+            got = shd.gather_payloads(d_enc, out_off[:sg_nb], [int(x) for x in enc_bytes[:sg_nb]], world * sg_nb, dev)   # X2
+            torch.cuda.synchronize()
+            comm.barrier()
+            t3 = time.perf_counter()
+            assert torch.equal(local, d_in[:sg_shard]), "scattered shard differs from the resident one"
+            if rank != 0:
+                return None
             assert len(got) == world * sg_nb and all(g is not None for g in got)
-            sg = {"blocks_per_gpu": sg_nb, "backend": comm.backend,
-                  "x1_scatter_ms": (t1 - t0) * 1e3, "encode_ms": (t2 - t1) * 1e3, "x2_gather_ms": (t3 - t2) * 1e3,
-                  "encode_GiBs_resident_sharded": total_all / GIB / (t2 - t1),
-                  "encode_GiBs_root_scatter_gather_included": total_all / GIB / (t3 - t0)}
-        del src, local, got
+            return {"blocks_per_gpu": sg_nb, "backend": comm.backend,
+                    "x1_scatter_ms": (t1 - t0) * 1e3, "encode_ms": (t2 - t1) * 1e3, "x2_gather_ms": (t3 - t2) * 1e3,
+                    "encode_GiBs_resident_sharded": total_all / GIB / (t2 - t1),
+                    "encode_GiBs_root_scatter_gather_included": total_all / GIB / (t3 - t0)}
+        try:
+            sg = scatter_gather_leg()
+        except Exception as e:                             # the headline line must not depend on the X1/X2 leg
+            sg = {"error": f"{type(e).__name__}: {e}"[:300]} if rank == 0 else None
         encode()                                           # restore d_enc for anything that follows
         bt.finish(st, nb)
 

@@ -154,3 +154,14 @@ def test_one_pass_error_semantics(shafa, oracle, one_pass):
     caps = [((w + 15) // 16 + 1) * 16 for w in want_sizes]
     caps[4] = (want_sizes[4] // 2) // 16 * 16                      # half of what block 4 needs
     run_batch(shafa, oracle, blocks, tables, caps=caps, expect_err={2: shafa.FILE_UNRECOGNIZABLE, 4: shafa.LACK_OF_MEMORY})
+
+
+def test_one_pass_more_blocks_than_workgroups(shafa, oracle):
+    """1300 small blocks in one launch: more blocks than the persistent grid has workgroups (1024), so workgroups move on
+    to a second block (table reload, pipeline drain and restart); sizes around the tile size, default dispatch."""
+    sizes = [8192 * (1 + i % 4) + (i * 37) % 8192 for i in range(1300)]
+    sizes[7] = 8192
+    sizes[8] = 5
+    blocks, tables = zipf_blocks(shafa, oracle, sizes, seed0=3000)
+    shafa.lib().shafa_hip_init(0)
+    run_batch(shafa, oracle, blocks, tables)
