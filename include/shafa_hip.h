@@ -71,7 +71,10 @@ const char *shafa_hip_last_error(void);      /* text of the last SHAFA_DEVICE_ER
 /* Tuning knobs (no reference counterpart).  Unknown names return SHAFA_OUTSIDE_MODULE.
  *   "sf_encode_one_pass_min_blocks": a shafa_hipd_sf_encode launch with at least this many blocks of <= 16-bit
  *       codes takes the one-pass encoder, smaller launches the count/scan/pack kernels (default 96).
- * shafa_hip_init() reads the environment variable SHAFA_SF_ENCODE_ONE_PASS_MIN_BLOCKS once for the same knob. */
+ *   "sf_decode_speculate": 1 (default) lets blocks whose code re-synchronises take the speculative entry kernels of
+ *       the Shannon-Fano decoder (verified exactly; falls back to the exact kernels per block), 0 = exact kernels only.
+ * shafa_hip_init() reads the environment variables SHAFA_SF_ENCODE_ONE_PASS_MIN_BLOCKS and SHAFA_SF_DECODE_SPECULATE
+ * once for the same knobs. */
 int shafa_hip_set_option(const char *name, long value);
 
 /* ------------------------------------------------------------------ layer 1: host buffers, one block */

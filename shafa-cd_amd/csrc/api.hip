@@ -115,6 +115,10 @@ int shafa_hip_set_option(const char *name, long value)
         sfenc_configure(value < 1 ? 1 : (value > (1 << 30) ? (1 << 30) : (int)value));
         return SHAFA_SUCCESS;
     }
+    if (name && !strcmp(name, "sf_decode_speculate")) {
+        sfdec_configure(value != 0);
+        return SHAFA_SUCCESS;
+    }
     return SHAFA_OUTSIDE_MODULE;
 }
 
@@ -268,6 +272,7 @@ int shafa_hip_init(int device)
     if (device < 0 || device >= n) return SHAFA_OUTSIDE_MODULE;
     HIP_TRY(hipSetDevice(device));
     if (const char *e = getenv("SHAFA_SF_ENCODE_ONE_PASS_MIN_BLOCKS")) shafa_hip_set_option("sf_encode_one_pass_min_blocks", atol(e));
+    if (const char *e = getenv("SHAFA_SF_DECODE_SPECULATE")) shafa_hip_set_option("sf_decode_speculate", atol(e));
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     shafa_hipd_batch *bh = nullptr;
     int rc = shafa_hipd_batch_create(1, (size_t)1 << 27, &bh);

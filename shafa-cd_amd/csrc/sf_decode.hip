@@ -75,7 +75,15 @@ struct DecBlk {
     const u8 *lenlut32;    // 2^13 entries: len <= 13, or 128 + k = internal node root13[k] of long32 (16 < Lmax <= 32 launches)
     const u16 *long32;     // LONG32_BYTES: sorted 12-bit prefixes of the codes of 13..32 bits + their sub-tries
     const u16 *longtab;    // LONG_BYTES: sorted 12-bit prefixes of the codes of 13..16 bits + 16 entries sym | len << 8 each
+    u32 *run_dp;           // speculative launches: *run_dp != 0 <=> the block needs the exact (DP) kernels: it was not
+                           //   tried speculatively or did not verify; NULL: no speculation, the DP kernels always run
 };
+
+// the exact kernels of a launch that also runs the speculative ones: skip the blocks that verified
+__device__ __forceinline__ bool dp_skipped(const DecBlk &blk)
+{
+    return blk.run_dp && __hip_atomic_load(blk.run_dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+}
 
 // stream words are kept big-endian in LDS, one pad word per 8 (chunk stride 9 words: no bank conflicts)
 __device__ __forceinline__ u32 widx(u32 w) { return w + (w >> 3); }
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_sync16(const DecBlk *__restri
     // static LDS: constant addresses fold into the ds_read offset field (no per-lookup address add)
     __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + (PAIR ? 2 : 1) * (1 << LEN_MAXK) + DEC_THREADS * 8 + 64 + (LONG ? LONG_BYTES : 0)];
     const DecBlk blk = blks[blockIdx.y];
-    if (blockIdx.x * tpw >= blk.n_tiles) return;
+    if (blockIdx.x * tpw >= blk.n_tiles || dp_skipped(blk)) return;
     u32 *data = (u32 *)smem;
     u8 *lenlut = smem + LDS_DATA;
     u64 *cmap = (u64 *)(lenlut + (PAIR ? 2u : 1u) * (1u << LEN_MAXK));
@@ -733,6 +741,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tiles16(const DecBlk *__restr
     __shared__ u8 segmap[16 * 16], segent[16];
     __shared__ u32 carry;
     const DecBlk blk = blks[blockIdx.x];
+    if (dp_skipped(blk)) return;
     const u32 tid = threadIdx.x, sg = tid >> 4, d = tid & 15u;
     if (tid == 0) carry = 0;
     for (u32 t0 = 0; t0 < blk.n_tiles; t0 += TB) {
@@ -1067,7 +1076,7 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) __attribute__((amdgpu_waves_per
     __shared__ __attribute__((aligned(16))) u8 smem[SUBS * PER_SUB + 16384 + 2048 + 64];
     const DecBlk blk = blks[blockIdx.y];
     const u32 first_tile = blockIdx.x * tpw * SUBS;
-    if (first_tile >= blk.n_tiles) return;
+    if (first_tile >= blk.n_tiles || dp_skipped(blk)) return;
     const u32 sub = threadIdx.x >> 8, tid = threadIdx.x & 255u, lane = tid & 63, wv = tid >> 6;
     u8 *mine = smem + sub * PER_SUB;
     u32 *data = (u32 *)mine;
@@ -1137,6 +1146,175 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) __attribute__((amdgpu_waves_per
     __syncthreads();
     if (active && tid == 0) tile_cnt[gt] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
+}
+
+// ================================================================================================
+// Speculative chunk entries for self-synchronising codes (complete codes, Lmax <= 13), verified exactly.
+//
+// The packed DP above prices every bit position (6.7 VALU per bit) to be exact for ANY code.  Shannon-Fano codes of
+// skewed data re-synchronise: a decoder started at an arbitrary bit agrees with the true parse after a few dozen bits
+// (measured: started 256 bits early it is off at the chunk boundary in 0.2 % of the chunks of Zipf(1.2) mod 256 data,
+// 0.02 % for Zipf truncated to 256 ranks, 85 % for uniform bytes, whose 8/9-bit codes never merge).  So every lane
+//   1. walks the chunk BEFORE its own from that chunk's first bit (three codes per look-up, cnt3), which leaves it at
+//      its guess of its own entry, then walks its own chunk, counting the codes that start there, to its exit;
+//   2. compares its guess with the exit of the lane before it; lanes that differ take that exit as their entry and walk
+//      their own chunk again (a few rounds: a repaired lane's exit almost never moves).
+// A tile's first lane guesses from the last chunk of the previous tile; sfd_spec_check compares every tile's guess with
+// the previous tile's exit and sfd_spec<true> redoes the tiles that differ with the entry forced.  When every
+// comparison of a block holds — entry(c) == exit(c-1) for all chunks, entry 0 at the block's first bit — the entries
+// ARE the true parse, by induction: nothing is approximate.  A block that does not get there in the fixed number of
+// rounds sets *run_dp and goes through the exact kernels, which skip the blocks that verified; which blocks try at all
+// is decided per table on the host (spec_worthwhile()).  Outputs are those of sfd_countfsm.
+// static LDS: stream of the tile with 32 bytes in front (as load_tile: big-endian words, one pad word per 8) | cnt3 | exits
+// ================================================================================================
+constexpr int SPEC_PRE_WORDS = 8;                  // 256 bits in front of the tile: the first lane's run-up
+constexpr int SPEC_WORDS = SPEC_PRE_WORDS + DATA_WORDS;
+constexpr int SPEC_LDS_DATA = (SPEC_WORDS + SPEC_WORDS / 8 + 8) * 4;
+
+// one walk: from bit p (a code start, by assumption) to the first code start >= b; counts the codes started on the way.
+// LAST: the stream ends at bit `limit` of this frame; a code that does not end inside the stream is not a symbol.
+template <bool LAST>
+__device__ __forceinline__ void spec_walk(const u32 *data, const u16 *tab, u32 K1, u32 &p, BitBuf &bb, u32 b, u32 limit, u32 &cnt)
+{
+    const u32 sh = 32 - K1;
+    if (!LAST) {
+        while (p + K1 <= b) {                           // the window holds only codes that start before b
+            const u32 e = tab[bb.peek32() >> sh];
+            p += e & 15u;
+            cnt += e >> 12;
+            bb.skip(data, e & 15u);
+        }
+    }
+    while (p < b) {
+        const u32 l0 = (tab[bb.peek32() >> sh] >> 4) & 15u;
+        if (LAST && p + l0 > limit) { p = b + 15u; break; }      // cut by the end of the stream: nothing starts after it
+        p += l0;
+        ++cnt;
+        bb.skip(data, l0);
+    }
+}
+
+template <bool FIX>
+__global__ __launch_bounds__(DEC_THREADS) void sfd_spec(const DecBlk *__restrict__ blks, u8 *__restrict__ chunk_entry,
+                                                        u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt,
+                                                        u8 *__restrict__ tile_guess, u8 *__restrict__ tile_exit,
+                                                        const u8 *__restrict__ tile_fix, u32 tpw)
+{
+    __shared__ __attribute__((aligned(16))) u8 smem[SPEC_LDS_DATA + (2 << LEN_MAXK) + DEC_THREADS + 16 + 64];
+    const DecBlk blk = blks[blockIdx.y];
+    if (blockIdx.x * tpw >= blk.n_tiles) return;
+    if (!blk.run_dp || __hip_atomic_load(blk.run_dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // exact path
+    u32 *data = (u32 *)smem;
+    const u16 *tab = (const u16 *)(smem + SPEC_LDS_DATA);
+    u8 *ex = smem + SPEC_LDS_DATA + (2 << LEN_MAXK);
+    u32 *wsum = (u32 *)(ex + DEC_THREADS);
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 K1 = blk.K1;
+    bool table_loaded = false;
+    const u32 tile_end = (blockIdx.x + 1) * tpw < blk.n_tiles ? (blockIdx.x + 1) * tpw : blk.n_tiles;
+    for (u32 tile = blockIdx.x * tpw; tile < tile_end; ++tile) {
+        const size_t gt = (size_t)blk.tile_base + tile;
+        if (FIX && !tile_fix[gt]) continue;             // uniform
+        if (!table_loaded) { fill_lds16((void *)tab, (const void *)blk.cnt3, 2u << K1); table_loaded = true; }
+        __syncthreads();                                // the previous tile's LDS reads are done
+        {   // the tile's stream from 32 bytes before it: frame bit 0 = stream bit 8 * (tile * DTILE - 32)
+            const long long base = (long long)tile * DTILE - 4 * SPEC_PRE_WORDS;
+            for (u32 i = tid; i < SPEC_WORDS / 4; i += DEC_THREADS) {
+                const long long off = base + (long long)i * 16;
+                u32 w[4] = {0, 0, 0, 0};
+                if (off >= 0 && (u64)off + 16 <= blk.in_n) {
+                    const uint4 v = gload<uint4>(blk.in + off);
+                    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+                } else if (off >= 0 && (u64)off < blk.in_n) {
+                    const int nv = (int)(blk.in_n - (u64)off);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        if (q < nv) w[q >> 2] |= (u32)gload<u8>(blk.in + off + q) << (8 * (q & 3));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) data[widx(4 * i + q)] = bswap32(w[q]);
+            }
+        }
+        __syncthreads();
+        // frame bits: chunk `tid` = [256 (tid + 1), 256 (tid + 2)); the stream ends at frame bit `limit`
+        const u64 start = (u64)tile * DTILE;
+        const u64 left = blk.in_n > start ? blk.in_n - start : 0;
+        const u64 capb = (u64)DTILE + HALO_WORDS * 4;
+        const u32 limit = 256u + (u32)((left < capb ? left : capb) * 8);
+        const bool last = left < capb;                  // the stream ends inside this frame
+        const u32 b1 = 256u * (tid + 1), b2 = b1 + 256u;
+        u32 p, entry, cnt = 0, dummy = 0;
+        BitBuf bb;
+        const bool exact0 = tile == 0 && tid == 0;      // the block's first bit: entry 0, no guess
+        const bool forced = FIX && tid == 0 && tile > 0;
+        if (exact0 || forced) {
+            entry = exact0 ? 0u : (u32)tile_exit[gt - 1];
+            p = b1 + entry;
+            bb.init(data, p);
+        } else {
+            p = b1 - 256u;                              // run-up: the chunk in front, from its first bit
+            bb.init(data, p);
+            if (last) spec_walk<true>(data, tab, K1, p, bb, b1, limit, dummy);
+            else spec_walk<false>(data, tab, K1, p, bb, b1, limit, dummy);
+            entry = p - b1;
+        }
+        if (last) spec_walk<true>(data, tab, K1, p, bb, b2, limit, cnt);
+        else spec_walk<false>(data, tab, K1, p, bb, b2, limit, cnt);
+        u32 exit_ = (p - b2) & 15u;
+        ex[tid] = (u8)exit_;
+        __syncthreads();
+        // lanes whose guess differs from the exit in front of them walk their chunk again from that exit
+        bool bad = false;
+        for (int round = 0; round < 4; ++round) {
+            bad = tid > 0 && entry != (u32)ex[tid - 1];
+            if (!__syncthreads_or(bad)) break;
+            if (bad) {
+                entry = ex[tid - 1];
+                p = b1 + entry;
+                bb.init(data, p);
+                cnt = 0;
+                if (last) spec_walk<true>(data, tab, K1, p, bb, b2, limit, cnt);
+                else spec_walk<false>(data, tab, K1, p, bb, b2, limit, cnt);
+                exit_ = (p - b2) & 15u;
+            }
+            __syncthreads();                            // every lane has read the exit in front of it
+            ex[tid] = (u8)exit_;
+            __syncthreads();
+            bad = tid > 0 && entry != (u32)ex[tid - 1];
+        }
+        if (__syncthreads_or(bad)) {                    // did not settle: the block takes the exact kernels
+            if (tid == 0) __hip_atomic_store(blk.run_dp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        chunk_entry[gt * DEC_THREADS + tid] = (u8)entry;
+        chunk_cnt[gt * DEC_THREADS + tid] = (u16)cnt;
+        const u32 tot = dpp_scan_add(cnt);
+        if (lane == 63) wsum[wv] = tot;
+        __syncthreads();
+        if (tid == 0) {
+            tile_cnt[gt] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            tile_guess[gt] = (u8)entry;
+        }
+        if (tid == DEC_THREADS - 1) tile_exit[gt] = (u8)exit_;
+    }
+}
+
+// per block: tiles whose first lane's guess differs from the previous tile's exit get tile_fix = 1 (redone by
+// sfd_spec<true>); FINAL: any difference left sends the block to the exact kernels
+template <bool FINAL>
+__global__ __launch_bounds__(DEC_THREADS) void sfd_spec_check(const DecBlk *__restrict__ blks, const u8 *__restrict__ tile_guess,
+                                                              const u8 *__restrict__ tile_exit, u8 *__restrict__ tile_fix)
+{
+    const DecBlk blk = blks[blockIdx.x];
+    if (!blk.n_tiles || !blk.run_dp || __hip_atomic_load(blk.run_dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    bool any = false;
+    for (u32 t = threadIdx.x; t < blk.n_tiles; t += DEC_THREADS) {
+        const size_t gt = (size_t)blk.tile_base + t;
+        const bool diff = t > 0 && tile_guess[gt] != tile_exit[gt - 1];
+        if (!FINAL) tile_fix[gt] = diff ? 1 : 0;
+        any |= diff;
+    }
+    if (FINAL && __syncthreads_or(any) && threadIdx.x == 0)
+        __hip_atomic_store(blk.run_dp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // sfd_write13: static LDS: SUBS x data | lut13[2^13] u16 (MULTI: sym3[2^12] u32) | SUBS x wsum[4]
@@ -1540,6 +1718,56 @@ void build_host_tab(const shafa_code_table &t, HostTab &h)
 }
 }  // namespace
 
+static bool g_sfd_speculate = true;
+void sfdec_configure(int speculate) { g_sfd_speculate = speculate != 0; }
+
+// Does a decoder that starts 256 bits early agree with the true parse when it reaches the chunk?  Answered per table by
+// simulation on random bits (any bit string is a concatenation of code words of a complete code, distributed as the
+// code's own lengths imply): the true parser starts at bit 0, a second one at a random offset 1..15; they "merge" when
+// the second lands on a start of the first.  Tables whose parsers fail to merge within 256 bits in more than 2 of 96
+// trials (Zipf-like data: ~0.2 %; uniform bytes, 8/9-bit codes: ~85 %) do not take the speculative kernels.
+// Verdicts are cached by a hash of the table (a launch usually repeats the previous launch's tables).
+static bool spec_worthwhile(const shafa_code_table &t, const HostTab &h)
+{
+    if (!h.ok || !h.complete || h.lmax > (u32)LEN_MAXK || h.lmax < 2) return false;
+    u64 key = 1469598103934665603ull;
+    for (int s2 = 0; s2 < 256; ++s2) {
+        key = (key ^ t.len[s2]) * 1099511628211ull;
+        for (int q = 0; q < (t.len[s2] + 7) / 8; ++q) key = (key ^ t.bits[s2][q]) * 1099511628211ull;
+    }
+    static u64 ckey[256];
+    static signed char cval[256];                       // 0 = empty, 1 = no, 2 = yes
+    const u32 slot = (u32)(key >> 17) & 255u;
+    if (cval[slot] && ckey[slot] == key) return cval[slot] == 2;
+    const u32 K1 = h.K1;
+    u64 rs = key | 1ull;
+    auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; };
+    int fails = 0;
+    for (int trial = 0; trial < 96 && fails <= 2; ++trial) {
+        u64 w[6];                                       // 384 random bits, bit i = bit (63 - i % 64) of w[i / 64]
+        for (u64 &x : w) x = rnd();
+        auto window = [&](u32 pos) -> u32 {             // the K1 bits at pos, MSB first
+            const u32 wi = pos >> 6, r = pos & 63;
+            u64 v = w[wi] << r;
+            if (r && wi + 1 < 6) v |= w[wi + 1] >> (64 - r);
+            return (u32)(v >> (64 - K1));
+        };
+        u64 starts[5] = {0, 0, 0, 0, 0};                // code starts of the true parse, bits 0..319
+        for (u32 pos = 0; pos < 300;) { starts[pos >> 6] |= 1ull << (pos & 63); pos += h.lenlut[window(pos)]; }
+        u32 pos = 1 + (u32)(rnd() % 15);
+        bool merged = false;
+        while (pos <= 256) {
+            if ((starts[pos >> 6] >> (pos & 63)) & 1ull) { merged = true; break; }
+            pos += h.lenlut[window(pos)];
+        }
+        if (!merged) ++fails;
+    }
+    const bool yes = fails <= 2;
+    ckey[slot] = key;
+    cval[slot] = yes ? 2 : 1;
+    return yes;
+}
+
 int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                  const u64 *h_in_n, const shafa_code_table *h_tables, const u64 *h_n_symbols, u8 *d_out,
                  const u64 *h_out_off)
@@ -1586,6 +1814,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     // workspace layout
     size_t off = 0;
     const size_t o_blk = off; off += ((size_t)nblocks * sizeof(DecBlk) + 15) & ~(size_t)15;
+    const size_t o_rundp = off; off += ((size_t)nblocks * 4 + 15) & ~(size_t)15;       // staged with the records: initial values
     const size_t o_tab = off; off += tab_bytes;
     const size_t stage_bytes = off;
     const size_t o_tilefn = off; off += (size_t)total_tiles * (R < 8 ? 8 : R); off = (off + 15) & ~(size_t)15;
@@ -1608,6 +1837,15 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const size_t o_fsm4 = off; off += need_tabs ? (size_t)nblocks * 16384 : 0;
     const size_t o_fsm1 = off; off += need_tabs ? (size_t)nblocks * 2048 : 0;
     const size_t o_cfn = off; off += packed ? (size_t)total_tiles * DEC_THREADS * 8 : (size_t)total_tiles * R * DEC_THREADS;
+    // speculative entries (complete codes, Lmax <= 13, tables that re-synchronise): per-tile guess / exit / redo flag
+    const bool spec_path = packed && fast13 && multi && !long_all && g_sfd_speculate;
+    std::vector<char> spec_blk(nblocks, 0);
+    bool any_spec = false;
+    for (int b = 0; spec_path && b < nblocks; ++b)
+        if (ntiles[b] && spec_worthwhile(h_tables[b], tabs[b])) { spec_blk[b] = 1; any_spec = true; }
+    const size_t o_tguess = off; off += any_spec ? (size_t)total_tiles : 0; off = (off + 15) & ~(size_t)15;
+    const size_t o_texit = off; off += any_spec ? (size_t)total_tiles : 0; off = (off + 15) & ~(size_t)15;
+    const size_t o_tfix = off; off += any_spec ? (size_t)total_tiles : 0; off = (off + 15) & ~(size_t)15;
     int rc = batch_reserve(bt, st, off);
     if (rc) return rc;
     u8 *ws = (u8 *)bt->d_ws;
@@ -1627,6 +1865,8 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         e.err = bt->d_err + b;
         e.n_tiles = ntiles[b];
         e.tile_base = tbase;
+        e.run_dp = any_spec ? (u32 *)(ws + o_rundp) + b : nullptr;
+        ((u32 *)(hs + o_rundp))[b] = spec_blk[b] ? 0u : 1u;               // 1: straight to the exact kernels
         e.pairlut = pair_all ? ws + o_pair + (size_t)b * (2u << LEN_MAXK) : nullptr;
         e.cnt3 = need_tabs ? (u16 *)(ws + o_cnt3 + (size_t)b * (2u << LEN_MAXK)) : nullptr;
         e.sym3 = need_tabs ? (u32 *)(ws + o_sym3 + (size_t)b * (4u << LEN_MAXK)) : nullptr;
@@ -1698,6 +1938,17 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     if (packed) {
         const size_t lds_count16 = lds_data + DEC_THREADS * 8 + lds_lut + 32 + DEC_THREADS + 64;
         if (need_tabs) hipLaunchKernelGGL(sfd_tables, grid_b, dim3(DEC_THREADS), 0, st, dblk);
+        if (any_spec) {                                // guesses, two rounds of tile repairs, final verdict per block
+            u8 *tg = ws + o_tguess, *tx = ws + o_texit, *tf = ws + o_tfix;
+            hipLaunchKernelGGL(sfd_spec<false>, grid_f, dim3(DEC_THREADS), 0, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
+                               (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tpw);
+            for (int round = 0; round < 2; ++round) {
+                hipLaunchKernelGGL(sfd_spec_check<false>, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
+                hipLaunchKernelGGL(sfd_spec<true>, grid_f, dim3(DEC_THREADS), 0, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
+                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tpw);
+            }
+            hipLaunchKernelGGL(sfd_spec_check<true>, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
+        }
         u32 k1_all = 0;                                // common K1 of the running blocks, 0 when they differ
         for (int b = 0; b < nblocks; ++b)
             if (ntiles[b]) k1_all = (k1_all == 0 || k1_all == tabs[b].K1) ? tabs[b].K1 : 0xFFFFFFFFu;
