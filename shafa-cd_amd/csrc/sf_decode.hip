@@ -1155,146 +1155,206 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) __attribute__((amdgpu_waves_per
 // skewed data re-synchronise: a decoder started at an arbitrary bit agrees with the true parse after a few dozen bits
 // (measured: started 256 bits early it is off at the chunk boundary in 0.2 % of the chunks of Zipf(1.2) mod 256 data,
 // 0.02 % for Zipf truncated to 256 ranks, 85 % for uniform bytes, whose 8/9-bit codes never merge).  So every lane
-//   1. walks the chunk BEFORE its own from that chunk's first bit (three codes per look-up, cnt3), which leaves it at
-//      its guess of its own entry, then walks its own chunk, counting the codes that start there, to its exit;
+// takes a strip of four chunks and
+//   1. walks the chunk BEFORE its strip from that chunk's first bit (three codes per look-up, cnt3), which leaves it at
+//      its guess of the strip's entry, then walks the strip, noting entry and code count of each chunk, to its exit;
 //   2. compares its guess with the exit of the lane before it; lanes that differ take that exit as their entry and walk
-//      their own chunk again (a few rounds: a repaired lane's exit almost never moves).
-// A tile's first lane guesses from the last chunk of the previous tile; sfd_spec_check compares every tile's guess with
-// the previous tile's exit and sfd_spec<true> redoes the tiles that differ with the entry forced.  When every
+//      again until they are back on their earlier path (a few rounds: a repaired lane's exit almost never moves).
+// A workgroup covers four tiles (wave w = tile w); its first lane guesses from the last chunk of the previous tile;
+// sfd_spec_check compares every tile's guess with the previous tile's exit and sfd_spec<true> redoes the regions that
+// differ with the entry forced.  When every
 // comparison of a block holds — entry(c) == exit(c-1) for all chunks, entry 0 at the block's first bit — the entries
 // ARE the true parse, by induction: nothing is approximate.  A block that does not get there in the fixed number of
 // rounds sets *run_dp and goes through the exact kernels, which skip the blocks that verified; which blocks try at all
 // is decided per table on the host (spec_worthwhile()).  Outputs are those of sfd_countfsm.
 // static LDS: stream of the tile with 32 bytes in front (as load_tile: big-endian words, one pad word per 8) | cnt3 | exits
 // ================================================================================================
-constexpr int SPEC_PRE_WORDS = 8;                  // 256 bits in front of the tile: the first lane's run-up
-constexpr int SPEC_WORDS = SPEC_PRE_WORDS + DATA_WORDS;
-constexpr int SPEC_LDS_DATA = (SPEC_WORDS + SPEC_WORDS / 8 + 8) * 4;
+constexpr int SPEC_STRIP = 2;                      // chunks per lane: the 256-bit run-up is paid once per strip
+                                                   // (4: a fifth fewer steps, but twice the LDS per walk in flight: slower)
+constexpr int SPEC_TILES = SPEC_STRIP;             // a workgroup covers SPEC_STRIP tiles
+constexpr int SPEC_SW = 8 * SPEC_STRIP;            // stream words per strip
+constexpr int SPEC_ROW = SPEC_SW + 1;              // LDS words per strip: the strip, then a copy of the next strip's first word
+// LDS frame: strip 0 = the strip in front of the region (its last chunk is lane 0's run-up), strips 1..256 = the lanes';
+// neighbouring lanes are an odd number of words apart (no bank conflicts) and every walk sees its strip and one word
+// more as linear memory
+constexpr int SPEC_STRIPS = DEC_THREADS + 1;
+constexpr int SPEC_LDS_DATA = (SPEC_STRIPS * SPEC_ROW + 3) / 4 * 16;
 
-// one walk: from bit p (a code start, by assumption) to the first code start >= b; counts the codes started on the way.
-// LAST: the stream ends at bit `limit` of this frame; a code that does not end inside the stream is not a symbol.
+// one walk inside strip j (LDS row j): from bit r of the strip (a code start, by assumption) to the first code start >= b,
+// counting the codes started on the way.  The window at bit p is alignbit(W[(p-1)>>5], W[((p-1)>>5)+1], ~(p-1)): no bit
+// buffer to refill, two look-ups per step.  qb = 8 * (byte address of the row) - 1.
+// LAST: the stream ends at bit `limit` of the strip (may be negative); a code that does not end inside it is not a symbol.
 template <bool LAST>
-__device__ __forceinline__ void spec_walk(const u32 *data, const u16 *tab, u32 K1, u32 &p, BitBuf &bb, u32 b, u32 limit, u32 &cnt)
+__device__ __forceinline__ void spec_walk(const u8 *smem, u32 tab_off, u32 K1, u32 qb, int &r, int b, int limit, u32 &cnt)
 {
     const u32 sh = 32 - K1;
     if (!LAST) {
-        while (p + K1 <= b) {                           // the window holds only codes that start before b
-            const u32 e = tab[bb.peek32() >> sh];
-            p += e & 15u;
+        const int bk = b - (int)K1;
+        while (r <= bk) {                               // the window holds only codes that start before b
+            const u32 q = qb + (u32)r;
+            const u32 a = (q >> 3) & ~3u;
+            const u32 win = __builtin_amdgcn_alignbit(*(const u32 *)(smem + a), *(const u32 *)(smem + a + 4), ~q);
+            const u32 e = *(const u16 *)(smem + tab_off + ((win >> sh) << 1));
+            r += (int)(e & 15u);
             cnt += e >> 12;
-            bb.skip(data, e & 15u);
         }
     }
-    while (p < b) {
-        const u32 l0 = (tab[bb.peek32() >> sh] >> 4) & 15u;
-        if (LAST && p + l0 > limit) { p = b + 15u; break; }      // cut by the end of the stream: nothing starts after it
-        p += l0;
+    while (r < b) {
+        const u32 q = qb + (u32)r;
+        const u32 a = (q >> 3) & ~3u;
+        const u32 win = __builtin_amdgcn_alignbit(*(const u32 *)(smem + a), *(const u32 *)(smem + a + 4), ~q);
+        const int l0 = (int)((*(const u16 *)(smem + tab_off + ((win >> sh) << 1)) >> 4) & 15u);
+        if (LAST && r + l0 > limit) { r = b + 15; break; }       // cut by the end of the stream: nothing starts after it
+        r += l0;
         ++cnt;
-        bb.skip(data, l0);
     }
 }
 
+// a strip from entry `ent0` of its first chunk: entries and counts of its SPEC_STRIP chunks, exit of the last one.
+// HAVE_OLD: ent[] holds the entries of an earlier walk of the same strip: once this walk meets it the rest is unchanged.
+template <bool LAST, bool HAVE_OLD>
+__device__ __forceinline__ void spec_strip(const u8 *smem, u32 tab_off, u32 K1, u32 qb, int limit, u32 ent0,
+                                           u32 (&ent)[SPEC_STRIP], u32 (&cnt)[SPEC_STRIP], u32 &exit_)
+{
+    int r = (int)ent0;
+#pragma unroll
+    for (int k = 0; k < SPEC_STRIP; ++k) {
+        if (HAVE_OLD && k > 0 && (u32)(r - 256 * k) == ent[k]) return;  // back on the earlier walk's path
+        ent[k] = (u32)(r - 256 * k);
+        u32 c = 0;
+        spec_walk<LAST>(smem, tab_off, K1, qb, r, 256 * (k + 1), limit, c);
+        cnt[k] = c;
+    }
+    exit_ = (u32)(r - 256 * SPEC_STRIP) & 15u;
+}
+
+// dynamic LDS: stream frame | cnt3 (2 << K1max bytes) | exits[256] | wsum[4]
 template <bool FIX>
 __global__ __launch_bounds__(DEC_THREADS) void sfd_spec(const DecBlk *__restrict__ blks, u8 *__restrict__ chunk_entry,
                                                         u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt,
                                                         u8 *__restrict__ tile_guess, u8 *__restrict__ tile_exit,
-                                                        const u8 *__restrict__ tile_fix, u32 tpw)
+                                                        const u8 *__restrict__ tile_fix, u32 tab_bytes)
 {
-    __shared__ __attribute__((aligned(16))) u8 smem[SPEC_LDS_DATA + (2 << LEN_MAXK) + DEC_THREADS + 16 + 64];
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const DecBlk blk = blks[blockIdx.y];
-    if (blockIdx.x * tpw >= blk.n_tiles) return;
+    const u32 tile0 = blockIdx.x * SPEC_TILES;          // first tile of this workgroup's region
+    if (tile0 >= blk.n_tiles) return;
     if (!blk.run_dp || __hip_atomic_load(blk.run_dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // exact path
+    const size_t gt0 = (size_t)blk.tile_base + tile0;
+    const u32 ntl = blk.n_tiles - tile0 < (u32)SPEC_TILES ? blk.n_tiles - tile0 : (u32)SPEC_TILES;   // tiles of the region
+    if (FIX) {
+        bool any = false;
+        for (u32 t = 0; t < ntl; ++t) any |= tile_fix[gt0 + t] != 0;
+        if (!any) return;
+    }
     u32 *data = (u32 *)smem;
-    const u16 *tab = (const u16 *)(smem + SPEC_LDS_DATA);
-    u8 *ex = smem + SPEC_LDS_DATA + (2 << LEN_MAXK);
-    u32 *wsum = (u32 *)(ex + DEC_THREADS);
+    const u32 tab_off = SPEC_LDS_DATA;
+    u8 *ex = smem + SPEC_LDS_DATA + tab_bytes;
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 K1 = blk.K1;
-    bool table_loaded = false;
-    const u32 tile_end = (blockIdx.x + 1) * tpw < blk.n_tiles ? (blockIdx.x + 1) * tpw : blk.n_tiles;
-    for (u32 tile = blockIdx.x * tpw; tile < tile_end; ++tile) {
-        const size_t gt = (size_t)blk.tile_base + tile;
-        if (FIX && !tile_fix[gt]) continue;             // uniform
-        if (!table_loaded) { fill_lds16((void *)tab, (const void *)blk.cnt3, 2u << K1); table_loaded = true; }
-        __syncthreads();                                // the previous tile's LDS reads are done
-        {   // the tile's stream from 32 bytes before it: frame bit 0 = stream bit 8 * (tile * DTILE - 32)
-            const long long base = (long long)tile * DTILE - 4 * SPEC_PRE_WORDS;
-            for (u32 i = tid; i < SPEC_WORDS / 4; i += DEC_THREADS) {
-                const long long off = base + (long long)i * 16;
-                u32 w[4] = {0, 0, 0, 0};
-                if (off >= 0 && (u64)off + 16 <= blk.in_n) {
-                    const uint4 v = gload<uint4>(blk.in + off);
-                    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-                } else if (off >= 0 && (u64)off < blk.in_n) {
-                    const int nv = (int)(blk.in_n - (u64)off);
+    fill_lds16((void *)(smem + tab_off), (const void *)blk.cnt3, 2u << K1);
+    {   // the region's stream from one strip before it, 16 bytes a lane; frame word f -> LDS word f + f / SPEC_SW
+        const long long base = (long long)tile0 * DTILE - 4 * SPEC_SW;
+        for (u32 i = tid; i < (u32)(SPEC_STRIPS * SPEC_SW / 4 + 1); i += DEC_THREADS) {
+            const long long off = base + (long long)i * 16;
+            u32 w[4] = {0, 0, 0, 0};
+            if (off >= 0 && (u64)off + 16 <= blk.in_n) {
+                const uint4 v = gload<uint4>(blk.in + off);
+                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            } else if (off >= 0 && (u64)off < blk.in_n) {
+                const int nv = (int)(blk.in_n - (u64)off);
 #pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        if (q < nv) w[q >> 2] |= (u32)gload<u8>(blk.in + off + q) << (8 * (q & 3));
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) data[widx(4 * i + q)] = bswap32(w[q]);
+                for (int q = 0; q < 16; ++q)
+                    if (q < nv) w[q >> 2] |= (u32)gload<u8>(blk.in + off + q) << (8 * (q & 3));
+            }
+            const u32 f = 4 * i, at = f + f / SPEC_SW;
+            const u32 w0 = bswap32(w[0]);
+            if (f % SPEC_SW == 0 && f > 0) data[at - 1] = w0;       // the previous row's look-ahead word
+            if (i < (u32)(SPEC_STRIPS * SPEC_SW / 4)) {
+                data[at] = w0;
+                data[at + 1] = bswap32(w[1]);
+                data[at + 2] = bswap32(w[2]);
+                data[at + 3] = bswap32(w[3]);
             }
         }
-        __syncthreads();
-        // frame bits: chunk `tid` = [256 (tid + 1), 256 (tid + 2)); the stream ends at frame bit `limit`
-        const u64 start = (u64)tile * DTILE;
-        const u64 left = blk.in_n > start ? blk.in_n - start : 0;
-        const u64 capb = (u64)DTILE + HALO_WORDS * 4;
-        const u32 limit = 256u + (u32)((left < capb ? left : capb) * 8);
-        const bool last = left < capb;                  // the stream ends inside this frame
-        const u32 b1 = 256u * (tid + 1), b2 = b1 + 256u;
-        u32 p, entry, cnt = 0, dummy = 0;
-        BitBuf bb;
-        const bool exact0 = tile == 0 && tid == 0;      // the block's first bit: entry 0, no guess
-        const bool forced = FIX && tid == 0 && tile > 0;
-        if (exact0 || forced) {
-            entry = exact0 ? 0u : (u32)tile_exit[gt - 1];
-            p = b1 + entry;
-            bb.init(data, p);
-        } else {
-            p = b1 - 256u;                              // run-up: the chunk in front, from its first bit
-            bb.init(data, p);
-            if (last) spec_walk<true>(data, tab, K1, p, bb, b1, limit, dummy);
-            else spec_walk<false>(data, tab, K1, p, bb, b1, limit, dummy);
-            entry = p - b1;
+    }
+    __syncthreads();
+    // lane tid owns frame strip tid + 1; the stream ends at bit `limit` of that strip (<= 0: before it)
+    const u64 start = (u64)tile0 * DTILE;
+    const u64 left = blk.in_n > start ? blk.in_n - start : 0;
+    const u64 capb = (u64)SPEC_TILES * DTILE + 4;
+    const bool last = left < capb;                      // the stream ends inside this frame
+    const int limit = last ? (int)(left * 8) - (int)(256u * SPEC_STRIP * tid) : 0;
+    const u32 qb = 8u * (4u * SPEC_ROW) * (tid + 1) - 1u;
+    u32 ent[SPEC_STRIP], cnt[SPEC_STRIP], exit_ = 0;
+    {
+        u32 e0;
+        const bool exact0 = tile0 == 0 && tid == 0;     // the block's first bit: entry 0, no guess
+        const bool forced = FIX && tid == 0 && tile0 > 0 && tile_fix[gt0] != 0;
+        if (exact0) e0 = 0;
+        else if (forced) e0 = (u32)tile_exit[gt0 - 1];
+        else {                                          // run-up: the last chunk of the strip in front, from its first bit
+            int r = 256 * (SPEC_STRIP - 1);
+            u32 dummy = 0;
+            const u32 qp = qb - 8u * (4u * SPEC_ROW);
+            if (last) spec_walk<true>(smem, tab_off, K1, qp, r, 256 * SPEC_STRIP, limit + 256 * SPEC_STRIP, dummy);
+            else spec_walk<false>(smem, tab_off, K1, qp, r, 256 * SPEC_STRIP, 0, dummy);
+            e0 = (u32)(r - 256 * SPEC_STRIP) & 15u;
         }
-        if (last) spec_walk<true>(data, tab, K1, p, bb, b2, limit, cnt);
-        else spec_walk<false>(data, tab, K1, p, bb, b2, limit, cnt);
-        u32 exit_ = (p - b2) & 15u;
+        if (last) spec_strip<true, false>(smem, tab_off, K1, qb, limit, e0, ent, cnt, exit_);
+        else spec_strip<false, false>(smem, tab_off, K1, qb, limit, e0, ent, cnt, exit_);
+    }
+    ex[tid] = (u8)exit_;
+    __syncthreads();
+    // strips whose guess differs from the exit in front of them walk again from that exit, until the walk meets the old one
+    bool bad = false;
+    for (int round = 0; round < 4; ++round) {
+        bad = tid > 0 && ent[0] != (u32)ex[tid - 1];
+        if (!__syncthreads_or(bad)) break;
+        if (bad) {
+            const u32 e0 = ex[tid - 1];
+            if (last) spec_strip<true, true>(smem, tab_off, K1, qb, limit, e0, ent, cnt, exit_);
+            else spec_strip<false, true>(smem, tab_off, K1, qb, limit, e0, ent, cnt, exit_);
+        }
+        __syncthreads();                                // every lane has read the exit in front of it
         ex[tid] = (u8)exit_;
         __syncthreads();
-        // lanes whose guess differs from the exit in front of them walk their chunk again from that exit
-        bool bad = false;
-        for (int round = 0; round < 4; ++round) {
-            bad = tid > 0 && entry != (u32)ex[tid - 1];
-            if (!__syncthreads_or(bad)) break;
-            if (bad) {
-                entry = ex[tid - 1];
-                p = b1 + entry;
-                bb.init(data, p);
-                cnt = 0;
-                if (last) spec_walk<true>(data, tab, K1, p, bb, b2, limit, cnt);
-                else spec_walk<false>(data, tab, K1, p, bb, b2, limit, cnt);
-                exit_ = (p - b2) & 15u;
-            }
-            __syncthreads();                            // every lane has read the exit in front of it
-            ex[tid] = (u8)exit_;
-            __syncthreads();
-            bad = tid > 0 && entry != (u32)ex[tid - 1];
+        bad = tid > 0 && ent[0] != (u32)ex[tid - 1];
+    }
+    if (__syncthreads_or(bad)) {                        // did not settle: the block takes the exact kernels
+        if (tid == 0) __hip_atomic_store(blk.run_dp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // chunk tid * SPEC_STRIP + k of the region; a tile is 256 / SPEC_STRIP consecutive lanes
+    const u32 my_tile = tid * SPEC_STRIP / DEC_THREADS;
+    u32 mine = 0;
+#pragma unroll
+    for (int k = 0; k < SPEC_STRIP; ++k) mine += cnt[k];
+    const u32 wtot = dpp_scan_add(mine);                // lane 63: the wave's codes
+    u32 *wsum = (u32 *)(ex + DEC_THREADS);
+    if (lane == 63) wsum[wv] = wtot;
+    __syncthreads();
+    if (my_tile < ntl) {
+        const size_t c0 = gt0 * DEC_THREADS + (size_t)tid * SPEC_STRIP;
+        if (SPEC_STRIP == 4) {
+            gstore<u32>(chunk_entry + c0, (ent[0] & 0xFFu) | ((ent[1 % SPEC_STRIP] & 0xFFu) << 8) |
+                                              ((ent[2 % SPEC_STRIP] & 0xFFu) << 16) | (ent[3 % SPEC_STRIP] << 24));
+            gstore<uint2>(chunk_cnt + c0, make_uint2(cnt[0] | (cnt[1 % SPEC_STRIP] << 16), cnt[2 % SPEC_STRIP] | (cnt[3 % SPEC_STRIP] << 16)));
+        } else if (SPEC_STRIP == 2) {
+            gstore<u16>(chunk_entry + c0, (u16)((ent[0] & 0xFFu) | (ent[1 % SPEC_STRIP] << 8)));
+            gstore<u32>(chunk_cnt + c0, cnt[0] | (cnt[1 % SPEC_STRIP] << 16));
+        } else {
+            for (int k = 0; k < SPEC_STRIP; ++k) { chunk_entry[c0 + k] = (u8)ent[k]; chunk_cnt[c0 + k] = (u16)cnt[k]; }
         }
-        if (__syncthreads_or(bad)) {                    // did not settle: the block takes the exact kernels
-            if (tid == 0) __hip_atomic_store(blk.run_dp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        constexpr u32 LPT = DEC_THREADS / SPEC_STRIP;   // lanes per tile
+        constexpr u32 WPT = LPT / 64;                   // waves per tile
+        const u32 in_tile = tid % LPT;
+        if (in_tile == 0) {
+            u32 tot = 0;
+            for (u32 w = 0; w < WPT; ++w) tot += wsum[my_tile * WPT + w];
+            tile_cnt[gt0 + my_tile] = tot;
+            tile_guess[gt0 + my_tile] = (u8)ent[0];
         }
-        chunk_entry[gt * DEC_THREADS + tid] = (u8)entry;
-        chunk_cnt[gt * DEC_THREADS + tid] = (u16)cnt;
-        const u32 tot = dpp_scan_add(cnt);
-        if (lane == 63) wsum[wv] = tot;
-        __syncthreads();
-        if (tid == 0) {
-            tile_cnt[gt] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-            tile_guess[gt] = (u8)entry;
-        }
-        if (tid == DEC_THREADS - 1) tile_exit[gt] = (u8)exit_;
+        if (in_tile == LPT - 1) tile_exit[gt0 + my_tile] = (u8)exit_;
     }
 }
 
@@ -1435,6 +1495,182 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *
     }
     na >>= 3;
     for (u32 q = 0; q < na; ++q) gstore<u8>(op + q, (u8)(acc >> (8 * q)));
+    }
+    if (bad) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
+}
+
+// ------------------------------------------------------------------------------------------------
+// sfd_wstage: the symbol pass for complete codes (three codes per look-up), staged through LDS.
+// A lane decodes one chunk from its entry, exactly the symbols counted for it.  The workgroup's symbols are one
+// contiguous run of the output, so they are collected in an LDS image of that run (aligned like the output address)
+// and leave as aligned 16-byte stores, fully coalesced.  A lane gathers symbols in a 32-bit word and ORs each finished
+// word into the image (ds_or_b32: the words at both ends of a lane's run are shared with its neighbours; unfinished
+// words go to a per-lane dump word so that the loop has no divergent flush).  The stream sits in LDS one row per
+// chunk (8 words + the next row's first: rows 9 words apart, conflict free); the window at bit p is
+// alignbit(W[(p-1)>>5], W[((p-1)>>5)+1], ~(p-1)), no bit buffer.
+// dynamic LDS: rows | sym3 (tab_bytes) | long table (LONG) | image (cap bytes) | dump[256] | wsum[4], next
+// The host sizes the image for the launch's average symbols per tile plus a margin (LDS is what limits the waves per
+// CU); a tile with more symbols than it holds goes in several rounds of consecutive lanes.
+// ------------------------------------------------------------------------------------------------
+constexpr int WS_ROW = CH_BYTES / 4 + 1;            // LDS words per chunk row
+constexpr int WS_ROWS_BYTES = 16 + DEC_THREADS * WS_ROW * 4;     // 16 in front: the window at a row's bit 0 reads the word before it
+constexpr int WS_MISC = DEC_THREADS * 4 + 32;
+
+template <int LONG>
+__global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restrict__ blks, const u8 *__restrict__ chunk_entry,
+                                                          const u16 *__restrict__ chunk_cnt, const u64 *__restrict__ tile_off,
+                                                          u32 tpw, u32 tab_bytes, u32 cap)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const DecBlk blk = blks[blockIdx.y];
+    const u32 first_tile = blockIdx.x * tpw;
+    if (first_tile >= blk.n_tiles) return;
+    if (tile_off[(size_t)blk.tile_base + first_tile] >= blk.n_sym) return;   // all padding / past the end
+    constexpr u32 LONGB = LONG == 1 ? LONG_BYTES : LONG == 2 ? LONG32_BYTES : 0;
+    u32 *rows = (u32 *)(smem + 16);
+    const u32 tab_off = WS_ROWS_BYTES;
+    const u16 *lt = (const u16 *)(smem + tab_off + tab_bytes);
+    const u32 img_off = tab_off + tab_bytes + LONGB;
+    u32 *dump = (u32 *)(smem + img_off + cap);
+    u32 *wsum = dump + DEC_THREADS;
+    u32 *next = wsum + 4;
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 K1 = blk.K1, K3 = K1 < (u32)SYM3_MAXK ? K1 : (u32)SYM3_MAXK;
+    const u32 sh = 32 - K1, sh3 = 32 - K3;
+    fill_lds16(smem + tab_off, (const void *)blk.sym3, 4u << K3);
+    if (LONG) {
+        const u16 *src = LONG == 1 ? blk.longtab : blk.long32;
+        if (src) fill_lds16((void *)lt, src, LONGB);
+        else if (tid == 0) *(u16 *)lt = 0;
+    }
+    for (u32 i = tid; i < cap / 16; i += DEC_THREADS) *(uint4 *)(smem + img_off + 16 * i) = make_uint4(0, 0, 0, 0);
+    bool bad = false;
+    const u32 qb = 8u * (16u + 4u * WS_ROW * tid) - 1u;
+    const u32 dump_a = img_off + cap + 4 * tid;
+    // 16 stream bytes at `off` (zeros past the end)
+    auto fetch16 = [&](const u64 off) -> uint4 {
+        if (off + 16 <= blk.in_n) return gload<uint4>(blk.in + off);
+        u32 w[4] = {0, 0, 0, 0};
+        if (off < blk.in_n) {
+            const int nv = (int)(blk.in_n - off);
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q < nv) w[q >> 2] |= (u32)gload<u8>(blk.in + off + q) << (8 * (q & 3));
+        }
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    };
+    // a tile's inputs travel through registers: they are requested while the tile before is being decoded
+    uint4 pf0, pf1, pf2 = make_uint4(0, 0, 0, 0);
+    u32 pf_entry = 0, pf_cnt = 0;
+    auto prefetch = [&](const u32 tile) {
+        const u64 base = (u64)tile * DTILE;
+        pf0 = fetch16(base + 16ull * tid);
+        pf1 = fetch16(base + 16ull * (tid + DEC_THREADS));
+        if (tid == 0) pf2 = fetch16(base + DTILE);      // the last row's look-ahead word
+        const size_t g = ((size_t)blk.tile_base + tile) * DEC_THREADS + tid;
+        pf_entry = chunk_entry[g];
+        pf_cnt = chunk_cnt[g];
+    };
+    // tile word f -> LDS word f + f / 8; the first word of a row is also the look-ahead word of the row before
+    auto put16 = [&](const u32 i, const uint4 v) {
+        const u32 f = 4 * i, at = f + (f >> 3);
+        const u32 w0 = bswap32(v.x);
+        if ((f & 7u) == 0 && f > 0) rows[at - 1] = w0;
+        if (i < (u32)(DTILE / 16)) {
+            rows[at] = w0;
+            rows[at + 1] = bswap32(v.y);
+            rows[at + 2] = bswap32(v.z);
+            rows[at + 3] = bswap32(v.w);
+        }
+    };
+    prefetch(first_tile);
+    for (u32 it = 0; it < tpw; ++it) {
+        const u32 tile = first_tile + it;
+        if (tile >= blk.n_tiles) break;
+        const size_t gt = (size_t)blk.tile_base + tile;
+        const u64 toff = tile_off[gt];
+        if (toff >= blk.n_sym) break;                   // the rest is padding / past the end
+        __syncthreads();                                // the previous tile's rows and image are done with
+        put16(tid, pf0);
+        put16(tid + DEC_THREADS, pf1);
+        if (tid == 0) put16(DTILE / 16, pf2);
+        const u32 entry = pf_entry, cnt = pf_cnt;
+        if (it + 1 < tpw && tile + 1 < blk.n_tiles) prefetch(tile + 1);
+        const u32 incl = wave_incl_scan_add<u32>(cnt);
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        u32 pre = incl - cnt, total = 0;
+        for (u32 w = 0; w < 4; ++w) { if (w < wv) pre += wsum[w]; total += wsum[w]; }
+        const u64 room = blk.n_sym - toff;              // symbols of this tile that exist in the block
+        const u32 tot_c = room < (u64)total ? (u32)room : total;
+        u32 want = pre >= tot_c ? 0u : (tot_c - pre < cnt ? tot_c - pre : cnt);
+        int r = (int)entry;
+        for (u32 done = 0; done < tot_c;) {
+            u8 *gout = blk.out + toff + done;
+            const u32 mis = (u32)((uintptr_t)gout & 15u);
+            const u32 capw = cap - 32;
+            u32 nxt = tot_c;
+            if (mis + (tot_c - done) > capw) {          // (uniform) more than the image holds: consecutive lanes that fit
+                if (tid == 0) *next = tot_c;
+                __syncthreads();
+                if (want && pre >= done && mis + (pre - done) + want > capw) atomicMin(next, pre);
+                __syncthreads();
+                nxt = *next;
+                __syncthreads();
+            }
+            if (want && pre >= done && pre + want <= nxt) {
+                const u32 x = mis + (pre - done);
+                u32 wp = img_off + (x & ~3u), nb8 = (x & 3u) * 8, acc = 0;
+                auto step = [&](const bool tail) {
+                    const u32 q = qb + (u32)r;
+                    const u32 a = (q >> 3) & ~3u;
+                    const u32 win = __builtin_amdgcn_alignbit(*(const u32 *)(smem + a), *(const u32 *)(smem + a + 4), ~q);
+                    u32 e = *(const u32 *)(smem + tab_off + ((win >> sh3) << 2));
+                    if (__builtin_expect((e >> 30) == 0, 0)) {      // first code longer than the window: one code
+                        u32 e1 = LONG == 1 ? long_code(lt, win) : LONG == 2 ? long_code32(lt, win)
+                                           : (u32)gload<u16>(blk.lut13 + (win >> sh));
+                        if (e1 == 0) { bad = true; e1 = 1u << 8; }  // not a code (complete tables never get here)
+                        e = (e1 & 0xFFu) | ((e1 >> 8) << 24) | (1u << 30);
+                    }
+                    u32 n = e >> 30, syms = e & 0xFFFFFFu;
+                    if (tail) {
+                        n = n < want ? n : want;
+                        syms &= (1u << (8 * n)) - 1u;
+                    }
+                    const u64 t = (u64)syms << nb8;
+                    const u32 lo = acc | (u32)t;
+                    const u32 nbn = nb8 + 8 * n;
+                    const bool ov = nbn >= 32;
+                    __hip_atomic_fetch_or((u32 *)__builtin_assume_aligned(smem + (ov ? wp : dump_a), 4), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    acc = ov ? (u32)(t >> 32) : lo;
+                    wp += ov ? 4u : 0u;
+                    nb8 = nbn & 31u;
+                    r += (int)((e >> 24) & 63u);
+                    want -= n;
+                };
+                while (want >= 3) step(false);
+                while (want) step(true);
+                if (nb8) __hip_atomic_fetch_or((u32 *)__builtin_assume_aligned(smem + wp, 4), acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __syncthreads();
+            const u32 end = mis + (nxt - done);         // image bytes [mis, end) are this round's symbols
+            for (u32 u = tid; 16 * u < end; u += DEC_THREADS) {
+                uint4 *ip = (uint4 *)(smem + img_off + 16 * u);
+                const uint4 v = *ip;
+                *ip = make_uint4(0, 0, 0, 0);
+                u8 *ga = gout - mis + 16 * u;
+                if (16 * u >= mis && 16 * u + 16 <= end) {
+                    gstore<uint4>(ga, v);
+                } else {
+                    const u32 wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (u32 q = 0; q < 16; ++q)
+                        if (16 * u + q >= mis && 16 * u + q < end) gstore<u8>(ga + q, (u8)(wds[q >> 2] >> (8 * (q & 3))));
+                }
+            }
+            done = nxt;
+            if (done < tot_c) __syncthreads();          // the image is clean again before the next round's ORs
+        }
     }
     if (bad) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
 }
@@ -1940,12 +2176,17 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         if (need_tabs) hipLaunchKernelGGL(sfd_tables, grid_b, dim3(DEC_THREADS), 0, st, dblk);
         if (any_spec) {                                // guesses, two rounds of tile repairs, final verdict per block
             u8 *tg = ws + o_tguess, *tx = ws + o_texit, *tf = ws + o_tfix;
-            hipLaunchKernelGGL(sfd_spec<false>, grid_f, dim3(DEC_THREADS), 0, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
-                               (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tpw);
+            u32 k1_max = 1;
+            for (int b = 0; b < nblocks; ++b) if (spec_blk[b] && tabs[b].K1 > k1_max) k1_max = tabs[b].K1;
+            const u32 tabb = 2u << k1_max;
+            const size_t lds_spec = (size_t)SPEC_LDS_DATA + tabb + DEC_THREADS + 16;
+            const dim3 grid_s((u32)ceil_div_u64(max_tiles, SPEC_TILES), (u32)nblocks);
+            hipLaunchKernelGGL(sfd_spec<false>, grid_s, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
+                               (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb);
             for (int round = 0; round < 2; ++round) {
                 hipLaunchKernelGGL(sfd_spec_check<false>, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
-                hipLaunchKernelGGL(sfd_spec<true>, grid_f, dim3(DEC_THREADS), 0, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
-                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tpw);
+                hipLaunchKernelGGL(sfd_spec<true>, grid_s, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
+                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb);
             }
             hipLaunchKernelGGL(sfd_spec_check<true>, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
         }
@@ -2000,16 +2241,36 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     }
     hipLaunchKernelGGL(sfd_offsets, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u32 *)(ws + o_tcnt),
                        (u64 *)(ws + o_toff));
+    u32 ws_tab = 16;                                   // sym3 bytes of the widest table of the launch
+    for (int b = 0; b < nblocks; ++b) {
+        const u32 k3 = tabs[b].K1 < (u32)SYM3_MAXK ? tabs[b].K1 : (u32)SYM3_MAXK;
+        if ((4u << k3) > ws_tab) ws_tab = 4u << k3;
+    }
+    // image: the densest block's average symbols per tile + 1/8 + 1 KiB, 4 .. 40 KiB
+    u32 ws_cap = 4096;
+    for (int b = 0; b < nblocks; ++b) {
+        if (!ntiles[b]) continue;
+        const u64 per_tile = ceil_div_u64(h_n_symbols[b], ntiles[b]);
+        const u64 c = per_tile + per_tile / 8 + 1024;
+        if (c > ws_cap) ws_cap = (u32)(c > 40960 ? 40960 : c);
+    }
+    {
+        const u32 longb = mid32 ? (u32)LONG32_BYTES : long_all ? (u32)LONG_BYTES : 0u;
+        const u32 most = 65536u - (u32)WS_ROWS_BYTES - ws_tab - longb - (u32)WS_MISC;     // 64 KiB of dynamic LDS
+        if (ws_cap > most) ws_cap = most;
+    }
+    ws_cap &= ~15u;
+    const size_t lds_ws = (size_t)WS_ROWS_BYTES + ws_tab + ws_cap + WS_MISC;
     if (mid32) {
-        hipLaunchKernelGGL((sfd_write13<true, WSUBS, 2>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
-                           (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw);
+        hipLaunchKernelGGL((sfd_wstage<2>), grid_f, dim3(DEC_THREADS), lds_ws + LONG32_BYTES, st, dblk,
+                           (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, ws_tab, ws_cap);
     } else if (fast13) {
         if (multi && long_all)
-            hipLaunchKernelGGL((sfd_write13<true, WSUBS, 1>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
-                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw);
+            hipLaunchKernelGGL((sfd_wstage<1>), grid_f, dim3(DEC_THREADS), lds_ws + LONG_BYTES, st, dblk,
+                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, ws_tab, ws_cap);
         else if (multi)
-            hipLaunchKernelGGL((sfd_write13<true, WSUBS, 0>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
-                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw);
+            hipLaunchKernelGGL((sfd_wstage<0>), grid_f, dim3(DEC_THREADS), lds_ws, st, dblk,
+                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, ws_tab, ws_cap);
         else
             hipLaunchKernelGGL((sfd_write13<false, WSUBS, 0>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
                                (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw);
