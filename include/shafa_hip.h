@@ -72,7 +72,8 @@ const char *shafa_hip_last_error(void);      /* text of the last SHAFA_DEVICE_ER
  *   "sf_encode_one_pass_min_blocks": a shafa_hipd_sf_encode launch with at least this many blocks of <= 16-bit
  *       codes takes the one-pass encoder, smaller launches the count/scan/pack kernels (default 96).
  *   "sf_decode_speculate": 1 (default) lets blocks whose code re-synchronises take the speculative entry kernels of
- *       the Shannon-Fano decoder (verified exactly; falls back to the exact kernels per block), 0 = exact kernels only.
+ *       the Shannon-Fano decoder (verified exactly; falls back to the exact kernels per block), 0 = exact kernels only,
+ *       2 = speculate for every block the kernels apply to, whatever its code (for tests of the fall-back).
  * shafa_hip_init() reads the environment variables SHAFA_SF_ENCODE_ONE_PASS_MIN_BLOCKS and SHAFA_SF_DECODE_SPECULATE
  * once for the same knobs. */
 int shafa_hip_set_option(const char *name, long value);

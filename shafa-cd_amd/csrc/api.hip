@@ -116,7 +116,7 @@ int shafa_hip_set_option(const char *name, long value)
         return SHAFA_SUCCESS;
     }
     if (name && !strcmp(name, "sf_decode_speculate")) {
-        sfdec_configure(value != 0);
+        sfdec_configure(value <= 0 ? 0 : value >= 2 ? 2 : 1);
         return SHAFA_SUCCESS;
     }
     return SHAFA_OUTSIDE_MODULE;

@@ -1954,8 +1954,8 @@ void build_host_tab(const shafa_code_table &t, HostTab &h)
 }
 }  // namespace
 
-static bool g_sfd_speculate = true;
-void sfdec_configure(int speculate) { g_sfd_speculate = speculate != 0; }
+static int g_sfd_speculate = 1;                    // 0 never, 1 where spec_worthwhile() says so, 2 wherever the kernels apply
+void sfdec_configure(int speculate) { g_sfd_speculate = speculate; }
 
 // Does a decoder that starts 256 bits early agree with the true parse when it reaches the chunk?  Answered per table by
 // simulation on random bits (any bit string is a concatenation of code words of a complete code, distributed as the
@@ -1963,9 +1963,10 @@ void sfdec_configure(int speculate) { g_sfd_speculate = speculate != 0; }
 // the second lands on a start of the first.  Tables whose parsers fail to merge within 256 bits in more than 2 of 96
 // trials (Zipf-like data: ~0.2 %; uniform bytes, 8/9-bit codes: ~85 %) do not take the speculative kernels.
 // Verdicts are cached by a hash of the table (a launch usually repeats the previous launch's tables).
-static bool spec_worthwhile(const shafa_code_table &t, const HostTab &h)
+static bool spec_worthwhile(const shafa_code_table &t, const HostTab &h, bool force)
 {
     if (!h.ok || !h.complete || h.lmax > (u32)LEN_MAXK || h.lmax < 2) return false;
+    if (force) return true;
     u64 key = 1469598103934665603ull;
     for (int s2 = 0; s2 < 256; ++s2) {
         key = (key ^ t.len[s2]) * 1099511628211ull;
@@ -2074,11 +2075,11 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const size_t o_fsm1 = off; off += need_tabs ? (size_t)nblocks * 2048 : 0;
     const size_t o_cfn = off; off += packed ? (size_t)total_tiles * DEC_THREADS * 8 : (size_t)total_tiles * R * DEC_THREADS;
     // speculative entries (complete codes, Lmax <= 13, tables that re-synchronise): per-tile guess / exit / redo flag
-    const bool spec_path = packed && fast13 && multi && !long_all && g_sfd_speculate;
+    const bool spec_path = packed && fast13 && multi && !long_all && g_sfd_speculate != 0;
     std::vector<char> spec_blk(nblocks, 0);
     bool any_spec = false;
     for (int b = 0; spec_path && b < nblocks; ++b)
-        if (ntiles[b] && spec_worthwhile(h_tables[b], tabs[b])) { spec_blk[b] = 1; any_spec = true; }
+        if (ntiles[b] && spec_worthwhile(h_tables[b], tabs[b], g_sfd_speculate == 2)) { spec_blk[b] = 1; any_spec = true; }
     const size_t o_tguess = off; off += any_spec ? (size_t)total_tiles : 0; off = (off + 15) & ~(size_t)15;
     const size_t o_texit = off; off += any_spec ? (size_t)total_tiles : 0; off = (off + 15) & ~(size_t)15;
     const size_t o_tfix = off; off += any_spec ? (size_t)total_tiles : 0; off = (off + 15) & ~(size_t)15;
