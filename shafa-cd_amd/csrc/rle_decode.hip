@@ -2,11 +2,16 @@
 //
 // A 0 byte may be an escape, a symbol or a count, so token boundaries are found with a 3-state machine
 //     S0 (token start): b == 0 -> S1, else literal -> S0      S1 (symbol) -> S2      S2 (count) -> S0
-// whose per-byte transition maps {S0,S1,S2}->{S0,S1,S2} are composed with an ordered scan (6 bits per
-// map): lanes -> waves -> tiles (look-back over tile maps; a map that sends every state to the same
-// state ends the walk, which almost every tile's does).  Token output sizes ({0,s,c}: c, or 1 when
-// c == 0, d.c:179-184; literal: 1) are scanned for output offsets (second look-back, 64-bit), and the
-// output is filled in coalesced 16-byte pieces by binary-searching the tile's token table in LDS.
+// which only looks at "is the byte zero".  A lane takes 32 bytes: their zero mask indexes a 256-entry table (8 bytes
+// at a time: exit state and token-start mask for each of the three entry states), the lane's map {S0,S1,S2}->{S0,S1,S2}
+// (6 bits) is composed with an ordered scan lanes -> waves -> tiles (look-back over tile maps; a map that sends every
+// state to the same state ends the walk, which almost every tile's does).  With its entry state a lane has its
+// token-start mask, hence its literal mask L and escape mask E as bits, and SWAR gives the per-byte output lengths
+// (1 at a literal, the count byte two places on at an escape — 1 when that is 0, d.c:179-184 — else 0): their sum is
+// scanned for output offsets (second look-back, 64-bit).  The tile's output is then built in an LDS image aligned
+// like the output address — literals as byte writes at running positions (one add per byte), runs as aligned word
+// writes with the two end words ORed in — and leaves as aligned 16-byte stores.  A tile whose output exceeds the
+// image goes in rounds of consecutive lanes.
 //
 // Algorithmic HBM bytes per block: rle_n read + orig_n written.
 #include "common.hpp"
@@ -15,8 +20,31 @@
 namespace {
 
 constexpr int RLD_THREADS = 256;
-constexpr int RLD_TILE = RLD_THREADS * 16;
+constexpr int RLD_BPL = 32;                        // bytes per lane
+constexpr int RLD_TILE = RLD_THREADS * RLD_BPL;
+constexpr int RLD_IMG = 16 * 1024;                 // bytes of the output image
 constexpr u32 FN_IDENT = 0u | (1u << 2) | (2u << 4);
+
+// per 8-bit zero mask (bit i = byte i is 0) and entry state s: bits [10 s, 10 s + 8) = token starts, [10 s + 8, 10 s + 10) = exit
+struct RldFsm {
+    u32 v[256];
+    constexpr RldFsm() : v()
+    {
+        for (u32 z = 0; z < 256; ++z) {
+            u32 e = 0;
+            for (u32 s0 = 0; s0 < 3; ++s0) {
+                u32 st = s0, starts = 0;
+                for (u32 i = 0; i < 8; ++i) {
+                    if (st == 0) { starts |= 1u << i; st = ((z >> i) & 1u) ? 1u : 0u; }
+                    else st = st == 1 ? 2u : 0u;
+                }
+                e |= (starts | (st << 8)) << (10 * s0);
+            }
+            v[z] = e;
+        }
+    }
+};
+__device__ const RldFsm g_rld_fsm = RldFsm();
 
 struct RldBlk {
     const u8 *in;
@@ -81,15 +109,35 @@ __device__ __forceinline__ u32 lookback_state(const u64 *desc, int k, int *err)
 }
 
 struct RldShared {
-    u32 tok_off[RLD_TILE + 4];     // output offset (tile-local) of token t; [ntok] = tile total
-    u8 tok_sym[RLD_TILE + 16];
+    u8 in[RLD_TILE + 32];          // the tile, two look-ahead bytes, zeros
+    u8 img[RLD_IMG + 16];
+    u32 fsm[256];
     u32 wfn[4];
-    u32 wcnt[4];
     u32 wlen[4];
     u32 tile;
     u32 state_in;
+    u32 next;
     u64 O;
 };
+
+// bit i of a nibble -> 0x01 in byte i
+__device__ __forceinline__ u32 nib_flags(u32 mask, int i) { return (((mask >> (4 * i)) & 15u) * 0x00204081u) & 0x01010101u; }
+
+// `c` copies of `sym` at image byte p (c >= 1): whole words written, the two end words ORed into the zeroed image
+__device__ __forceinline__ void rld_fill(u8 *smem, u32 p, u32 sym, u32 c)
+{
+    const u32 pat = sym * 0x01010101u;
+    const u32 e = p + c, w0 = p & ~3u, w1 = e & ~3u;
+    const u32 hm = 0xFFFFFFFFu << (8 * (p & 3u));
+    const u32 tm = (e & 3u) ? (0xFFFFFFFFu >> (32 - 8 * (e & 3u))) : 0u;
+    if (w0 == w1) {
+        __hip_atomic_fetch_or((u32 *)__builtin_assume_aligned(smem + w0, 4), pat & hm & tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        __hip_atomic_fetch_or((u32 *)__builtin_assume_aligned(smem + w0, 4), pat & hm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (u32 a = w0 + 4; a < w1; a += 4) *(u32 *)__builtin_assume_aligned(smem + a, 4) = pat;
+        if (tm) __hip_atomic_fetch_or((u32 *)__builtin_assume_aligned(smem + w1, 4), pat & tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
 
 __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *__restrict__ blks, int nblk,
                                                                  u64 *desc_state, u64 *desc_sum, u32 *tickets)
@@ -100,36 +148,62 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
     const RldBlk blk = blks[b];
     if ((u32)(blockIdx.x / nblk) >= blk.n_tiles) return;
     if (tid == 0) sh.tile = atomicAdd(tickets + blk.ticket, 1u);
+    sh.fsm[tid] = g_rld_fsm.v[tid];
+    for (int i = tid; i < RLD_IMG / 16 + 1; i += RLD_THREADS) *(uint4 *)(sh.img + 16 * i) = make_uint4(0, 0, 0, 0);
+    if (tid < 2) *(uint4 *)(sh.in + RLD_TILE + 16 * tid) = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const int k = (int)sh.tile;
     const u64 n = blk.n;
-    const u64 pos = (u64)k * RLD_TILE + (u64)tid * 16;
+    const u64 pos = (u64)k * RLD_TILE + (u64)tid * RLD_BPL;
     u64 *dst = desc_state + blk.desc_base, *dsum = desc_sum + blk.desc_base;
 
-    // ---- load 16 bytes (+2 of look-ahead for a triple that starts at byte 14/15) --------------------------
-    u32 x[18];
+    // ---- the lane's 32 bytes -> registers and LDS; zero mask ---------------------------------------------------
+    u32 w[9];
     int nvalid = 0;
-    if (pos + 16 <= n) {
-        const uint4 v = *(const uint4 *)(blk.in + pos);
-        const u32 w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int j = 0; j < 16; ++j) x[j] = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-        nvalid = 16;
+    if (pos + RLD_BPL <= n) {
+        const uint4 v0 = *(const uint4 *)(blk.in + pos), v1 = *(const uint4 *)(blk.in + pos + 16);
+        w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
+        nvalid = RLD_BPL;
     } else {
         nvalid = pos < n ? (int)(n - pos) : 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) x[j] = (j < nvalid) ? (u32)blk.in[pos + j] : 0u;
-    }
-    x[16] = (pos + 16 < n) ? (u32)blk.in[pos + 16] : 0u;
-    x[17] = (pos + 17 < n) ? (u32)blk.in[pos + 17] : 0u;
-
-    // ---- this thread's transition map, then ordered scan over lanes and waves ----------------------------
-    u32 t0 = 0, t1 = 1, t2 = 2;
+        for (int i = 0; i < 8; ++i) w[i] = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        if (j < nvalid) { t0 = step(t0, x[j]); t1 = step(t1, x[j]); t2 = step(t2, x[j]); }
+        for (int j = 0; j < RLD_BPL; ++j)
+            if (j < nvalid) w[j >> 2] |= (u32)blk.in[pos + j] << (8 * (j & 3));
     }
-    u32 f = t0 | (t1 << 2) | (t2 << 4);
+    *(uint4 *)(sh.in + tid * RLD_BPL) = make_uint4(w[0], w[1], w[2], w[3]);
+    *(uint4 *)(sh.in + tid * RLD_BPL + 16) = make_uint4(w[4], w[5], w[6], w[7]);
+    if (tid == RLD_THREADS - 1) {       // count / symbol bytes of a triple that starts in the tile's last two bytes
+        const u32 la = (pos + 32 < n ? (u32)blk.in[pos + 32] : 0u) | (pos + 33 < n ? (u32)blk.in[pos + 33] << 8 : 0u);
+        *(u32 *)(sh.in + RLD_TILE) = la;
+    }
+    const u32 vm = nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
+    u32 z = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const u32 t = ((w[i] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w[i];
+        const u32 f = (~t >> 7) & 0x01010101u;                       // 0x01 in the zero bytes
+        z |= (((f * 0x00204081u) >> 21) & 15u) << (4 * i);
+    }
+    z &= vm;
+
+    // ---- this lane's transition map and token starts for each entry state, ordered scan over lanes and waves --------
+    u32 st3[3], ex3[3];
+    {
+        const u32 e0 = sh.fsm[z & 255u], e1 = sh.fsm[(z >> 8) & 255u], e2 = sh.fsm[(z >> 16) & 255u], e3 = sh.fsm[z >> 24];
+#pragma unroll
+        for (int s0 = 0; s0 < 3; ++s0) {
+            u32 x = (e0 >> (10 * s0)) & 1023u, starts = x & 255u;
+            x = (e1 >> (10 * (x >> 8))) & 1023u; starts |= (x & 255u) << 8;
+            x = (e2 >> (10 * (x >> 8))) & 1023u; starts |= (x & 255u) << 16;
+            x = (e3 >> (10 * (x >> 8))) & 1023u; starts |= (x & 255u) << 24;
+            st3[s0] = starts;
+            ex3[s0] = x >> 8;
+        }
+    }
+    // bytes past the end of the block do not move the state (vm clears them from every mask below)
+    u32 f = ex3[0] | (ex3[1] << 2) | (ex3[2] << 4);
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const u32 y = (u32)__shfl_up((int)f, d, 64);
@@ -141,11 +215,11 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
     __syncthreads();
     u32 wcar = FN_IDENT, ftile = FN_IDENT;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        if (w < wv) wcar = fn_compose(wcar, sh.wfn[w]);
-        ftile = fn_compose(ftile, sh.wfn[w]);
+    for (int q = 0; q < 4; ++q) {
+        if (q < wv) wcar = fn_compose(wcar, sh.wfn[q]);
+        ftile = fn_compose(ftile, sh.wfn[q]);
     }
-    const u32 fpre = fn_compose(wcar, fex);     // map of all bytes of the tile before this thread
+    const u32 fpre = fn_compose(wcar, fex);     // map of all bytes of the tile before this lane
 
     if (wv == 0) {
         u32 sin = 0;
@@ -163,59 +237,48 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
     }
     __syncthreads();
 
-    // ---- tokens of this thread ---------------------------------------------------------------------------------
-    u32 s = fn_apply(fpre, sh.state_in);
-    u32 tlen[16];
-    u32 cnt = 0, len = 0;
-    bool trunc = false;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        u32 l = 0;
-        if (j < nvalid) {
-            if (s == 0) {
-                if (x[j] == 0) {
-                    if (pos + j + 2 >= n) trunc = true;          // triple cut by the block end
-                    else l = x[j + 2] ? x[j + 2] : 1u;           // count 0 behaves as one literal (d.c:179-184)
-                } else l = 1;
-                cnt += 1;
-            }
-            s = step(s, x[j]);
-        }
-        tlen[j] = l;
-        len += l;
+    // ---- literal / escape masks, per-byte output lengths ------------------------------------------------------------
+    const u32 s_in = fn_apply(fpre, sh.state_in);
+    const u32 S = (s_in == 0 ? st3[0] : s_in == 1 ? st3[1] : st3[2]) & vm;
+    const u32 Lm = S & ~z;
+    u32 E = S & z;
+    {   // a triple cut by the end of the block: error, no output
+        const long long lim = (long long)n - (long long)pos - 2;           // escapes at j < lim have their count byte
+        const u32 ok = lim >= 32 ? 0xFFFFFFFFu : lim <= 0 ? 0u : ((1u << (int)lim) - 1u);
+        if (E & ~ok) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
+        E &= ok;
     }
-    // (a token start with l == 0 only happens for a truncated triple)
-    if (trunc) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
+    w[8] = *(const u32 *)(sh.in + (tid + 1) * RLD_BPL);                    // the next lane's first bytes / the look-ahead
+    u32 lenw[8], len = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const u32 fe = nib_flags(E, i);
+        const u32 cnt2 = __builtin_amdgcn_alignbit(w[i + 1], w[i], 16);    // the bytes two places on
+        lenw[i] = nib_flags(Lm, i) | (cnt2 & ((fe << 8) - fe));
+    }
+    {   // count byte 0 behaves as 1 (d.c:179-184)
+        const u32 t = ((w[8] & 0x7F7Fu) + 0x7F7Fu) | w[8];
+        const u32 zn = (~t >> 7) & 0x0101u;
+        const u64 z34 = (u64)z | ((u64)((zn & 1u) | ((zn >> 7) & 2u)) << 32);
+        const u32 ez = E & (u32)(z34 >> 2);
+        if (ez) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) lenw[i] |= nib_flags(ez, i);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) len = __builtin_amdgcn_sad_u8(lenw[i], 0u, len);
 
-    // ---- scan token counts and output lengths ----------------------------------------------------------------------
-    const u32 icnt = wave_incl_scan_add<u32>(cnt), ilen = wave_incl_scan_add<u32>(len);
-    if (lane == 63) { sh.wcnt[wv] = icnt; sh.wlen[wv] = ilen; }
+    // ---- output offsets --------------------------------------------------------------------------------------------
+    const u32 ilen = wave_incl_scan_add<u32>(len);
+    if (lane == 63) sh.wlen[wv] = ilen;
     __syncthreads();
-    u32 cbase = 0, lbase = 0, ctot = 0, ltot = 0;
+    u32 lbase = 0, ltot = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        if (w == wv) { cbase = ctot + icnt - cnt; lbase = ltot + ilen - len; }
-        ctot += sh.wcnt[w];
-        ltot += sh.wlen[w];
+    for (int q = 0; q < 4; ++q) {
+        if (q == wv) lbase = ltot + ilen - len;
+        ltot += sh.wlen[q];
     }
-    // token table
-    {
-        u32 s2 = fn_apply(fpre, sh.state_in), ti = cbase, lo = lbase;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (j < nvalid) {
-                if (s2 == 0) {
-                    sh.tok_off[ti] = lo;
-                    sh.tok_sym[ti] = (u8)(x[j] == 0 ? x[j + 1] : x[j]);
-                    ++ti;
-                    lo += tlen[j];
-                }
-                s2 = step(s2, x[j]);
-            }
-        }
-    }
-    if (tid == 0) sh.tok_off[ctot] = ltot;
-
     if (wv == 0) {
         u64 O = 0;
         if (k > 0) {
@@ -234,43 +297,63 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
     if (Oend > (u64)SHAFA_RLE_DECODE_MAX) { if (tid == 0) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE); }
     else if (Oend > blk.out_cap) { if (tid == 0) set_error(blk.err, SHAFA_LACK_OF_MEMORY); }
     if (k == (int)blk.n_tiles - 1 && tid == 0) *blk.out_n = Oend;
+    if (!ltot || O >= limit) return;
 
-    // ---- fill: 16-byte pieces aligned in the output, token found by binary search --------------------------------
-    if (ltot && O < limit) {
-        const u64 wend = Oend < limit ? Oend : limit;
-        const u64 c0 = O >> 4, c1 = (wend + 15) >> 4;
-        const int ntok = (int)ctot;
-        for (u64 c = c0 + tid; c < c1; c += RLD_THREADS) {
-            const u64 g0 = c << 4;
-            const u64 lo_g = g0 < O ? O : g0, hi_g = (g0 + 16 < wend) ? g0 + 16 : wend;
-            const u32 lstart = (u32)(lo_g - O);
-            // last token with tok_off <= lstart
-            int a = 0, z = ntok - 1;
-            while (a < z) {
-                const int mid = (a + z + 1) >> 1;
-                if (sh.tok_off[mid] <= lstart) a = mid; else z = mid - 1;
-            }
-            u32 wds[4] = {0, 0, 0, 0};
-            int t = a;
-            u32 nxt = sh.tok_off[t + 1];
-            u32 sym = sh.tok_sym[t];
+    // ---- build the output in the LDS image, store it in aligned 16-byte pieces ------------------------------------
+    u8 *smem = (u8 *)&sh;
+    const u32 img_off = (u32)offsetof(RldShared, img), in_off = (u32)offsetof(RldShared, in) + (u32)tid * RLD_BPL;
+    const u32 capw = RLD_IMG - 16;
+    for (u32 done = 0; done < ltot;) {
+        u8 *gout = blk.out + O + done;
+        const u32 mis = (u32)((uintptr_t)gout & 15u);
+        u32 nxt = ltot;
+        if (mis + (ltot - done) > capw) {               // (uniform) more than the image holds: consecutive lanes that fit
+            if (tid == 0) sh.next = ltot;
+            __syncthreads();
+            if (len && lbase >= done && mis + (lbase - done) + len > capw) atomicMin(&sh.next, lbase);
+            __syncthreads();
+            nxt = sh.next;
+            __syncthreads();
+        }
+        if (len && lbase >= done && lbase + len <= nxt) {
+            const u32 p0 = img_off + mis + (lbase - done);
+            {   // literals: running position, one byte write each
+                u32 p = p0;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const u64 gp = g0 + q;
-                if (gp >= lo_g && gp < hi_g) {
-                    const u32 lp = (u32)(gp - O);
-                    while (lp >= nxt) { ++t; nxt = sh.tok_off[t + 1]; sym = sh.tok_sym[t]; }
-                    wds[q >> 2] |= sym << (8 * (q & 3));
+                for (int j = 0; j < RLD_BPL; ++j) {
+                    if ((Lm >> j) & 1u) smem[p] = (u8)(w[j >> 2] >> (8 * (j & 3)));
+                    p += (lenw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
                 }
             }
-            if (lo_g == g0 && hi_g == g0 + 16) {
-                *(uint4 *)(blk.out + g0) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 16; ++q)
-                    if (g0 + q >= lo_g && g0 + q < hi_g) blk.out[g0 + q] = (u8)(wds[q >> 2] >> (8 * (q & 3)));
+            u32 g = 0;                                  // bytes of the runs so far
+            for (u32 e = E; e; e &= e - 1) {            // runs: the lane's escapes in order
+                const u32 j = (u32)__builtin_ctz(e);
+                const u32 sym = smem[in_off + j + 1], c0 = smem[in_off + j + 2], c = c0 ? c0 : 1u;
+                rld_fill(smem, p0 + (u32)__builtin_popcount(Lm & ((1u << j) - 1u)) + g, sym, c);
+                g += c;
             }
         }
+        __syncthreads();
+        const u32 end = mis + (nxt - done);             // image bytes [mis, end) are this round's output
+        const u64 gbase = O + done;                     // index of image byte `mis` in the block's output
+        for (u32 u = tid; 16 * u < end; u += RLD_THREADS) {
+            uint4 *ip = (uint4 *)(sh.img + 16 * u);
+            const uint4 v = *ip;
+            *ip = make_uint4(0, 0, 0, 0);
+            u8 *ga = gout - mis + 16 * u;
+            const u64 i0 = gbase + 16 * u - mis;        // index of the piece's first byte (wraps below 0 only where masked)
+            if (16 * u >= mis && 16 * u + 16 <= end && i0 + 16 <= limit) {
+                *(uint4 *)ga = v;
+            } else {
+                const u32 wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (u32 q = 0; q < 16; ++q)
+                    if (16 * u + q >= mis && 16 * u + q < end && gbase + (16 * u + q - mis) < limit)
+                        ga[q] = (u8)(wds[q >> 2] >> (8 * (q & 3)));
+            }
+        }
+        done = nxt;
+        if (done < ltot) __syncthreads();
     }
 }
 
