@@ -111,7 +111,10 @@ __device__ __forceinline__ u32 lookback_state(const u64 *desc, int k, int *err)
 struct RldShared {
     u8 in[RLD_TILE + 32];          // the tile, two look-ahead bytes, zeros
     u8 img[RLD_IMG + 16];
-    u32 fsm[256];
+    union {
+        u32 fsm[256];              // token-start table: used until the lane masks exist,
+        u32 dump[RLD_THREADS];     // then the words that swallow the byte writes of non-literal bytes
+    };
     u32 wfn[4];
     u32 wlen[4];
     u32 tile;
