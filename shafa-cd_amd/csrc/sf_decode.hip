@@ -40,7 +40,7 @@ constexpr int HALO_WORDS = 16;                     // 64 bytes past the tile (wi
 constexpr int DATA_WORDS = DTILE / 4 + HALO_WORDS;
 constexpr int LUT_MAXK = 11;
 constexpr int LUT2_MAX = 4096;                     // level-2 entries kept in LDS (8 KiB)
-constexpr int SYM3_MAXK = 12;                      // window of the three-codes table of sfd_write13: 16 KiB
+constexpr int SYM3_MAXK = 12;                      // widest window of the three-codes table of sfd_wstage: 16 KiB
 constexpr int LDS_DATA = (DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
 constexpr int LONG_PFX = 128;                      // codes longer than SYM3_MAXK bits, grouped by their first SYM3_MAXK bits
 constexpr int LONG_BYTES = 16 + LONG_PFX * 2 + LONG_PFX * 16 * 2;   // [n u16 x8 pad][pfx u16 x128][ent u16 x128x16]
@@ -1155,19 +1155,18 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) __attribute__((amdgpu_waves_per
 // skewed data re-synchronise: a decoder started at an arbitrary bit agrees with the true parse after a few dozen bits
 // (measured: started 256 bits early it is off at the chunk boundary in 0.2 % of the chunks of Zipf(1.2) mod 256 data,
 // 0.02 % for Zipf truncated to 256 ranks, 85 % for uniform bytes, whose 8/9-bit codes never merge).  So every lane
-// takes a strip of four chunks and
+// takes a strip of SPEC_STRIP chunks and
 //   1. walks the chunk BEFORE its strip from that chunk's first bit (three codes per look-up, cnt3), which leaves it at
 //      its guess of the strip's entry, then walks the strip, noting entry and code count of each chunk, to its exit;
 //   2. compares its guess with the exit of the lane before it; lanes that differ take that exit as their entry and walk
 //      again until they are back on their earlier path (a few rounds: a repaired lane's exit almost never moves).
-// A workgroup covers four tiles (wave w = tile w); its first lane guesses from the last chunk of the previous tile;
+// A workgroup covers SPEC_STRIP tiles; its first lane guesses from the last chunk of the previous tile;
 // sfd_spec_check compares every tile's guess with the previous tile's exit and sfd_spec<true> redoes the regions that
 // differ with the entry forced.  When every
 // comparison of a block holds — entry(c) == exit(c-1) for all chunks, entry 0 at the block's first bit — the entries
 // ARE the true parse, by induction: nothing is approximate.  A block that does not get there in the fixed number of
 // rounds sets *run_dp and goes through the exact kernels, which skip the blocks that verified; which blocks try at all
 // is decided per table on the host (spec_worthwhile()).  Outputs are those of sfd_countfsm.
-// static LDS: stream of the tile with 32 bytes in front (as load_tile: big-endian words, one pad word per 8) | cnt3 | exits
 // ================================================================================================
 constexpr int SPEC_STRIP = 2;                      // chunks per lane: the 256-bit run-up is paid once per strip
                                                    // (4: a fifth fewer steps, but twice the LDS per walk in flight: slower)
@@ -1377,17 +1376,18 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_spec_check(const DecBlk *__re
         __hip_atomic_store(blk.run_dp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// sfd_write13: static LDS: SUBS x data | lut13[2^13] u16 (MULTI: sym3[2^12] u32) | SUBS x wsum[4]
+// sfd_write13: the symbol pass for incomplete codes of <= 13 bits (one code per look-up, direct stores; complete
+// codes take sfd_wstage).  static LDS: SUBS x data | lut13[2^13] u16 | SUBS x wsum[4]
 // A workgroup is SUBS groups of 256 lanes, each decoding its own tile, sharing one copy of the table: the loop is
 // latency bound (dependent LDS look-ups), so what counts is waves per CU, and the table is what limits them.
-template <bool MULTI, int SUBS, int LONG>
+template <int SUBS>
 __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *__restrict__ blks,
                                                                   const u8 *__restrict__ chunk_entry,
                                                                   const u16 *__restrict__ chunk_cnt,
                                                                   const u64 *__restrict__ tile_off, u32 tpw)
 {
-    constexpr int TAB = MULTI ? (4 << SYM3_MAXK) : (2 << LEN_MAXK);
-    __shared__ __attribute__((aligned(16))) u8 smem[SUBS * LDS_DATA + TAB + SUBS * 16 + 64 + (LONG == 1 ? LONG_BYTES : LONG == 2 ? LONG32_BYTES : 0)];
+    constexpr int TAB = 2 << LEN_MAXK;
+    __shared__ __attribute__((aligned(16))) u8 smem[SUBS * LDS_DATA + TAB + SUBS * 16 + 64];
     const DecBlk blk = blks[blockIdx.y];
     const u32 first_tile = blockIdx.x * tpw * SUBS;
     if (first_tile >= blk.n_tiles) return;
@@ -1395,16 +1395,9 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *
     u32 *data = (u32 *)(smem + sub * LDS_DATA);
     u16 *lut = (u16 *)(smem + SUBS * LDS_DATA);
     u32 *wsum = (u32 *)(smem + SUBS * LDS_DATA + TAB) + sub * 4;
-    const u16 *lt = (const u16 *)(smem + SUBS * LDS_DATA + TAB + SUBS * 16 + 16);
     const u32 K1 = blk.K1;
     if (tile_off[(size_t)blk.tile_base + first_tile] >= blk.n_sym) return;   // all padding / past the end
-    const u32 K3 = K1 < (u32)SYM3_MAXK ? K1 : (u32)SYM3_MAXK;
-    fill_lds16(lut, MULTI ? (const void *)blk.sym3 : (const void *)blk.lut13, MULTI ? (4u << K3) : (2u << K1));
-    if (LONG) {
-        const u16 *src = LONG == 1 ? blk.longtab : blk.long32;
-        if (src) fill_lds16((void *)lt, src, LONG == 1 ? LONG_BYTES : LONG32_BYTES);
-        else if (threadIdx.x == 0) *(u16 *)lt = 0;
-    }
+    fill_lds16(lut, (const void *)blk.lut13, 2u << K1);
     bool bad = false;
     for (u32 it = 0; it < tpw && first_tile + it * SUBS < blk.n_tiles; ++it) {
     const u32 tile = first_tile + it * SUBS + sub;
@@ -1434,46 +1427,6 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *
     u64 acc = 0;
     BitBuf bb;
     bb.init(data, cbase + p);
-    if (MULTI) {
-        const u32 *tab = (const u32 *)lut;
-        const u32 sh3 = 32 - K3;
-        u32 nb = 0;                                     // bytes waiting in acc (< 8 between iterations)
-        u64 pend = 0;                                   // a full first half waiting for its second half
-        bool have_pend = false;
-        while (want) {                                  // up to three symbols per lookup; stops on the count
-            u32 e = tab[bb.peek32() >> sh3];
-            if (__builtin_expect((e >> 30) == 0, 0)) {  // first code longer than the window: one code from lut13 / the long table
-                u32 e1 = LONG == 1 ? long_code(lt, bb.peek32()) : LONG == 2 ? long_code32(lt, bb.peek32())
-                                   : (u32)gload<u16>(blk.lut13 + (bb.peek32() >> sh));
-                if (e1 == 0) { bad = true; e1 = 1u << 8; }      // not a code (complete tables never get here)
-                e = (e1 & 0xFFu) | ((e1 >> 8) << 24) | (1u << 30);
-            }
-            const u32 n = e >> 30, take = n < want ? n : want, syms = e & 0xFFFFFFu;
-            acc |= (u64)syms << (8 * nb);
-            const u32 room = 8 - nb;                    // bytes of `syms` that fitted
-            nb += take;
-            want -= take;
-            if (nb >= 8) {                              // sixteen symbols per store (any byte alignment)
-                if (have_pend) {
-                    gstore<uint4>(op, make_uint4((u32)pend, (u32)(pend >> 32), (u32)acc, (u32)(acc >> 32)));
-                    op += 16;
-                } else {
-                    pend = acc;
-                }
-                have_pend = !have_pend;
-                nb -= 8;
-                acc = room < 3 ? (u64)(syms >> (8 * room)) : 0ull;
-            }
-            {
-                const u32 tot = (e >> 24) & 63u;
-                p += tot;
-                if (LONG == 2 && __builtin_expect(tot > 31, 0)) bb.init(data, cbase + p); else bb.skip(data, tot);
-            }
-        }
-        if (have_pend) { gstore<u64>(op, pend); op += 8; }
-        for (u32 q = 0; q < nb; ++q) gstore<u8>(op + q, (u8)(acc >> (8 * q)));
-        continue;
-    }
     while (want) {                                      // exactly the symbols counted by sfd_count13
         const u32 e = lut[bb.peek32() >> sh];
         u32 len = e >> 8, sym = e & 0xFF;
@@ -1960,7 +1913,7 @@ void sfdec_configure(int speculate) { g_sfd_speculate = speculate; }
 // Does a decoder that starts 256 bits early agree with the true parse when it reaches the chunk?  Answered per table by
 // simulation on random bits (any bit string is a concatenation of code words of a complete code, distributed as the
 // code's own lengths imply): the true parser starts at bit 0, a second one at a random offset 1..15; they "merge" when
-// the second lands on a start of the first.  Tables whose parsers fail to merge within 256 bits in more than 2 of 96
+// the second lands on a start of the first.  Tables whose parsers fail to merge within 256 bits in more than 1 of 32
 // trials (Zipf-like data: ~0.2 %; uniform bytes, 8/9-bit codes: ~85 %) do not take the speculative kernels.
 // Verdicts are cached by a hash of the table (a launch usually repeats the previous launch's tables).
 static bool spec_worthwhile(const shafa_code_table &t, const HostTab &h, bool force)
@@ -1972,15 +1925,15 @@ static bool spec_worthwhile(const shafa_code_table &t, const HostTab &h, bool fo
         key = (key ^ t.len[s2]) * 1099511628211ull;
         for (int q = 0; q < (t.len[s2] + 7) / 8; ++q) key = (key ^ t.bits[s2][q]) * 1099511628211ull;
     }
-    static u64 ckey[256];
-    static signed char cval[256];                       // 0 = empty, 1 = no, 2 = yes
-    const u32 slot = (u32)(key >> 17) & 255u;
+    static u64 ckey[1024];
+    static signed char cval[1024];                      // 0 = empty, 1 = no, 2 = yes
+    const u32 slot = (u32)(key >> 17) & 1023u;
     if (cval[slot] && ckey[slot] == key) return cval[slot] == 2;
     const u32 K1 = h.K1;
     u64 rs = key | 1ull;
     auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; };
     int fails = 0;
-    for (int trial = 0; trial < 96 && fails <= 2; ++trial) {
+    for (int trial = 0; trial < 32 && fails <= 1; ++trial) {
         u64 w[6];                                       // 384 random bits, bit i = bit (63 - i % 64) of w[i / 64]
         for (u64 &x : w) x = rnd();
         auto window = [&](u32 pos) -> u32 {             // the K1 bits at pos, MSB first
@@ -1999,7 +1952,7 @@ static bool spec_worthwhile(const shafa_code_table &t, const HostTab &h, bool fo
         }
         if (!merged) ++fails;
     }
-    const bool yes = fails <= 2;
+    const bool yes = fails <= 1;
     ckey[slot] = key;
     cval[slot] = yes ? 2 : 1;
     return yes;
@@ -2273,7 +2226,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
             hipLaunchKernelGGL((sfd_wstage<0>), grid_f, dim3(DEC_THREADS), lds_ws, st, dblk,
                                (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, ws_tab, ws_cap);
         else
-            hipLaunchKernelGGL((sfd_write13<false, WSUBS, 0>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
+            hipLaunchKernelGGL((sfd_write13<WSUBS>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
                                (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw);
     } else {
         hipLaunchKernelGGL(sfd_write, grid_t, dim3(DEC_THREADS), lds_write, st, dblk, l2cap, (const u8 *)(ws + o_cent),
