@@ -288,8 +288,9 @@ __global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *
         if (cur >= nfull) continue;
         u32 req = E4_NONE;
         if (tid == 0) req = atomicAdd(tick, 1u);
-        TileIn cin, nin;
+        TileIn cin, nin, nin2;                         // inputs are requested two tiles ahead
         load_tile(in, cur, tid, cin);
+        if (nxt < nfull) load_tile(in, nxt, tid, nin);
         // wave 0: descriptor windows and the 32 symbols in front of the tiles in the pipeline (q = one iteration old, p = two)
         u64 first_q = 0, first_p = 0;
         u32 c_pv = 0, q_pv = 0, p_pv = 0;
@@ -303,7 +304,6 @@ __global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *
             const bool cur_ok = cur < nfull;
             const bool have_q = q_tile != E4_NONE, have_p = p_tile != E4_NONE;
             if (!cur_ok && !have_q && !have_p) break;
-            const bool nxt_ok = cur_ok && nxt < nfull;
             const u32 pbuf = buf >= 2 ? buf - 2 : buf + 1;
             u32 *win = dynwin + buf * win_stride + E4_GUARD;               // this tile's window
             u32 *pwin = dynwin + pbuf * win_stride + E4_GUARD;             // the window that is stored in this iteration
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *
                 if (cur_ok && cur > 0 && lane < 32) c_pv = gload_off<u8>(in + (u64)cur * E4_TILE - 32, 31u - (u32)lane);
             }
             E4_T(7);
-            if (nxt_ok) load_tile(in, nxt, tid, nin);
+            if (cur_ok && nn < nfull) load_tile(in, nn, tid, nin2);
 
             // ---- this tile: zero its window, look up, group, scan ------------------------------------------------
             if (cur_ok) {
@@ -392,6 +392,7 @@ __global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *
             buf = buf == 2 ? 0 : buf + 1;
             cur = nxt;
             cin = nin;
+            nin = nin2;
             nxt = nn;
             nn = n3;
         }
