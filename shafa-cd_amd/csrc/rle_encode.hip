@@ -5,11 +5,13 @@
 //     r = (i - head(i)) mod 255          e = min(255, end(i) - i)
 //     r == 0 : emit {0, s, e} if s == 0 or e >= 4, else the literal s
 //     r  > 0 : emit the literal s if s != 0 and r + e < 4, else nothing
-// r needs the run length that enters a tile from the left (a chained look-back over tiles that are
-// one single run), e needs at most 255 bytes of look-ahead (a halo read).  Output offsets are an
-// exclusive scan of the emit sizes, chained across tiles by a second look-back.  Tiles are taken in
-// ticket order per block (deadlock-free for any dispatch order); tokens are staged in LDS and stored
-// as aligned words.
+// r needs the run length that enters a tile from the left, e needs at most 255 bytes of look-ahead (a halo read), the
+// output offset of a tile the sizes of all tiles before it.  Three passes of independent workgroups and two tiny
+// per-block scans deliver them (rle3_* below: no tickets, no look-backs); tokens are staged in LDS and stored as
+// aligned words.  (A single chained pass — one read of the input — was built twice, rounds 1 and 2: on inputs that
+// take the mask code it is no faster, a workgroup spends 10 of its 15 us waiting for its ticket, its loads and its two
+// look-backs, and on long runs its general tile code is 40 times slower; it needs the deferred look-backs of a
+// persistent pipeline like sfe4's to pay)
 //
 // Algorithmic HBM bytes per block: n read + rle_n written.
 #include "common.hpp"
@@ -43,63 +45,20 @@ __device__ __forceinline__ Seg comb_f(Seg a, Seg b) { return Seg{a.f & b.f, b.f 
 // backward: combine(left a, right b) — a's run absorbs b's
 __device__ __forceinline__ Seg comb_b(Seg a, Seg b) { return Seg{a.f & b.f, a.f ? a.v + b.v : a.v}; }
 
-#define RUN_C_BIT 40
-#define RUN_V_MASK ((1ull << RUN_C_BIT) - 1)
-
-// run length (from its true head inside the block) of the run that ends at the last byte of tile k-1
-__device__ __forceinline__ u64 lookback_run(const u64 *desc, int k, int *err)
-{
-    const int lane = lane_id();
-    u64 acc = 0;
-    int j = k - 1;
-    for (;;) {
-        const int idx = j - lane;
-        u64 d = 0;
-        u32 spins = 0;
-        for (;;) {
-            d = (idx >= 0) ? desc_load(desc + idx) : (DESC_PREFIX << 62);
-            if (__all((d >> 62) != DESC_EMPTY)) break;
-            if (++spins > SPIN_LIMIT) {
-                if (lane == 0) set_error(err, SHAFA_DEVICE_ERROR);
-                if ((d >> 62) == DESC_EMPTY) d = (DESC_PREFIX << 62);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        const u64 val = d & RUN_V_MASK;
-        const bool stop = ((d >> 62) == DESC_PREFIX) || !((d >> RUN_C_BIT) & 1);
-        const u64 m = __ballot(stop);
-        if (m) {
-            const int pl = __ffsll((unsigned long long)m) - 1;
-            acc += wave_reduce_add<u64>(lane <= pl ? val : 0ull);
-            break;
-        }
-        acc += wave_reduce_add<u64>(val);
-        j -= 64;
-    }
-    return acc;
-}
-
 struct RleShared {
     u32 stage[RLE_STAGE / 4];
     Seg wf[4], wb[4];
     u32 wsum[4];
-    u32 tile;
     u32 R;          // run length entering the tile from the left
     u32 H;          // bytes after the tile equal to its last byte (<= 255)
-    u32 pad;
-    u64 G;          // output byte offset of the tile
     u16 E[260];     // fast path: equality masks of the threads, [0] = the 16 bytes before the tile, [257] = after
     u16 lastb[258]; // fast path: last byte of every thread, [0] = the byte before the tile (0x100: none)
-    u32 slow;       // fast path: fall back to the general tile code
 };
 
 // General tile code: any input (runs of any length, ragged last tile).  Per element closed form.
-// MODE 0: chained (look-backs over drun / dsum); 1: sizes only, carry Rin given, tile total to *Tout;
-// 2: emit, carry Rin and output offset Gin given.
+// MODE 1: sizes only, carry Rin given, tile total to *Tout; 2: emit, carry Rin and output offset Gin given.
 template <int MODE>
-__device__ __forceinline__ void rle_tile_general(RleShared &sh, const RleBlk &blk, const int k, u64 *drun, u64 *dsum,
-                                                 u64 Rin = 0, u64 Gin = 0, u32 *Tout = nullptr)
+__device__ __forceinline__ void rle_tile_general(RleShared &sh, const RleBlk &blk, const int k, u64 Rin, u64 Gin, u32 *Tout)
 {
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     const u64 n = blk.n;
@@ -171,19 +130,8 @@ __device__ __forceinline__ void rle_tile_general(RleShared &sh, const RleBlk &bl
 
     // ---- tile-level: run entering from the previous tile (look-back #1) and halo -----------------------
     if (wv == 0) {
-        const bool tile_cont = ftot.f != 0;                 // the whole tile is one run that continues
         const bool need_R = __shfl((int)eq0, 0, 64) != 0;   // first byte equals the byte before the tile
-        u64 R = 0;
-        if (MODE == 0) {
-            if (tid == 0) {
-                if (tile_cont) desc_store(drun + k, DESC_AGG, (u64)ftot.v | (1ull << RUN_C_BIT));
-                else desc_store(drun + k, DESC_PREFIX, (u64)ftot.v);
-            }
-            if (need_R && k > 0) R = lookback_run(drun, k, blk.err);
-            if (tid == 0 && tile_cont) desc_store(drun + k, DESC_PREFIX, R + ftot.v);
-        } else {
-            R = (need_R && k > 0) ? Rin : 0;
-        }
+        const u64 R = (need_R && k > 0) ? Rin : 0;
         if (tid == 0) sh.R = (u32)(R % 255u);
     } else if (wv == 1) {
         u32 H = 0;
@@ -250,21 +198,7 @@ __device__ __forceinline__ void rle_tile_general(RleShared &sh, const RleBlk &bl
         if (tid == 0) *Tout = T;
         return;
     }
-    if (MODE == 0) {
-        if (wv == 0) {
-            u64 G = 0;
-            if (k > 0) {
-                if (tid == 0) desc_store(dsum + k, DESC_AGG, T);
-                G = lookback_sum(dsum, k, blk.err);
-            }
-            if (tid == 0) {
-                desc_store(dsum + k, DESC_PREFIX, G + T);
-                sh.G = G;
-            }
-        }
-        __syncthreads();
-    }
-    const u64 G = MODE == 0 ? sh.G : Gin;
+    const u64 G = Gin;
     const u32 shift = (u32)G & 3;
 
     // ---- tokens into LDS (byte offset keeps the global 4-byte phase), then aligned word stores -----------
@@ -299,7 +233,6 @@ __device__ __forceinline__ void rle_tile_general(RleShared &sh, const RleBlk &bl
             }
         }
     }
-    if (MODE == 0 && k == (int)blk.n_tiles - 1 && tid == 0) *blk.out_n = end_b;
 }
 
 
@@ -311,155 +244,6 @@ __device__ __forceinline__ u32 eqmask4(u32 a, u32 b)
     t = ~(t | d | 0x7F7F7F7Fu);                       // 0x80 in every byte of d that is zero
     const u32 m = t >> 7;
     return (m | (m >> 7) | (m >> 14) | (m >> 21)) & 0xFu;
-}
-
-// Fast tile code: full tiles in which no thread's 16 bytes are all equal to the byte before them (so every run that
-// touches the tile is shorter than 32 bytes inside it) and whose entering run is shorter than 200.  Then no run needs
-// the mod-255 segmentation here and everything follows from bit masks: E = "equals the previous byte", Z = "is zero";
-// a byte is in a run of >= 4 iff three consecutive E bits cover it (3 bits of context on each side suffice).
-//   literal : non-zero byte of a run of < 4        triple {0, s, L} : head of a zero run or of a run of >= 4
-// Returns false (nothing emitted, general code must run) when the conditions do not hold.
-__device__ __forceinline__ bool rle_tile_fast(RleShared &sh, const RleBlk &blk, const int k, u64 *drun, u64 *dsum)
-{
-    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
-    const u64 n = blk.n;
-    const u64 tile_start = (u64)k * RLE_TILE, tile_end = tile_start + RLE_TILE;
-    if (tile_end + 4 > n) return false;                // ragged / last tiles: general code (uniform)
-    const u64 pos = tile_start + (u64)tid * 16;
-    const uint4 v = *(const uint4 *)(blk.in + pos);
-    const u32 w[4] = {v.x, v.y, v.z, v.w};
-    sh.lastb[tid + 1] = (u16)(w[3] >> 24);
-    if (tid == 0) {
-        u32 e0 = 0, lb = 0x100u;                       // first tile: nothing before it
-        if (k > 0) {
-            const u32 q = *(const u32 *)(blk.in + tile_start - 4);      // bytes -4 .. -1
-            e0 = (eqmask4(q, q << 8) >> 1) << 13;      // E of positions -3, -2, -1 in bits 13..15
-            lb = q >> 24;
-        }
-        sh.E[0] = (u16)e0;
-        sh.lastb[0] = (u16)lb;
-        sh.slow = 0;
-    }
-    if (tid == RLE_THREADS - 1) {
-        const u32 q = *(const u32 *)(blk.in + tile_end);                // bytes 4096 .. 4099 of the tile's frame
-        sh.E[RLE_THREADS + 1] = (u16)(eqmask4(q, (q << 8) | (w[3] >> 24)) & 7u);
-    }
-    __syncthreads();
-    const u32 pb = sh.lastb[tid];
-    const u32 p0 = (w[0] << 8) | (pb & 0xFFu);
-    u32 E16 = eqmask4(w[0], p0) | (eqmask4(w[1], __builtin_amdgcn_alignbit(w[1], w[0], 24)) << 4) |
-              (eqmask4(w[2], __builtin_amdgcn_alignbit(w[2], w[1], 24)) << 8) |
-              (eqmask4(w[3], __builtin_amdgcn_alignbit(w[3], w[2], 24)) << 12);
-    if (pb > 0xFFu) E16 &= ~1u;
-    const u32 Z16 = eqmask4(w[0], 0) | (eqmask4(w[1], 0) << 4) | (eqmask4(w[2], 0) << 8) | (eqmask4(w[3], 0) << 12);
-    sh.E[tid + 1] = (u16)E16;
-    if (__syncthreads_or(E16 == 0xFFFFu)) return false;   // a thread inside one long run: general code
-
-    // run entering the tile (look-back #1) and halo; the tile's descriptor: its trailing run, never "all one run"
-    const u32 H16 = ~E16 & 0xFFFFu;                      // run heads; every thread has one here
-    if (tid == RLE_THREADS - 1) desc_store(drun + k, DESC_PREFIX, (u64)(__builtin_clz(H16) - 15));   // 16 - msb(H16)
-    if (wv == 0) {
-        const bool need_R = (sh.E[1] & 1u) != 0;
-        u64 R = 0;
-        if (need_R && k > 0) R = lookback_run(drun, k, blk.err);
-        if (tid == 0 && R >= 200) sh.slow = 1;           // the 255-byte segmentation could reach into this tile
-    } else if (wv == 1) {
-        u32 H = 0;
-        const u32 lastb = sh.lastb[RLE_THREADS];
-        const u64 q = tile_end + (u64)lane * 4;
-        u32 cnt = 0;
-        bool go = true;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const u32 c = (q + j < n) ? (u32)blk.in[q + j] : 0x400u;
-            go &= (c == lastb);
-            cnt += go ? 1u : 0u;
-        }
-        const u64 full = __ballot(cnt == 4);
-        const int l0 = (~full) ? (__ffsll((unsigned long long)~full) - 1) : 64;
-        const u32 c0 = (l0 < 64) ? (u32)__shfl((int)cnt, l0, 64) : 0u;
-        H = (u32)l0 * 4 + c0;
-        if (H > 255) H = 255;
-        if (lane == 0) sh.H = H;
-    }
-    __syncthreads();
-    if (sh.slow) return false;
-
-    // ---- classification -----------------------------------------------------------------------------------
-    const u32 B = ((u32)sh.E[tid] >> 13) | (E16 << 3) | (((u32)sh.E[tid + 2] & 7u) << 19);   // positions -3 .. 18
-    const u32 T = B & (B >> 1) & (B >> 2);
-    const u32 LC = (((T >> 1) | T | (T << 1) | (T << 2)) >> 3) & 0xFFFFu;                     // bytes of runs of >= 4
-    const u32 Lit = ~Z16 & ~LC & 0xFFFFu;
-    const u32 T3 = H16 & (Z16 | LC);
-    const u32 tot = (u32)__builtin_popcount(Lit) + 3u * (u32)__builtin_popcount(T3);
-
-    // ---- output offsets: workgroup scan + look-back #2 ----------------------------------------------------
-    const u32 incl = wave_incl_scan_add<u32>(tot);
-    if (lane == 63) sh.wsum[wv] = incl;
-    __syncthreads();
-    u32 run = 0, off = 0;
-#pragma unroll
-    for (int ww = 0; ww < 4; ++ww) {
-        if (ww == wv) off = run + incl - tot;
-        run += sh.wsum[ww];
-    }
-    const u32 Tt = run;
-    if (wv == 0) {
-        u64 G = 0;
-        if (k > 0) {
-            if (tid == 0) desc_store(dsum + k, DESC_AGG, Tt);
-            G = lookback_sum(dsum, k, blk.err);
-        }
-        if (tid == 0) {
-            desc_store(dsum + k, DESC_PREFIX, G + Tt);
-            sh.G = G;
-        }
-    }
-    __syncthreads();
-    const u64 G = sh.G;
-    const u32 shift = (u32)G & 3;
-
-    // ---- tokens into LDS, then aligned word stores -----------------------------------------------------------
-    u8 *st8 = (u8 *)sh.stage;
-    u32 o = shift + off;
-    const u32 Hn = tid == RLE_THREADS - 1 ? 0u : (~(u32)sh.E[tid + 2] & 0xFFFFu);   // heads of the next thread
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const u32 xj = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-        if ((T3 >> j) & 1u) {
-            const u32 hn = H16 >> (j + 1);
-            u32 L;
-            if (j < 15 && hn) L = (u32)__builtin_ctz(hn) + 1;                       // next head inside this thread
-            else if (tid != RLE_THREADS - 1) L = (16 - j) + (u32)__builtin_ctz(Hn); // in the next thread
-            else { L = (16 - j) + sh.H; L = L > 255u ? 255u : L; }                  // past the tile: halo count
-            st8[o] = 0; st8[o + 1] = (u8)xj; st8[o + 2] = (u8)L;
-            o += 3;
-        } else if ((Lit >> j) & 1u) {
-            st8[o] = (u8)xj;
-            o += 1;
-        }
-    }
-    __syncthreads();
-    const u64 end_b = G + Tt;
-    if (end_b > blk.out_cap) {
-        if (tid == 0) set_error(blk.err, SHAFA_LACK_OF_MEMORY);
-    } else {
-        const u32 nwords = (shift + Tt + 3) >> 2;
-        const u64 gw0 = G >> 2;
-        for (u32 ww = tid; ww < nwords; ww += RLE_THREADS) {
-            const u32 val = sh.stage[ww];
-            const u64 byte0 = (gw0 + ww) * 4;
-            if (byte0 >= G && byte0 + 4 <= end_b) {
-                ((u32 *)blk.out)[gw0 + ww] = val;
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (byte0 + q >= G && byte0 + q < end_b) blk.out[byte0 + q] = (u8)(val >> (8 * q));
-            }
-        }
-    }
-    if (k == (int)blk.n_tiles - 1 && tid == 0) *blk.out_n = end_b;
-    return true;
 }
 
 // ================================================================================================
@@ -631,7 +415,7 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_pass(const RleBlk *__restric
     }
     if (!fast) {
         __syncthreads();
-        rle_tile_general<MODE>(sh, blk, k, nullptr, nullptr, Rin, Gin, Tarr + blk.desc_base + k);
+        rle_tile_general<MODE>(sh, blk, k, Rin, Gin, Tarr + blk.desc_base + k);
         return;
     }
     const u32 E16 = c.E16, Z16 = c.Z16, H16 = ~E16 & 0xFFFFu;
@@ -752,14 +536,11 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
         ndesc += t;
         if (t > max_tiles) max_tiles = (u32)t;
     }
-    // workspace: [desc_run][desc_sum][tickets] (zeroed) [RleBlk]
+    // workspace: [G: output offset per tile] [RleBlk] [tsum] [R] [T]
     size_t off = 0;
-    const size_t o_run = off; off += ndesc * 8;
-    const size_t o_sum = off; off += ndesc * 8;
-    const size_t o_tick = off; off += (size_t)nblocks * 4; off = (off + 15) & ~(size_t)15;
-    const size_t o_zero_end = off;
+    const size_t o_sum = off; off += ndesc * 8; off = (off + 15) & ~(size_t)15;
     const size_t o_blk = off; off += (size_t)nblocks * sizeof(RleBlk); off = (off + 15) & ~(size_t)15;
-    const size_t o_tsum = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;     // three-pass path
+    const size_t o_tsum = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;
     const size_t o_R = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;
     const size_t o_T = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;
     int rc = batch_reserve(bt, st, off);
@@ -782,14 +563,13 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
         e.pad = 0;
         dbase += e.n_tiles;
     }
-    HIP_TRY(hipMemsetAsync(ws, 0, o_zero_end, st));
     HIP_TRY(hipMemsetAsync(d_out_n, 0, (size_t)nblocks * 8, st));      // empty blocks: size 0
     HIP_TRY(hipMemcpyAsync(ws + o_blk, hb, (size_t)nblocks * sizeof(RleBlk), hipMemcpyHostToDevice, st));
     if (max_tiles) {
         const RleBlk *dblk = (const RleBlk *)(ws + o_blk);
         const dim3 grid_t(max_tiles, (u32)nblocks), grid_b((u32)nblocks);
         u32 *tsum = (u32 *)(ws + o_tsum), *Rr = (u32 *)(ws + o_R), *Tt = (u32 *)(ws + o_T);
-        u64 *Gg = (u64 *)(ws + o_sum);                     // the chained path's descriptor array doubles as G
+        u64 *Gg = (u64 *)(ws + o_sum);
         hipLaunchKernelGGL(rle3_summary, grid_t, dim3(RLE_THREADS), 0, st, dblk, tsum);
         hipLaunchKernelGGL(rle3_carry, grid_b, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)tsum, Rr);
         hipLaunchKernelGGL(rle3_pass<1>, grid_t, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Rr, Tt, (const u64 *)Gg);
