@@ -8,10 +8,11 @@
 // state to the same state ends the walk, which almost every tile's does).  With its entry state a lane has its
 // token-start mask, hence its literal mask L and escape mask E as bits, and SWAR gives the per-byte output lengths
 // (1 at a literal, the count byte two places on at an escape — 1 when that is 0, d.c:179-184 — else 0): their sum is
-// scanned for output offsets (second look-back, 64-bit).  The tile's output is then built in an LDS image aligned
-// like the output address — literals as byte writes at running positions (one add per byte), runs as aligned word
-// writes with the two end words ORed in — and leaves as aligned 16-byte stores.  A tile whose output exceeds the
-// image goes in rounds of consecutive lanes.
+// scanned for output offsets (second look-back, 64-bit).  The tile's output is built in an LDS image
+// — literals as byte writes at running positions (one add per byte), runs as word writes with byte writes at both
+// ends — while wave 0 is still looking back for the tile's output offset, and leaves as aligned 16-byte stores (five
+// dwords of the image funnel-shifted by the offset's misalignment).  A tile whose output exceeds the image goes in
+// rounds of consecutive lanes.
 //
 // Algorithmic HBM bytes per block: rle_n read + orig_n written.
 #include "common.hpp"
@@ -110,7 +111,7 @@ __device__ __forceinline__ u32 lookback_state(const u64 *desc, int k, int *err)
 
 struct RldShared {
     u8 in[RLD_TILE + 32];          // the tile, two look-ahead bytes, zeros
-    u8 img[RLD_IMG + 16];
+    u8 img[RLD_IMG + 48];          // 16 bytes in front (a piece may start before the image), slack for the last piece
     union {
         u32 fsm[256];              // token-start table: used until the lane masks exist,
         u32 dump[RLD_THREADS];     // then the words that swallow the byte writes of non-literal bytes
@@ -124,22 +125,23 @@ struct RldShared {
 };
 
 // bit i of a nibble -> 0x01 in byte i
-__device__ __forceinline__ u32 nib_flags(u32 mask, int i) { return (((mask >> (4 * i)) & 15u) * 0x00204081u) & 0x01010101u; }
+__device__ __forceinline__ u32 nib_flags(u32 mask, int i) { return __umul24((mask >> (4 * i)) & 15u, 0x00204081u) & 0x01010101u; }
 
-// `c` copies of `sym` at image byte p (c >= 1): whole words written, the two end words ORed into the zeroed image
+// `c` copies of `sym` at image byte p (c >= 1): bytes up to the word boundary, whole words, the bytes left
 __device__ __forceinline__ void rld_fill(u8 *smem, u32 p, u32 sym, u32 c)
 {
     const u32 pat = sym * 0x01010101u;
-    const u32 e = p + c, w0 = p & ~3u, w1 = e & ~3u;
-    const u32 hm = 0xFFFFFFFFu << (8 * (p & 3u));
-    const u32 tm = (e & 3u) ? (0xFFFFFFFFu >> (32 - 8 * (e & 3u))) : 0u;
-    if (w0 == w1) {
-        __hip_atomic_fetch_or((u32 *)__builtin_assume_aligned(smem + w0, 4), pat & hm & tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else {
-        __hip_atomic_fetch_or((u32 *)__builtin_assume_aligned(smem + w0, 4), pat & hm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        for (u32 a = w0 + 4; a < w1; a += 4) *(u32 *)__builtin_assume_aligned(smem + a, 4) = pat;
-        if (tm) __hip_atomic_fetch_or((u32 *)__builtin_assume_aligned(smem + w1, 4), pat & tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    const u32 to_b = (4u - (p & 3u)) & 3u, h = to_b < c ? to_b : c;
+#pragma unroll
+    for (u32 q = 0; q < 3; ++q)
+        if (q < h) smem[p + q] = (u8)sym;
+    p += h;
+    c -= h;
+    const u32 e = p + (c & ~3u);
+    for (; p < e; p += 4) *(u32 *)__builtin_assume_aligned(smem + p, 4) = pat;
+#pragma unroll
+    for (u32 q = 0; q < 3; ++q)
+        if (q < (c & 3u)) smem[p + q] = (u8)sym;
 }
 
 __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *__restrict__ blks, int nblk,
@@ -152,7 +154,6 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
     if ((u32)(blockIdx.x / nblk) >= blk.n_tiles) return;
     if (tid == 0) sh.tile = atomicAdd(tickets + blk.ticket, 1u);
     sh.fsm[tid] = g_rld_fsm.v[tid];
-    for (int i = tid; i < RLD_IMG / 16 + 1; i += RLD_THREADS) *(uint4 *)(sh.img + 16 * i) = make_uint4(0, 0, 0, 0);
     if (tid < 2) *(uint4 *)(sh.in + RLD_TILE + 16 * tid) = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const int k = (int)sh.tile;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
     u32 w[9];
     int nvalid = 0;
     if (pos + RLD_BPL <= n) {
-        const uint4 v0 = *(const uint4 *)(blk.in + pos), v1 = *(const uint4 *)(blk.in + pos + 16);
+        const uint4 v0 = gload_nt<uint4>(blk.in + pos), v1 = gload_nt<uint4>(blk.in + pos + 16);
         w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
         nvalid = RLD_BPL;
     } else {
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
     for (int i = 0; i < 8; ++i) {
         const u32 t = ((w[i] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w[i];
         const u32 f = (~t >> 7) & 0x01010101u;                       // 0x01 in the zero bytes
-        z |= (((f * 0x00204081u) >> 21) & 15u) << (4 * i);
+        z |= (((__umul24(f, 0x00204081u) >> 21) & 7u) | ((f >> 21) & 8u)) << (4 * i);
     }
     z &= vm;
 
@@ -207,14 +208,21 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
     }
     // bytes past the end of the block do not move the state (vm clears them from every mask below)
     u32 f = ex3[0] | (ex3[1] << 2) | (ex3[2] << 4);
+    u32 fex;
+    if (__all(fn_const(f))) {                   // the usual wave: every lane's bytes settle the state whatever it was,
+        fex = (u32)__shfl_up((int)f, 1, 64);    // so the map of all bytes before a lane is its neighbour's (constant) map
+        if (lane == 0) fex = FN_IDENT;
+        if (lane == 63) sh.wfn[wv] = f;
+    } else {
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const u32 y = (u32)__shfl_up((int)f, d, 64);
-        if (lane >= d) f = fn_compose(y, f);
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 y = (u32)__shfl_up((int)f, d, 64);
+            if (lane >= d) f = fn_compose(y, f);
+        }
+        if (lane == 63) sh.wfn[wv] = f;
+        fex = (u32)__shfl_up((int)f, 1, 64);
+        if (lane == 0) fex = FN_IDENT;
     }
-    if (lane == 63) sh.wfn[wv] = f;
-    u32 fex = (u32)__shfl_up((int)f, 1, 64);
-    if (lane == 0) fex = FN_IDENT;
     __syncthreads();
     u32 wcar = FN_IDENT, ftile = FN_IDENT;
 #pragma unroll
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
 #pragma unroll
     for (int i = 0; i < 8; ++i) len = __builtin_amdgcn_sad_u8(lenw[i], 0u, len);
 
-    // ---- output offsets --------------------------------------------------------------------------------------------
+    // ---- output offsets: wave 0 publishes the tile's total and looks back while the other waves build the image ------
     const u32 ilen = wave_incl_scan_add<u32>(len);
     if (lane == 63) sh.wlen[wv] = ilen;
     __syncthreads();
@@ -293,38 +301,30 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
             sh.O = O;
         }
     }
-    __syncthreads();
 
-    const u64 O = sh.O, Oend = O + ltot;
-    const u64 limit = blk.out_cap < (u64)SHAFA_RLE_DECODE_MAX ? blk.out_cap : (u64)SHAFA_RLE_DECODE_MAX;
-    if (Oend > (u64)SHAFA_RLE_DECODE_MAX) { if (tid == 0) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE); }
-    else if (Oend > blk.out_cap) { if (tid == 0) set_error(blk.err, SHAFA_LACK_OF_MEMORY); }
-    if (k == (int)blk.n_tiles - 1 && tid == 0) *blk.out_n = Oend;
-    if (!ltot || O >= limit) return;
-
-    // ---- build the output in the LDS image, store it in aligned 16-byte pieces ------------------------------------
+    // ---- the output, in rounds of what the image holds: image byte i = output byte O + done + i ----------------------
     u8 *smem = (u8 *)&sh;
-    const u32 img_off = (u32)offsetof(RldShared, img), in_off = (u32)offsetof(RldShared, in) + (u32)tid * RLD_BPL;
-    const u32 capw = RLD_IMG - 16;
-    for (u32 done = 0; done < ltot;) {
-        u8 *gout = blk.out + O + done;
-        const u32 mis = (u32)((uintptr_t)gout & 15u);
+    const u32 img_off = (u32)offsetof(RldShared, img) + 16u, in_off = (u32)offsetof(RldShared, in) + (u32)tid * RLD_BPL;
+    const u64 limit = blk.out_cap < (u64)SHAFA_RLE_DECODE_MAX ? blk.out_cap : (u64)SHAFA_RLE_DECODE_MAX;
+    u64 O = 0;
+    for (u32 done = 0;;) {
         u32 nxt = ltot;
-        if (mis + (ltot - done) > capw) {               // (uniform) more than the image holds: consecutive lanes that fit
+        if (ltot - done > (u32)RLD_IMG) {               // (uniform) more than the image holds: consecutive lanes that fit
             if (tid == 0) sh.next = ltot;
             __syncthreads();
-            if (len && lbase >= done && mis + (lbase - done) + len > capw) atomicMin(&sh.next, lbase);
+            if (len && lbase >= done && (lbase - done) + len > (u32)RLD_IMG) atomicMin(&sh.next, lbase);
             __syncthreads();
             nxt = sh.next;
             __syncthreads();
         }
         if (len && lbase >= done && lbase + len <= nxt) {
-            const u32 p0 = img_off + mis + (lbase - done);
-            {   // literals: running position, one byte write each
+            const u32 p0 = img_off + (lbase - done);
+            {   // literals: running position, one byte write each; the other bytes go to a dump word (no branches)
                 u32 p = p0;
+                const u32 dump = (u32)offsetof(RldShared, dump) + 4u * (u32)tid;
 #pragma unroll
                 for (int j = 0; j < RLD_BPL; ++j) {
-                    if ((Lm >> j) & 1u) smem[p] = (u8)(w[j >> 2] >> (8 * (j & 3)));
+                    smem[(Lm >> j) & 1u ? p : dump] = (u8)(w[j >> 2] >> (8 * (j & 3)));
                     p += (lenw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
                 }
             }
@@ -336,27 +336,40 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
                 g += c;
             }
         }
-        __syncthreads();
-        const u32 end = mis + (nxt - done);             // image bytes [mis, end) are this round's output
-        const u64 gbase = O + done;                     // index of image byte `mis` in the block's output
-        for (u32 u = tid; 16 * u < end; u += RLD_THREADS) {
-            uint4 *ip = (uint4 *)(sh.img + 16 * u);
-            const uint4 v = *ip;
-            *ip = make_uint4(0, 0, 0, 0);
+        __syncthreads();                                // the image is complete (and, the first time, O has arrived)
+        if (done == 0) {
+            O = sh.O;
+            const u64 Oend = O + ltot;
+            if (Oend > (u64)SHAFA_RLE_DECODE_MAX) { if (tid == 0) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE); }
+            else if (Oend > blk.out_cap) { if (tid == 0) set_error(blk.err, SHAFA_LACK_OF_MEMORY); }
+            if (k == (int)blk.n_tiles - 1 && tid == 0) *blk.out_n = Oend;
+            if (!ltot || O >= limit) return;
+        }
+        // aligned 16-byte pieces of the output; a piece's bytes sit at image offset 16 u - mis (any alignment)
+        u8 *gout = blk.out + O + done;
+        const u32 mis = (u32)((uintptr_t)gout & 15u), nbytes = nxt - done;
+        const u64 gidx = O + done;                      // index of image byte 0 in the block's output
+        for (u32 u = tid; 16 * u < mis + nbytes; u += RLD_THREADS) {
+            const u32 s0 = img_off + 16 * u - mis, sb = s0 & ~3u, sf = s0 & 3u;
+            const u32 d0 = *(const u32 *)__builtin_assume_aligned(smem + sb, 4), d1 = *(const u32 *)__builtin_assume_aligned(smem + sb + 4, 4),
+                      d2 = *(const u32 *)__builtin_assume_aligned(smem + sb + 8, 4), d3 = *(const u32 *)__builtin_assume_aligned(smem + sb + 12, 4),
+                      d4 = *(const u32 *)__builtin_assume_aligned(smem + sb + 16, 4);
+            const u32 wds[4] = {__builtin_amdgcn_alignbyte(d1, d0, sf), __builtin_amdgcn_alignbyte(d2, d1, sf),
+                                __builtin_amdgcn_alignbyte(d3, d2, sf), __builtin_amdgcn_alignbyte(d4, d3, sf)};
             u8 *ga = gout - mis + 16 * u;
-            const u64 i0 = gbase + 16 * u - mis;        // index of the piece's first byte (wraps below 0 only where masked)
-            if (16 * u >= mis && 16 * u + 16 <= end && i0 + 16 <= limit) {
-                *(uint4 *)ga = v;
+            const u32 lo = 16 * u;                      // the piece is image bytes [lo - mis, lo - mis + 16)
+            if (lo >= mis && lo + 16 <= mis + nbytes && gidx + (lo - mis) + 16 <= limit) {
+                gstore_nt<uint4>(ga, make_uint4(wds[0], wds[1], wds[2], wds[3]));
             } else {
-                const u32 wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (u32 q = 0; q < 16; ++q)
-                    if (16 * u + q >= mis && 16 * u + q < end && gbase + (16 * u + q - mis) < limit)
+                    if (lo + q >= mis && lo + q < mis + nbytes && gidx + (lo + q - mis) < limit)
                         ga[q] = (u8)(wds[q >> 2] >> (8 * (q & 3)));
             }
         }
         done = nxt;
-        if (done < ltot) __syncthreads();
+        if (done >= ltot) break;
+        __syncthreads();                                // the image is read out before the next round writes it
     }
 }
 
