@@ -43,6 +43,17 @@ __device__ __forceinline__ u64 desc_load(const u64 *p)
 // ---------------------------------------------------------------------------------------------
 // wave / workgroup primitives (wave = 64 lanes)
 // ---------------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS only.  __syncthreads() is also a workgroup-scope fence for GLOBAL memory: the
+// compiler puts s_waitcnt vmcnt(0) in front of it, so every wave first drains its loads and stores — exactly the
+// prefetches and streaming stores that are meant to stay in flight across the barrier.  Use this one where the waves
+// only hand each other LDS contents (global data published to other workgroups goes through the descriptor atomics).
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 
@@ -221,7 +232,11 @@ __device__ __forceinline__ u64 lookback_sum(const u64 *desc, int k, int *err, bo
             if (have_first) d = first;
             else d = (idx >= 0) ? desc_load(desc + idx) : (DESC_PREFIX << 62);
             have_first = false;
-            if (__all((d >> 62) != DESC_EMPTY)) break;
+            {   // entries behind the nearest inclusive prefix are not needed: do not wait for them
+                const u64 pm = __ballot((d >> 62) == DESC_PREFIX), em = __ballot((d >> 62) == DESC_EMPTY);
+                const u64 need = pm ? ((pm & (0 - pm)) - 1) : ~0ull;
+                if (!(em & need)) break;
+            }
             if (++spins > SPIN_LIMIT) {          // lost predecessor: flag instead of hanging
                 if (lane == 0) set_error(err, SHAFA_DEVICE_ERROR);
                 if ((d >> 62) == DESC_EMPTY) d = (DESC_PREFIX << 62);
@@ -244,7 +259,8 @@ __device__ __forceinline__ u64 lookback_sum(const u64 *desc, int k, int *err, bo
 
 // Same look-back for aggregates below 2^32 per 64-tile window (tile bit totals), without the LDS-routed shuffles of
 // wave_reduce_add: the window's aggregates are summed with a DPP scan of their low dwords, the one inclusive prefix that
-// ends the walk is read with v_readlane.  `first` = descriptors of tiles k-1-lane, loaded by the caller well ahead.
+// ends the walk is read with v_readlane.  `first` = descriptors of tiles max(k-1-lane, 0), loaded by the caller well ahead
+// (unconditionally: a select on a freshly loaded register would be a wait for the load).
 __device__ __forceinline__ u64 lookback_sum_dpp(const u64 *desc, int k, int *err, u64 first)
 {
     const int lane = lane_id();
@@ -256,7 +272,7 @@ __device__ __forceinline__ u64 lookback_sum_dpp(const u64 *desc, int k, int *err
         u64 d = 0;
         u32 spins = 0;
         for (;;) {
-            if (have_first) d = first;
+            if (have_first) d = (idx >= 0) ? first : (DESC_PREFIX << 62);   // the caller loaded desc[max(idx, 0)]: no select there
             else d = (idx >= 0) ? desc_load(desc + idx) : (DESC_PREFIX << 62);
             have_first = false;
             const u64 pm = __ballot((d >> 62) == DESC_PREFIX);

@@ -84,7 +84,12 @@ __device__ __forceinline__ u32 lookback_state(const u64 *desc, int k, int *err)
         u32 spins = 0;
         for (;;) {
             d = (idx >= 0) ? desc_load(desc + idx) : (DESC_PREFIX << 62);
-            if (__all((d >> 62) != DESC_EMPTY)) break;
+            {   // entries behind the nearest tile that settles the state are not needed: do not wait for them
+                const bool empty = (d >> 62) == DESC_EMPTY;
+                const u64 sm = __ballot(!empty && ((d >> 62) == DESC_PREFIX || fn_const((u32)d & 63u))), em = __ballot(empty);
+                const u64 need = sm ? ((sm & (0 - sm)) - 1) : ~0ull;
+                if (!(em & need)) break;
+            }
             if (++spins > SPIN_LIMIT) {
                 if (lane == 0) set_error(err, SHAFA_DEVICE_ERROR);
                 if ((d >> 62) == DESC_EMPTY) d = (DESC_PREFIX << 62);

@@ -1543,7 +1543,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
         const size_t gt = (size_t)blk.tile_base + tile;
         const u64 toff = tile_off[gt];
         if (toff >= blk.n_sym) break;                   // the rest is padding / past the end
-        __syncthreads();                                // the previous tile's rows and image are done with
+        lds_barrier();                                // the previous tile's rows and image are done with
         put16(tid, pf0);
         put16(tid + DEC_THREADS, pf1);
         if (tid == 0) put16(DTILE / 16, pf2);
@@ -1551,7 +1551,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
         if (it + 1 < tpw && tile + 1 < blk.n_tiles) prefetch(tile + 1);
         const u32 incl = wave_incl_scan_add<u32>(cnt);
         if (lane == 63) wsum[wv] = incl;
-        __syncthreads();
+        lds_barrier();
         u32 pre = incl - cnt, total = 0;
         for (u32 w = 0; w < 4; ++w) { if (w < wv) pre += wsum[w]; total += wsum[w]; }
         const u64 room = blk.n_sym - toff;              // symbols of this tile that exist in the block
@@ -1565,11 +1565,11 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
             u32 nxt = tot_c;
             if (mis + (tot_c - done) > capw) {          // (uniform) more than the image holds: consecutive lanes that fit
                 if (tid == 0) *next = tot_c;
-                __syncthreads();
+                lds_barrier();
                 if (want && pre >= done && mis + (pre - done) + want > capw) atomicMin(next, pre);
-                __syncthreads();
+                lds_barrier();
                 nxt = *next;
-                __syncthreads();
+                lds_barrier();
             }
             if (want && pre >= done && pre + want <= nxt) {
                 const u32 x = mis + (pre - done);
@@ -1605,7 +1605,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                 while (want) step(true);
                 if (nb8) __hip_atomic_fetch_or((u32 *)__builtin_assume_aligned(smem + wp, 4), acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            __syncthreads();
+            lds_barrier();
             const u32 end = mis + (nxt - done);         // image bytes [mis, end) are this round's symbols
             for (u32 u = tid; 16 * u < end; u += DEC_THREADS) {
                 uint4 *ip = (uint4 *)(smem + img_off + 16 * u);
@@ -1622,7 +1622,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                 }
             }
             done = nxt;
-            if (done < tot_c) __syncthreads();          // the image is clean again before the next round's ORs
+            if (done < tot_c) lds_barrier();          // the image is clean again before the next round's ORs
         }
     }
     if (bad) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);

@@ -291,14 +291,17 @@ __global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *
         TileIn cin, nin, nin2;                         // inputs are requested two tiles ahead
         load_tile(in, cur, tid, cin);
         if (nxt < nfull) load_tile(in, nxt, tid, nin);
-        // wave 0: descriptor windows and the 32 symbols in front of the tiles in the pipeline (q = one iteration old, p = two)
-        u64 first_q = 0, first_p = 0;
-        u32 c_pv = 0, q_pv = 0, p_pv = 0;
+        // wave 0: the descriptor window and the 32 symbols in front of the tile computed one iteration ago (q) are requested
+        // after barrier A and used at the top of the next iteration, when that tile is p: one variable each, never copied
+        // (a copy of a loaded register is a wait for the load)
+        u64 first_w = 0;
+        u32 pv_w = 0;
 
         u32 q_tile = E4_NONE, q_T = 0;                 // computed in the previous iteration: aggregate out, window requested now
         u32 p_tile = E4_NONE, p_T = 0;                 // computed two iterations ago: resolved and stored now
         u32 dirty[3] = {win_stride - E4_GUARD, win_stride - E4_GUARD, win_stride - E4_GUARD};   // dwords that may be non-zero
         u32 buf = 0;                                   // window buffer of `cur`; q: buf - 1, p: buf - 2 (mod 3)
+        bool rotate_in = false;
 
         for (;;) {
             const bool cur_ok = cur < nfull;
@@ -320,29 +323,35 @@ __global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *
                 if (have_p) {                          // prefix and lead bits of the tile that is stored in this iteration
                     u64 B = 0;
                     if (p_tile > 0) {
-                        B = lookback_sum_dpp(bdesc, (int)p_tile, bp->err, first_p);
+                        B = lookback_sum_dpp(bdesc, (int)p_tile, bp->err, first_w);
                         E4_T(0);
                         if (lane == 0) {
                             desc_store(bdesc + p_tile, DESC_PREFIX, B + p_T);
                             if (!ragged && p_tile == nfull - 1) gstore<u64>(bp->out_n, (B + p_T + 7) >> 3);
                         }
                         const u32 r = (u32)B & 31u;
-                        if (r) lead_bits(sh.lut, pwin, p_pv, r, lane);
+                        if (r) lead_bits(sh.lut, pwin, pv_w, r, lane);
                     }
                     if (lane == 0) sh.prefix = B;
                 }
-                // unconditional (a few tickets past the block's end are harmless): the returned value is not touched
-                // before the next iteration, so the atomic's round trip is never waited for
-                if (lane == 0) req = atomicAdd(tick, 1u);
-                if (cur_ok && cur > 0 && lane < 32) c_pv = gload_off<u8>(in + (u64)cur * E4_TILE - 32, 31u - (u32)lane);
             }
             E4_T(7);
-            if (cur_ok && nn < nfull) load_tile(in, nn, tid, nin2);
 
             // ---- this tile: zero its window, look up, group, scan ------------------------------------------------
             if (cur_ok) {
                 for (u32 i = (u32)tid; i < ((dirty[buf] + 3u) >> 2) + 1u; i += E4_THREADS)
                     ((uint4 *)win)[(int)i - 1] = make_uint4(0, 0, 0, 0);              // from dword -4: the lead word is win[-1]
+            }
+            // the input registers move up one place here, not at the end of the iteration: a wave that loads and stores
+            // has to drain its whole memory queue before it may touch a loaded register (loads and stores complete out of
+            // order with respect to each other), and here the window stores of the previous iteration are oldest
+            if (rotate_in) { cin = nin; nin = nin2; }
+            rotate_in = true;
+            if (cur_ok && nn < nfull) load_tile(in, nn, tid, nin2);
+            // the next ticket: unconditional (a few tickets past the block's end are harmless), and issued only now, after
+            // the wave's one drain of the iteration: the returned value is not touched before the next iteration's top
+            if (tid == 0) req = atomicAdd(tick, 1u);
+            if (cur_ok) {
                 u32 absent = 0;
                 tile_octs<false, NW, L16>(sh.lut, cin, 0u, tid, c_oct, incl, absent);
                 if (absent) set_error(bp->err, SHAFA_FILE_UNRECOGNIZABLE);   // data symbol without a code (output undefined, in bounds)
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *
                 }
             }
             E4_T(1);
-            __syncthreads();                                                           // A
+            lds_barrier();                                                             // A
             E4_T(3);
             const u32 n3 = sh.tick;
             u32 c_T = 0;
@@ -374,25 +383,24 @@ __global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *
             }
             E4_T(4);
             if (wv == 0) {
-                if (have_q && q_tile > 0) {            // the descriptor window of the tile computed one iteration ago
+                if (have_q && q_tile > 0) {            // descriptor window and leading symbols of the tile computed one iteration ago
                     const int idx = (int)q_tile - 1 - lane;
-                    first_q = idx >= 0 ? desc_load(bdesc + idx) : (DESC_PREFIX << 62);
+                    first_w = desc_load(bdesc + (idx > 0 ? idx : 0));
+                    if (lane < 32) pv_w = gload_off<u8>(in + (u64)q_tile * E4_TILE - 32, 31u - (u32)lane);
                 }
             } else if (have_p) {                       // waves 1..3 store the resolved tile's window
                 store_window(pwin, bp->out, bp->out_cap, bp->err, sh.prefix, p_T, !ragged && p_tile == nfull - 1, tid - 64,
                              E4_THREADS - 64);
             }
             E4_T(5);
-            __syncthreads();                                                           // B
+            lds_barrier();                                                             // B
             E4_T(6);
 
             // ---- rotate ------------------------------------------------------------------------------------------
-            p_tile = q_tile; p_T = q_T; p_pv = q_pv; first_p = first_q;
-            q_tile = cur_ok ? cur : E4_NONE; q_T = c_T; q_pv = c_pv;
+            p_tile = q_tile; p_T = q_T;
+            q_tile = cur_ok ? cur : E4_NONE; q_T = c_T;
             buf = buf == 2 ? 0 : buf + 1;
             cur = nxt;
-            cin = nin;
-            nin = nin2;
             nxt = nn;
             nn = n3;
         }

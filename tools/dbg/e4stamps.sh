@@ -1,8 +1,8 @@
 #!/bin/bash
 # diagnostic: rebuild libshafa_hip.so with -DE4_STAMPS on the GPU box, run the bench once, print per-phase cycle shares
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-touch shafa-cd_amd/csrc/sf_encode4.hip
-make -C shafa-cd_amd/csrc FLAGS_EXTRA=-DE4_STAMPS 2>&1 | grep -E "error" 
+# build first, here: touch shafa-cd_amd/csrc/sf_encode4.hip; make -C shafa-cd_amd/csrc FLAGS_EXTRA=-DE4_STAMPS   (then rebuild without the flag)
+
 python3 - <<'PY'
 import ctypes as C, os, sys, subprocess, json
 import numpy as np
