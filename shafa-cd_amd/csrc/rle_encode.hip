@@ -53,6 +53,7 @@ struct RleShared {
     u32 H;          // bytes after the tile equal to its last byte (<= 255)
     u16 E[260];     // fast path: equality masks of the threads, [0] = the 16 bytes before the tile, [257] = after
     u16 lastb[258]; // fast path: last byte of every thread, [0] = the byte before the tile (0x100: none)
+    u32 dump[RLE_THREADS];      // fast path: where the byte writes of bytes that emit nothing go
 };
 
 // General tile code: any input (runs of any length, ragged last tile).  Per element closed form.
@@ -235,6 +236,9 @@ __device__ __forceinline__ void rle_tile_general(RleShared &sh, const RleBlk &bl
     }
 }
 
+
+// bit i of nibble q of mask -> 0x01 in byte i
+__device__ __forceinline__ u32 nibf(u32 mask, int q) { return __umul24((mask >> (4 * q)) & 15u, 0x00204081u) & 0x01010101u; }
 
 // 4-bit mask of the bytes of a that equal the bytes of b (exact SWAR zero-byte test of a ^ b)
 __device__ __forceinline__ u32 eqmask4(u32 a, u32 b)
@@ -481,40 +485,51 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_pass(const RleBlk *__restric
         if (!has_above) after = 16u * (u32)(63 - lane) + (wv < 3 ? sh.wf[wv + 1].v : sh.H);
     }
     const u64 G = Gin;
-    const u32 shift = (u32)G & 3;
+    const u32 shift = (u32)((uintptr_t)(blk.out + G) & 15u);   // the staging buffer is aligned like the output address
     u8 *st8 = (u8 *)sh.stage;
-    u32 o = shift + off;
+    const u32 p0 = shift + off;
+    {   // every byte is written somewhere, no branches: a literal at the running position, the symbol of a triple in the
+        // triple's second place, a byte that emits nothing into the lane's dump word
+        u32 p = p0;
+        u8 *dp = (u8 *)&sh.dump[tid];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const u32 xj = (c.w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-        if ((T3 >> j) & 1u) {
-            const u32 hn = H16 >> (j + 1);
-            u32 L;
-            if (j < 15 && hn) L = (u32)__builtin_ctz(hn) + 1;           // next head inside this thread
-            else { L = (16 - j) + after; L = L > 255u ? 255u : L; }
-            st8[o] = 0; st8[o + 1] = (u8)xj; st8[o + 2] = (u8)L;
-            o += 3;
-        } else if ((Lit >> j) & 1u) {
-            st8[o] = (u8)xj;
-            o += 1;
+        for (int q = 0; q < 4; ++q) {
+            const u32 ft = nibf(T3, q), sz = nibf(Lit, q) | ft | (ft << 1);      // per byte: 1 at a literal, 3 at a triple head
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int j = 4 * q + b;
+                u8 *at = (Lit >> j) & 1u ? st8 + p : ((T3 >> j) & 1u ? st8 + p + 1 : dp);
+                *at = (u8)(c.w[q] >> (8 * b));
+                p += (sz >> (8 * b)) & 0xFFu;
+            }
         }
+    }
+    for (u32 t = T3; t; t &= t - 1) {                   // triples: the lane's heads in order
+        const u32 j = (u32)__builtin_ctz(t), below = (1u << j) - 1u;
+        const u32 hn = j < 15 ? H16 >> (j + 1) : 0u;
+        u32 L = hn ? (u32)__builtin_ctz(hn) + 1u : (16u - j) + after;   // to the next head: in this thread / beyond it
+        L = L > 255u ? 255u : L;
+        const u32 at = p0 + (u32)__builtin_popcount(Lit & below) + 3u * (u32)__builtin_popcount(T3 & below);
+        st8[at] = 0;
+        st8[at + 2] = (u8)L;
     }
     __syncthreads();
     const u64 end_b = G + Tt;
     if (end_b > blk.out_cap) {
         if (tid == 0) set_error(blk.err, SHAFA_LACK_OF_MEMORY);
-    } else {
-        const u32 nwords = (shift + Tt + 3) >> 2;
-        const u64 gw0 = G >> 2;
-        for (u32 ww = tid; ww < nwords; ww += RLE_THREADS) {
-            const u32 val = sh.stage[ww];
-            const u64 byte0 = (gw0 + ww) * 4;
-            if (byte0 >= G && byte0 + 4 <= end_b) {
-                ((u32 *)blk.out)[gw0 + ww] = val;
+    } else {                                            // aligned 16-byte pieces, non-temporal
+        u8 *gbase = blk.out + G - shift;
+        const u32 npieces = (shift + Tt + 15) >> 4;
+        for (u32 u = tid; u < npieces; u += RLE_THREADS) {
+            const uint4 v = ((const uint4 *)sh.stage)[u];
+            const u32 lo = 16 * u;
+            if (lo >= shift && lo + 16 <= shift + Tt) {
+                gstore_nt<uint4>(gbase + lo, v);
             } else {
+                const u32 wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (byte0 + q >= G && byte0 + q < end_b) blk.out[byte0 + q] = (u8)(val >> (8 * q));
+                for (u32 q = 0; q < 16; ++q)
+                    if (lo + q >= shift && lo + q < shift + Tt) gbase[lo + q] = (u8)(wds[q >> 2] >> (8 * (q & 3)));
             }
         }
     }
