@@ -160,7 +160,7 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
     if (tid == 0) sh.tile = atomicAdd(tickets + blk.ticket, 1u);
     sh.fsm[tid] = g_rld_fsm.v[tid];
     if (tid < 2) *(uint4 *)(sh.in + RLD_TILE + 16 * tid) = make_uint4(0, 0, 0, 0);
-    __syncthreads();
+    lds_barrier();
     const int k = (int)sh.tile;
     const u64 n = blk.n;
     const u64 pos = (u64)k * RLD_TILE + (u64)tid * RLD_BPL;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
         fex = (u32)__shfl_up((int)f, 1, 64);
         if (lane == 0) fex = FN_IDENT;
     }
-    __syncthreads();
+    lds_barrier();
     u32 wcar = FN_IDENT, ftile = FN_IDENT;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
             sh.state_in = sin;
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- literal / escape masks, per-byte output lengths ------------------------------------------------------------
     const u32 s_in = fn_apply(fpre, sh.state_in);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
     // ---- output offsets: wave 0 publishes the tile's total and looks back while the other waves build the image ------
     const u32 ilen = wave_incl_scan_add<u32>(len);
     if (lane == 63) sh.wlen[wv] = ilen;
-    __syncthreads();
+    lds_barrier();
     u32 lbase = 0, ltot = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -316,11 +316,11 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
         u32 nxt = ltot;
         if (ltot - done > (u32)RLD_IMG) {               // (uniform) more than the image holds: consecutive lanes that fit
             if (tid == 0) sh.next = ltot;
-            __syncthreads();
+            lds_barrier();
             if (len && lbase >= done && (lbase - done) + len > (u32)RLD_IMG) atomicMin(&sh.next, lbase);
-            __syncthreads();
+            lds_barrier();
             nxt = sh.next;
-            __syncthreads();
+            lds_barrier();
         }
         if (len && lbase >= done && lbase + len <= nxt) {
             const u32 p0 = img_off + (lbase - done);
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
                 g += c;
             }
         }
-        __syncthreads();                                // the image is complete (and, the first time, O has arrived)
+        lds_barrier();                                // the image is complete (and, the first time, O has arrived)
         if (done == 0) {
             O = sh.O;
             const u64 Oend = O + ltot;
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
         }
         done = nxt;
         if (done >= ltot) break;
-        __syncthreads();                                // the image is read out before the next round writes it
+        lds_barrier();                                // the image is read out before the next round writes it
     }
 }
 

@@ -1,0 +1,73 @@
+"""Randomised round trips through the whole block codec on the GPU (Module F -> C -> D of the reference: f.c:29-55,
+c.c:52-237, d.c:116-197 + 466-551): distributions from almost uniform to steep, runs, sizes from a few bytes to several
+tiles, launches that mix them.  RLE encode -> histogram -> codes (host Module T) -> SF encode -> SF decode -> RLE decode
+must return the input; every stage is also compared with the oracle on the same bytes.  The speculative decoder runs in
+its three modes."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import first_diff, to_shafa_table
+
+pytestmark = pytest.mark.gpu
+
+
+def make_block(rng, n):
+    kind = rng.integers(0, 6)
+    if kind == 0:                                   # Zipf with a random exponent over a random alphabet
+        s, m = rng.uniform(0.3, 2.5), int(rng.integers(2, 257))
+        p = np.arange(1, m + 1, dtype=np.float64) ** (-s)
+        x = rng.choice(m, size=n, p=p / p.sum()).astype(np.uint8)
+        return rng.permutation(256).astype(np.uint8)[x]
+    if kind == 1:                                   # runs of geometric length
+        out = np.empty(n, dtype=np.uint8)
+        pos, mean = 0, rng.choice([1.3, 3.0, 40.0, 700.0])
+        while pos < n:
+            L = int(rng.geometric(1.0 / mean))
+            out[pos:pos + L] = rng.integers(0, 256 if rng.random() < 0.7 else 4)
+            pos += L
+        return out
+    if kind == 2:
+        return rng.integers(0, 256, n, dtype=np.uint8)
+    if kind == 3:                                   # zeros with sparse other bytes
+        x = np.zeros(n, dtype=np.uint8)
+        idx = rng.integers(0, n, max(1, n // int(rng.integers(3, 300))))
+        x[idx] = rng.integers(1, 256, idx.size)
+        return x
+    if kind == 4:                                   # two alternating stretches of different statistics
+        a, b = make_block(rng, n // 2 + 1), make_block(rng, n // 2 + 1)
+        return np.concatenate([a, b])[:n]
+    return np.full(n, rng.integers(0, 256), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_round_trips(oracle, shafa, seed):
+    rng = np.random.default_rng(1000 + seed)
+    sizes = [int(rng.choice([1, 7, 300, 4096, 8191, 8193, 40000, 262144 + 5, 1500000])) for _ in range(7)]
+    blocks = [make_block(rng, n) for n in sizes]
+    bad = []
+    for mode in (1, 2, 0):
+        shafa.set_option("sf_decode_speculate", mode)
+        for i, b in enumerate(blocks):
+            rle, freq = shafa.rle_encode(b, want_freq=True)
+            want_rle = oracle.rle_encode(b)
+            if rle.tobytes() != want_rle.tobytes():
+                bad.append(f"seed {seed} block {i} n={b.size}: rle_encode {first_diff(rle, want_rle)}")
+                continue
+            otab = oracle.sf_build(oracle.hist256(want_rle))
+            if otab.lens().max() == 0:               # one symbol: no code, the reference rejects it
+                continue
+            tab = to_shafa_table(shafa, otab)
+            enc = shafa.sf_encode(rle, tab)
+            rc, want_enc = oracle.sf_encode(want_rle, otab)
+            if rc != 0 or enc.tobytes() != want_enc.tobytes():
+                bad.append(f"seed {seed} block {i} n={b.size}: sf_encode {first_diff(enc, want_enc)}")
+                continue
+            dec = shafa.sf_decode(enc, tab, rle.size)
+            if dec.tobytes() != rle.tobytes():
+                bad.append(f"seed {seed} mode {mode} block {i} n={b.size} lmax={otab.lens().max()}: sf_decode {first_diff(dec, rle)}")
+                continue
+            back = shafa.rle_decode(dec)
+            if back.tobytes() != b.tobytes():
+                bad.append(f"seed {seed} block {i} n={b.size}: rle_decode {first_diff(back, b)}")
+    shafa.set_option("sf_decode_speculate", 1)
+    assert not bad, "\n".join(bad[:12])
