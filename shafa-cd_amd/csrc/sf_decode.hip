@@ -1228,24 +1228,16 @@ __device__ __forceinline__ void spec_strip(const u8 *smem, u32 tab_off, u32 K1, 
 }
 
 // dynamic LDS: stream frame | cnt3 (2 << K1max bytes) | exits[256] | wsum[4]
+constexpr int SPEC_FIX_REGIONS = 32;               // regions a workgroup of a repair launch looks at (almost none needs work)
+
 template <bool FIX>
-__global__ __launch_bounds__(DEC_THREADS) void sfd_spec(const DecBlk *__restrict__ blks, u8 *__restrict__ chunk_entry,
-                                                        u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt,
-                                                        u8 *__restrict__ tile_guess, u8 *__restrict__ tile_exit,
-                                                        const u8 *__restrict__ tile_fix, u32 tab_bytes)
+__device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u32 tile0, u8 *__restrict__ chunk_entry,
+                                            u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt,
+                                            u8 *__restrict__ tile_guess, u8 *__restrict__ tile_exit,
+                                            const u8 *__restrict__ tile_fix, u32 tab_bytes)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const DecBlk blk = blks[blockIdx.y];
-    const u32 tile0 = blockIdx.x * SPEC_TILES;          // first tile of this workgroup's region
-    if (tile0 >= blk.n_tiles) return;
-    if (!blk.run_dp || __hip_atomic_load(blk.run_dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // exact path
     const size_t gt0 = (size_t)blk.tile_base + tile0;
     const u32 ntl = blk.n_tiles - tile0 < (u32)SPEC_TILES ? blk.n_tiles - tile0 : (u32)SPEC_TILES;   // tiles of the region
-    if (FIX) {
-        bool any = false;
-        for (u32 t = 0; t < ntl; ++t) any |= tile_fix[gt0 + t] != 0;
-        if (!any) return;
-    }
     u32 *data = (u32 *)smem;
     const u32 tab_off = SPEC_LDS_DATA;
     u8 *ex = smem + SPEC_LDS_DATA + tab_bytes;
@@ -1354,6 +1346,37 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_spec(const DecBlk *__restrict
             tile_guess[gt0 + my_tile] = (u8)ent[0];
         }
         if (in_tile == LPT - 1) tile_exit[gt0 + my_tile] = (u8)exit_;
+    }
+}
+
+template <bool FIX>
+__global__ __launch_bounds__(DEC_THREADS) void sfd_spec(const DecBlk *__restrict__ blks, u8 *__restrict__ chunk_entry,
+                                                        u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt,
+                                                        u8 *__restrict__ tile_guess, u8 *__restrict__ tile_exit,
+                                                        const u8 *__restrict__ tile_fix, u32 tab_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const DecBlk blk = blks[blockIdx.y];
+    if (!blk.run_dp || __hip_atomic_load(blk.run_dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // exact path
+    if (!FIX) {
+        const u32 tile0 = blockIdx.x * SPEC_TILES;      // first tile of this workgroup's region
+        if (tile0 < blk.n_tiles) spec_region<false>(smem, blk, tile0, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tile_fix, tab_bytes);
+        return;
+    }
+    // repair launch: a workgroup looks at the flags of SPEC_FIX_REGIONS regions and redoes the few that are marked
+    const u32 t_lo = blockIdx.x * (SPEC_FIX_REGIONS * SPEC_TILES);
+    if (t_lo >= blk.n_tiles) return;
+    const u32 t = t_lo + threadIdx.x;
+    const bool mine = threadIdx.x < SPEC_FIX_REGIONS * SPEC_TILES && t < blk.n_tiles && tile_fix[(size_t)blk.tile_base + t] != 0;
+    if (!__syncthreads_or(mine)) return;
+    for (u32 r = 0; r < SPEC_FIX_REGIONS; ++r) {
+        const u32 tile0 = t_lo + r * SPEC_TILES;
+        if (tile0 >= blk.n_tiles) break;
+        bool any = false;
+        for (u32 q = 0; q < SPEC_TILES && tile0 + q < blk.n_tiles; ++q) any |= tile_fix[(size_t)blk.tile_base + tile0 + q] != 0;
+        if (!any) continue;                             // uniform
+        __syncthreads();                                // the region before is done with the LDS
+        spec_region<true>(smem, blk, tile0, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tile_fix, tab_bytes);
     }
 }
 
@@ -2135,11 +2158,12 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
             const u32 tabb = 2u << k1_max;
             const size_t lds_spec = (size_t)SPEC_LDS_DATA + tabb + DEC_THREADS + 16;
             const dim3 grid_s((u32)ceil_div_u64(max_tiles, SPEC_TILES), (u32)nblocks);
+            const dim3 grid_sf((u32)ceil_div_u64(max_tiles, SPEC_TILES * SPEC_FIX_REGIONS), (u32)nblocks);
             hipLaunchKernelGGL(sfd_spec<false>, grid_s, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
                                (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb);
             for (int round = 0; round < 2; ++round) {
                 hipLaunchKernelGGL(sfd_spec_check<false>, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
-                hipLaunchKernelGGL(sfd_spec<true>, grid_s, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
+                hipLaunchKernelGGL(sfd_spec<true>, grid_sf, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
                                    (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb);
             }
             hipLaunchKernelGGL(sfd_spec_check<true>, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
