@@ -2168,35 +2168,42 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
             }
             hipLaunchKernelGGL(sfd_spec_check<true>, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
         }
+        // when every block of the launch speculates, the DP kernels below are fall-backs that normally return at once:
+        // fat workgroups (32 tiles each) make that a launch of a few thousand workgroups instead of a few hundred thousand
+        bool all_spec = any_spec;
+        for (int b = 0; b < nblocks; ++b) if (ntiles[b] && !spec_blk[b]) all_spec = false;
+        const u32 tpw_dp = all_spec ? 32u : tpw;
+        const dim3 grid_fd((u32)ceil_div_u64(max_tiles, tpw_dp), (u32)nblocks);
+        const dim3 grid_cd((u32)ceil_div_u64(max_tiles, tpw_dp * CSUBS), (u32)nblocks);
         u32 k1_all = 0;                                // common K1 of the running blocks, 0 when they differ
         for (int b = 0; b < nblocks; ++b)
             if (ntiles[b]) k1_all = (k1_all == 0 || k1_all == tabs[b].K1) ? tabs[b].K1 : 0xFFFFFFFFu;
         if (pair_all && k1_all == 12)
-            hipLaunchKernelGGL((sfd_sync16<true, false, 12>), grid_f, dim3(DEC_THREADS), 0, st, dblk,
-                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw);
+            hipLaunchKernelGGL((sfd_sync16<true, false, 12>), grid_fd, dim3(DEC_THREADS), 0, st, dblk,
+                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw_dp);
         else if (pair_all && k1_all == 13)
-            hipLaunchKernelGGL((sfd_sync16<true, false, 13>), grid_f, dim3(DEC_THREADS), 0, st, dblk,
-                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw);
+            hipLaunchKernelGGL((sfd_sync16<true, false, 13>), grid_fd, dim3(DEC_THREADS), 0, st, dblk,
+                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw_dp);
         else if (pair_all)
-            hipLaunchKernelGGL((sfd_sync16<true, false>), grid_f, dim3(DEC_THREADS), 0, st, dblk,
-                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw);
+            hipLaunchKernelGGL((sfd_sync16<true, false>), grid_fd, dim3(DEC_THREADS), 0, st, dblk,
+                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw_dp);
         else if (long_all)
-            hipLaunchKernelGGL((sfd_sync16<false, true>), grid_f, dim3(DEC_THREADS), 0, st, dblk,
-                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw);
+            hipLaunchKernelGGL((sfd_sync16<false, true>), grid_fd, dim3(DEC_THREADS), 0, st, dblk,
+                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw_dp);
         else
-            hipLaunchKernelGGL((sfd_sync16<false, false>), grid_f, dim3(DEC_THREADS), 0, st, dblk,
-                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw);
+            hipLaunchKernelGGL((sfd_sync16<false, false>), grid_fd, dim3(DEC_THREADS), 0, st, dblk,
+                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw_dp);
         hipLaunchKernelGGL(sfd_tiles16, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u64 *)(ws + o_tilefn),
                            ws + o_tent);
         if (fast13) {
             if (multi)
-                hipLaunchKernelGGL((sfd_countfsm<CSUBS>), grid_c, dim3(DEC_THREADS * CSUBS), 0, st, dblk,
+                hipLaunchKernelGGL((sfd_countfsm<CSUBS>), grid_cd, dim3(DEC_THREADS * CSUBS), 0, st, dblk,
                                    (const u64 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
-                                   (u32 *)(ws + o_tcnt), tpw);
+                                   (u32 *)(ws + o_tcnt), tpw_dp);
             else
-                hipLaunchKernelGGL(sfd_count13<false>, grid_f, dim3(DEC_THREADS), 0, st, dblk,
+                hipLaunchKernelGGL(sfd_count13<false>, grid_fd, dim3(DEC_THREADS), 0, st, dblk,
                                    (const u64 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
-                                   (u32 *)(ws + o_tcnt), tpw);
+                                   (u32 *)(ws + o_tcnt), tpw_dp);
         } else {
             hipLaunchKernelGGL(sfd_count<true>, grid_t, dim3(DEC_THREADS), lds_count16, st, dblk, R, l2cap,
                                (const u8 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
