@@ -1488,11 +1488,13 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *
 // The host sizes the image for the launch's average symbols per tile plus a margin (LDS is what limits the waves per
 // CU); a tile with more symbols than it holds goes in several rounds of consecutive lanes.
 // ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) u32 lds_u32;
 constexpr int WS_ROW = CH_BYTES / 4 + 1;            // LDS words per chunk row
 constexpr int WS_ROWS_BYTES = 16 + DEC_THREADS * WS_ROW * 4;     // 16 in front: the window at a row's bit 0 reads the word before it
 constexpr int WS_MISC = DEC_THREADS * 4 + 32;
 
-template <int LONG>
+// ESC: some code of the launch may be longer than its block's sym3 window (then a look-up can return no symbol)
+template <int LONG, bool ESC>
 __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restrict__ blks, const u8 *__restrict__ chunk_entry,
                                                           const u16 *__restrict__ chunk_cnt, const u64 *__restrict__ tile_off,
                                                           u32 tpw, u32 tab_bytes, u32 cap)
@@ -1521,8 +1523,9 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
     }
     for (u32 i = tid; i < cap / 16; i += DEC_THREADS) *(uint4 *)(smem + img_off + 16 * i) = make_uint4(0, 0, 0, 0);
     bool bad = false;
-    const u32 qb = 8u * (16u + 4u * WS_ROW * tid) - 1u;
-    const u32 dump_a = img_off + cap + 4 * tid;
+    const u32 sbase = (u32)(size_t)smem;               // LDS offset of the dynamic segment (low half of its flat address)
+    const u32 qb_abs = 8u * (sbase + 16u + 4u * WS_ROW * tid) - 1u;
+    const u32 tab_abs = sbase + tab_off, dump_abs = sbase + img_off + cap + 4 * tid;
     // 16 stream bytes at `off` (zeros past the end)
     auto fetch16 = [&](const u64 off) -> uint4 {
         if (off + 16 <= blk.in_n) return gload<uint4>(blk.in + off);
@@ -1596,13 +1599,15 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
             }
             if (want && pre >= done && pre + want <= nxt) {
                 const u32 x = mis + (pre - done);
-                u32 wp = img_off + (x & ~3u), nb8 = (x & 3u) * 8, acc = 0;
+                // LDS addresses are absolute from here on (the dynamic segment's base folded into the constants): an
+                // address that is "base + variable" costs an add per look-up that the ds instructions cannot absorb
+                u32 wp = sbase + img_off + (x & ~3u), nb8 = (x & 3u) * 8, acc = 0;
                 auto step = [&](const bool tail) {
-                    const u32 q = qb + (u32)r;
-                    const u32 a = (q >> 3) & ~3u;
-                    const u32 win = __builtin_amdgcn_alignbit(*(const u32 *)(smem + a), *(const u32 *)(smem + a + 4), ~q);
-                    u32 e = *(const u32 *)(smem + tab_off + ((win >> sh3) << 2));
-                    if (__builtin_expect((e >> 30) == 0, 0)) {      // first code longer than the window: one code
+                    const u32 q = qb_abs + (u32)r;
+                    const lds_u32 *pa = (const lds_u32 *)(size_t)((q >> 3) & ~3u);
+                    const u32 win = __builtin_amdgcn_alignbit(pa[0], pa[1], ~q);
+                    u32 e = *(const lds_u32 *)(size_t)(tab_abs + ((win >> sh3) << 2));
+                    if (ESC && __builtin_expect((e >> 30) == 0, 0)) {      // first code longer than the window: one code
                         u32 e1 = LONG == 1 ? long_code(lt, win) : LONG == 2 ? long_code32(lt, win)
                                            : (u32)gload<u16>(blk.lut13 + (win >> sh));
                         if (e1 == 0) { bad = true; e1 = 1u << 8; }  // not a code (complete tables never get here)
@@ -1617,7 +1622,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                     const u32 lo = acc | (u32)t;
                     const u32 nbn = nb8 + 8 * n;
                     const bool ov = nbn >= 32;
-                    __hip_atomic_fetch_or((u32 *)__builtin_assume_aligned(smem + (ov ? wp : dump_a), 4), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_or((lds_u32 *)(size_t)(ov ? wp : dump_abs), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     acc = ov ? (u32)(t >> 32) : lo;
                     wp += ov ? 4u : 0u;
                     nb8 = nbn & 31u;
@@ -1626,7 +1631,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                 };
                 while (want >= 3) step(false);
                 while (want) step(true);
-                if (nb8) __hip_atomic_fetch_or((u32 *)__builtin_assume_aligned(smem + wp, 4), acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (nb8) __hip_atomic_fetch_or((lds_u32 *)(size_t)wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             lds_barrier();
             const u32 end = mis + (nxt - done);         // image bytes [mis, end) are this round's symbols
@@ -2247,15 +2252,19 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     ws_cap &= ~15u;
     const size_t lds_ws = (size_t)WS_ROWS_BYTES + ws_tab + ws_cap + WS_MISC;
     if (mid32) {
-        hipLaunchKernelGGL((sfd_wstage<2>), grid_f, dim3(DEC_THREADS), lds_ws + LONG32_BYTES, st, dblk,
+        hipLaunchKernelGGL((sfd_wstage<2, true>), grid_f, dim3(DEC_THREADS), lds_ws + LONG32_BYTES, st, dblk,
                            (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, ws_tab, ws_cap);
     } else if (fast13) {
         if (multi && long_all)
-            hipLaunchKernelGGL((sfd_wstage<1>), grid_f, dim3(DEC_THREADS), lds_ws + LONG_BYTES, st, dblk,
+            hipLaunchKernelGGL((sfd_wstage<1, true>), grid_f, dim3(DEC_THREADS), lds_ws + LONG_BYTES, st, dblk,
                                (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, ws_tab, ws_cap);
         else if (multi)
-            hipLaunchKernelGGL((sfd_wstage<0>), grid_f, dim3(DEC_THREADS), lds_ws, st, dblk,
-                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, ws_tab, ws_cap);
+            if (lmax_all > (u32)SYM3_MAXK)
+                hipLaunchKernelGGL((sfd_wstage<0, true>), grid_f, dim3(DEC_THREADS), lds_ws, st, dblk,
+                                   (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, ws_tab, ws_cap);
+            else
+                hipLaunchKernelGGL((sfd_wstage<0, false>), grid_f, dim3(DEC_THREADS), lds_ws, st, dblk,
+                                   (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, ws_tab, ws_cap);
         else
             hipLaunchKernelGGL((sfd_write13<WSUBS>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
                                (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw);
