@@ -1168,6 +1168,8 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) __attribute__((amdgpu_waves_per
 // rounds sets *run_dp and goes through the exact kernels, which skip the blocks that verified; which blocks try at all
 // is decided per table on the host (spec_worthwhile()).  Outputs are those of sfd_countfsm.
 // ================================================================================================
+typedef __attribute__((address_space(3))) u32 lds_u32;
+typedef __attribute__((address_space(3))) u16 lds_u16;
 constexpr int SPEC_STRIP = 2;                      // chunks per lane: the 256-bit run-up is paid once per strip
                                                    // (4: a fifth fewer steps, but twice the LDS per walk in flight: slower)
 constexpr int SPEC_TILES = SPEC_STRIP;             // a workgroup covers SPEC_STRIP tiles
@@ -1184,25 +1186,26 @@ constexpr int SPEC_LDS_DATA = (SPEC_STRIPS * SPEC_ROW + 3) / 4 * 16;
 // buffer to refill, two look-ups per step.  qb = 8 * (byte address of the row) - 1.
 // LAST: the stream ends at bit `limit` of the strip (may be negative); a code that does not end inside it is not a symbol.
 template <bool LAST>
-__device__ __forceinline__ void spec_walk(const u8 *smem, u32 tab_off, u32 K1, u32 qb, int &r, int b, int limit, u32 &cnt)
+__device__ __forceinline__ void spec_walk(u32 tab_abs, u32 K1, u32 qb, int &r, int b, int limit, u32 &cnt)
 {
+    // qb and tab_abs hold absolute LDS addresses (the dynamic segment's base folded in): no base add per look-up
     const u32 sh = 32 - K1;
     if (!LAST) {
         const int bk = b - (int)K1;
         while (r <= bk) {                               // the window holds only codes that start before b
             const u32 q = qb + (u32)r;
-            const u32 a = (q >> 3) & ~3u;
-            const u32 win = __builtin_amdgcn_alignbit(*(const u32 *)(smem + a), *(const u32 *)(smem + a + 4), ~q);
-            const u32 e = *(const u16 *)(smem + tab_off + ((win >> sh) << 1));
+            const lds_u32 *pa = (const lds_u32 *)(size_t)((q >> 3) & ~3u);
+            const u32 win = __builtin_amdgcn_alignbit(pa[0], pa[1], ~q);
+            const u32 e = *(const lds_u16 *)(size_t)(tab_abs + ((win >> sh) << 1));
             r += (int)(e & 15u);
             cnt += e >> 12;
         }
     }
     while (r < b) {
         const u32 q = qb + (u32)r;
-        const u32 a = (q >> 3) & ~3u;
-        const u32 win = __builtin_amdgcn_alignbit(*(const u32 *)(smem + a), *(const u32 *)(smem + a + 4), ~q);
-        const int l0 = (int)((*(const u16 *)(smem + tab_off + ((win >> sh) << 1)) >> 4) & 15u);
+        const lds_u32 *pa = (const lds_u32 *)(size_t)((q >> 3) & ~3u);
+        const u32 win = __builtin_amdgcn_alignbit(pa[0], pa[1], ~q);
+        const int l0 = (int)((*(const lds_u16 *)(size_t)(tab_abs + ((win >> sh) << 1)) >> 4) & 15u);
         if (LAST && r + l0 > limit) { r = b + 15; break; }       // cut by the end of the stream: nothing starts after it
         r += l0;
         ++cnt;
@@ -1212,7 +1215,7 @@ __device__ __forceinline__ void spec_walk(const u8 *smem, u32 tab_off, u32 K1, u
 // a strip from entry `ent0` of its first chunk: entries and counts of its SPEC_STRIP chunks, exit of the last one.
 // HAVE_OLD: ent[] holds the entries of an earlier walk of the same strip: once this walk meets it the rest is unchanged.
 template <bool LAST, bool HAVE_OLD>
-__device__ __forceinline__ void spec_strip(const u8 *smem, u32 tab_off, u32 K1, u32 qb, int limit, u32 ent0,
+__device__ __forceinline__ void spec_strip(u32 tab_abs, u32 K1, u32 qb, int limit, u32 ent0,
                                            u32 (&ent)[SPEC_STRIP], u32 (&cnt)[SPEC_STRIP], u32 &exit_)
 {
     int r = (int)ent0;
@@ -1221,7 +1224,7 @@ __device__ __forceinline__ void spec_strip(const u8 *smem, u32 tab_off, u32 K1, 
         if (HAVE_OLD && k > 0 && (u32)(r - 256 * k) == ent[k]) return;  // back on the earlier walk's path
         ent[k] = (u32)(r - 256 * k);
         u32 c = 0;
-        spec_walk<LAST>(smem, tab_off, K1, qb, r, 256 * (k + 1), limit, c);
+        spec_walk<LAST>(tab_abs, K1, qb, r, 256 * (k + 1), limit, c);
         cnt[k] = c;
     }
     exit_ = (u32)(r - 256 * SPEC_STRIP) & 15u;
@@ -1276,7 +1279,8 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
     const u64 capb = (u64)SPEC_TILES * DTILE + 4;
     const bool last = left < capb;                      // the stream ends inside this frame
     const int limit = last ? (int)(left * 8) - (int)(256u * SPEC_STRIP * tid) : 0;
-    const u32 qb = 8u * (4u * SPEC_ROW) * (tid + 1) - 1u;
+    const u32 sbase = (u32)(size_t)smem;               // LDS offset of the dynamic segment (low half of its flat address)
+    const u32 qb = 8u * (sbase + (4u * SPEC_ROW) * (tid + 1)) - 1u, tab_abs = sbase + tab_off;
     u32 ent[SPEC_STRIP], cnt[SPEC_STRIP], exit_ = 0;
     {
         u32 e0;
@@ -1288,12 +1292,12 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
             int r = 256 * (SPEC_STRIP - 1);
             u32 dummy = 0;
             const u32 qp = qb - 8u * (4u * SPEC_ROW);
-            if (last) spec_walk<true>(smem, tab_off, K1, qp, r, 256 * SPEC_STRIP, limit + 256 * SPEC_STRIP, dummy);
-            else spec_walk<false>(smem, tab_off, K1, qp, r, 256 * SPEC_STRIP, 0, dummy);
+            if (last) spec_walk<true>(tab_abs, K1, qp, r, 256 * SPEC_STRIP, limit + 256 * SPEC_STRIP, dummy);
+            else spec_walk<false>(tab_abs, K1, qp, r, 256 * SPEC_STRIP, 0, dummy);
             e0 = (u32)(r - 256 * SPEC_STRIP) & 15u;
         }
-        if (last) spec_strip<true, false>(smem, tab_off, K1, qb, limit, e0, ent, cnt, exit_);
-        else spec_strip<false, false>(smem, tab_off, K1, qb, limit, e0, ent, cnt, exit_);
+        if (last) spec_strip<true, false>(tab_abs, K1, qb, limit, e0, ent, cnt, exit_);
+        else spec_strip<false, false>(tab_abs, K1, qb, limit, e0, ent, cnt, exit_);
     }
     ex[tid] = (u8)exit_;
     __syncthreads();
@@ -1304,8 +1308,8 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
         if (!__syncthreads_or(bad)) break;
         if (bad) {
             const u32 e0 = ex[tid - 1];
-            if (last) spec_strip<true, true>(smem, tab_off, K1, qb, limit, e0, ent, cnt, exit_);
-            else spec_strip<false, true>(smem, tab_off, K1, qb, limit, e0, ent, cnt, exit_);
+            if (last) spec_strip<true, true>(tab_abs, K1, qb, limit, e0, ent, cnt, exit_);
+            else spec_strip<false, true>(tab_abs, K1, qb, limit, e0, ent, cnt, exit_);
         }
         __syncthreads();                                // every lane has read the exit in front of it
         ex[tid] = (u8)exit_;
@@ -1488,7 +1492,6 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *
 // The host sizes the image for the launch's average symbols per tile plus a margin (LDS is what limits the waves per
 // CU); a tile with more symbols than it holds goes in several rounds of consecutive lanes.
 // ------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) u32 lds_u32;
 constexpr int WS_ROW = CH_BYTES / 4 + 1;            // LDS words per chunk row
 constexpr int WS_ROWS_BYTES = 16 + DEC_THREADS * WS_ROW * 4;     // 16 in front: the window at a row's bit 0 reads the word before it
 constexpr int WS_MISC = DEC_THREADS * 4 + 32;
