@@ -84,6 +84,12 @@ __device__ __forceinline__ bool dp_skipped(const DecBlk &blk)
 {
     return blk.run_dp && __hip_atomic_load(blk.run_dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
 }
+// the same question before the block record is copied (the usual answer is "skipped": read one pointer, not the record)
+__device__ __forceinline__ bool dp_skipped_early(const DecBlk *p)
+{
+    u32 *const rd = p->run_dp;
+    return rd && __hip_atomic_load(rd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+}
 
 // stream words are kept big-endian in LDS, one pad word per 8 (chunk stride 9 words: no bank conflicts)
 __device__ __forceinline__ u32 widx(u32 w) { return w + (w >> 3); }
@@ -413,8 +419,9 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_sync16(const DecBlk *__restri
 {
     // static LDS: constant addresses fold into the ds_read offset field (no per-lookup address add)
     __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + (PAIR ? 2 : 1) * (1 << LEN_MAXK) + DEC_THREADS * 8 + 64 + (LONG ? LONG_BYTES : 0)];
+    if (dp_skipped_early(blks + blockIdx.y)) return;
     const DecBlk blk = blks[blockIdx.y];
-    if (blockIdx.x * tpw >= blk.n_tiles || dp_skipped(blk)) return;
+    if (blockIdx.x * tpw >= blk.n_tiles) return;
     u32 *data = (u32 *)smem;
     u8 *lenlut = smem + LDS_DATA;
     u64 *cmap = (u64 *)(lenlut + (PAIR ? 2u : 1u) * (1u << LEN_MAXK));
@@ -740,8 +747,8 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tiles16(const DecBlk *__restr
     __shared__ u8 ent[TB];
     __shared__ u8 segmap[16 * 16], segent[16];
     __shared__ u32 carry;
+    if (dp_skipped_early(blks + blockIdx.x)) return;
     const DecBlk blk = blks[blockIdx.x];
-    if (dp_skipped(blk)) return;
     const u32 tid = threadIdx.x, sg = tid >> 4, d = tid & 15u;
     if (tid == 0) carry = 0;
     for (u32 t0 = 0; t0 < blk.n_tiles; t0 += TB) {
@@ -1074,9 +1081,10 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) __attribute__((amdgpu_waves_per
     // lane is latency bound: waves per CU is what counts)
     constexpr int PER_SUB = LDS_DATA + DEC_THREADS * 16 + 64 + 16;
     __shared__ __attribute__((aligned(16))) u8 smem[SUBS * PER_SUB + 16384 + 2048 + 64];
+    if (dp_skipped_early(blks + blockIdx.y)) return;
     const DecBlk blk = blks[blockIdx.y];
     const u32 first_tile = blockIdx.x * tpw * SUBS;
-    if (first_tile >= blk.n_tiles || dp_skipped(blk)) return;
+    if (first_tile >= blk.n_tiles) return;
     const u32 sub = threadIdx.x >> 8, tid = threadIdx.x & 255u, lane = tid & 63, wv = tid >> 6;
     u8 *mine = smem + sub * PER_SUB;
     u32 *data = (u32 *)mine;
@@ -2177,10 +2185,10 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
             hipLaunchKernelGGL(sfd_spec_check<true>, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
         }
         // when every block of the launch speculates, the DP kernels below are fall-backs that normally return at once:
-        // fat workgroups (32 tiles each) make that a launch of a few thousand workgroups instead of a few hundred thousand
+        // fat workgroups (256 tiles each) make that a launch of a few thousand workgroups instead of a few hundred thousand
         bool all_spec = any_spec;
         for (int b = 0; b < nblocks; ++b) if (ntiles[b] && !spec_blk[b]) all_spec = false;
-        const u32 tpw_dp = all_spec ? 32u : tpw;
+        const u32 tpw_dp = all_spec ? 256u : tpw;
         const dim3 grid_fd((u32)ceil_div_u64(max_tiles, tpw_dp), (u32)nblocks);
         const dim3 grid_cd((u32)ceil_div_u64(max_tiles, tpw_dp * CSUBS), (u32)nblocks);
         u32 k1_all = 0;                                // common K1 of the running blocks, 0 when they differ
