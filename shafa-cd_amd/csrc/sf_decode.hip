@@ -40,6 +40,9 @@ constexpr int HALO_WORDS = 16;                     // 64 bytes past the tile (wi
 constexpr int DATA_WORDS = DTILE / 4 + HALO_WORDS;
 constexpr int LUT_MAXK = 11;
 constexpr int LUT2_MAX = 4096;                     // level-2 entries kept in LDS (8 KiB)
+constexpr int SPEC_MINW = 1;                       // narrowest window of the counting table of sfd_spec (1 = the longest code's
+                                                   // length; measured on Lmax = 10 data: 11 bits no gain, 12 bits 3 % slower:
+                                                   // fewer steps, but an 8 KiB table costs two workgroups per CU)
 constexpr int SYM3_MAXK = 12;                      // widest window of the three-codes table of sfd_wstage: 16 KiB
 constexpr int LDS_DATA = (DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
 constexpr int LONG_PFX = 128;                      // codes longer than SYM3_MAXK bits, grouped by their first SYM3_MAXK bits
@@ -58,7 +61,7 @@ struct DecBlk {
                            //   group (next nb bits index lut2[base..]) ; 0 = go to the trie
     const u16 *lut2;       // level 2 (codes of K+1 .. K+8 bits): sym | len << 8 ; 0 = go to the trie
     const u8 *lenlut;      // 2^K1 entries: len only (DP of the packed path); 0 = longer than K1 bits
-    u16 *cnt3;             // 2^K1 entries: up to three codes per window: total bits | len0 << 4 | n << 12
+    u16 *cnt3;             // 2^spec_window(K1) entries: the whole codes in a window: total bits | len0 << 4 | n << 12
     u32 *sym3;             // 2^K3 entries: sym0 | sym1 << 8 | sym2 << 16 | total bits << 24 (6 bits) | n << 30
     u8 *pairlut;           // 2^(K1+1) entries: (len(p)-1) | (len(p+1)-1) << 4 from a K1+1-bit window (complete codes)
     const u16 *lut13;      // 2^K1 entries: sym | len << 8, single level (only when Lmax <= 13), else NULL
@@ -78,6 +81,9 @@ struct DecBlk {
     u32 *run_dp;           // speculative launches: *run_dp != 0 <=> the block needs the exact (DP) kernels: it was not
                            //   tried speculatively or did not verify; NULL: no speculation, the DP kernels always run
 };
+
+// window of the code-counting table of sfd_spec: wider than the longest code when that is short (more bits per look-up)
+__host__ __device__ __forceinline__ u32 spec_window(u32 K1) { return K1 < (u32)SPEC_MINW ? (u32)SPEC_MINW : K1; }
 
 // the exact kernels of a launch that also runs the speculative ones: skip the blocks that verified
 __device__ __forceinline__ bool dp_skipped(const DecBlk &blk)
@@ -373,11 +379,12 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
     for (u32 i = threadIdx.x; blk.pairlut && i < (2u << K1); i += DEC_THREADS)
         blk.pairlut[i] = (u8)((blk.lenlut[i >> 1] - 1u) | ((blk.lenlut[i & mask] - 1u) << 4));
     const u32 K3 = K1 < (u32)SYM3_MAXK ? K1 : (u32)SYM3_MAXK;
-    for (u32 i = threadIdx.x; i <= mask; i += DEC_THREADS) {
+    const u32 KW = spec_window(K1), maskw = (1u << KW) - 1;      // the counting window may be wider than the longest code
+    for (u32 i = threadIdx.x; i <= maskw; i += DEC_THREADS) {
         u32 pos = 0, n = 0, l0 = 0;
-        for (; n < 3; ++n) {
-            const u32 L = blk.lut13[(i << pos) & mask] >> 8;     // window shifted left, zero filled
-            if (L == 0 || L > K1 - pos) break;                   // longer than the window / would use bits outside it
+        for (; n < 15; ++n) {
+            const u32 L = blk.lut13[((i << pos) & maskw) >> (KW - K1)] >> 8;      // window shifted left, zero filled
+            if (L == 0 || L > KW - pos) break;                   // longer than the window / would use bits outside it
             if (n == 0) l0 = L;
             pos += L;
         }
@@ -992,54 +999,25 @@ __device__ __forceinline__ u32 count13_loop(const u32 *data, const u8 *lenlut, u
     return cnt;
 }
 
-// up to three codes per lookup (complete tables); the chunk tail and the last tile step one code at a time
-template <bool LAST>
-__device__ __forceinline__ u32 count3_loop(const u32 *data, const u16 *tab, u32 K1, u32 cbase, u32 entry, u32 limit)
-{
-    u32 p = entry, cnt = 0;
-    const u32 sh = 32 - K1;
-    BitBuf bb;
-    bb.init(data, cbase + p);
-    if (!LAST) {
-        const u32 stop = (u32)CH_BITS - K1;       // a window at p <= stop holds only codes that start inside the chunk
-        while (p <= stop) {
-            const u32 e = tab[bb.peek32() >> sh];
-            const u32 tot = e & 15u;
-            cnt += e >> 12;
-            p += tot;
-            bb.skip(data, tot);
-        }
-    }
-    while (p < (u32)CH_BITS) {
-        const u32 l0 = (tab[bb.peek32() >> sh] >> 4) & 15u;
-        if (LAST && cbase + p + l0 > limit) break;
-        p += l0;
-        ++cnt;
-        bb.skip(data, l0);
-    }
-    return cnt;
-}
-
-template <bool MULTI>
 __global__ __launch_bounds__(DEC_THREADS) void sfd_count13(const DecBlk *__restrict__ blks,
                                                            const u64 *__restrict__ chunkfn,
                                                            const u8 *__restrict__ tile_entry,
                                                            u8 *__restrict__ chunk_entry, u16 *__restrict__ chunk_cnt,
                                                            u32 *__restrict__ tile_cnt, u32 tpw)
 {
-    __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + DEC_THREADS * 16 + (MULTI ? 2 : 1) * (1 << LEN_MAXK) + 64 + 16 + 64];
+    __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + DEC_THREADS * 16 + (1 << LEN_MAXK) + 64 + 16 + 64];
     const DecBlk blk = blks[blockIdx.y];
     if (blockIdx.x * tpw >= blk.n_tiles) return;
     u32 *data = (u32 *)smem;
     u64 *cm = (u64 *)(smem + LDS_DATA);
     u8 *lenlut = (u8 *)(cm + DEC_THREADS);
-    u64 *hist = (u64 *)(lenlut + (MULTI ? 2u : 1u) * (1u << LEN_MAXK));
+    u64 *hist = (u64 *)(lenlut + (1u << LEN_MAXK));
     u8 *wmb = (u8 *)(hist + DEC_THREADS);
     u32 *wsum = (u32 *)(wmb + 64);
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 K1 = blk.K1;
 
-    fill_lds16(lenlut, MULTI ? (const void *)blk.cnt3 : (const void *)blk.lenlut, MULTI ? (2u << K1) : (1u << K1));
+    fill_lds16(lenlut, (const void *)blk.lenlut, 1u << K1);
     const u32 tile_end = (blockIdx.x + 1) * tpw < blk.n_tiles ? (blockIdx.x + 1) * tpw : blk.n_tiles;
     for (u32 tile = blockIdx.x * tpw; tile < tile_end; ++tile) {
     const size_t gt = (size_t)blk.tile_base + tile;
@@ -1050,13 +1028,8 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_count13(const DecBlk *__restr
     const u32 entry = chunk_entry_of(cm, hist, wmb, tile_entry[gt]);
     const u32 limit = tile_bit_limit(blk, tile);
     const bool last = limit < (u32)(DTILE + HALO_WORDS * 4) * 8;          // the stream ends inside this window
-    u32 cnt;
-    if (MULTI)
-        cnt = last ? count3_loop<true>(data, (const u16 *)lenlut, K1, tid * CH_BITS, entry, limit)
-                   : count3_loop<false>(data, (const u16 *)lenlut, K1, tid * CH_BITS, entry, limit);
-    else
-        cnt = last ? count13_loop<true>(data, lenlut, 32 - K1, blk.trie, tid * CH_BITS, entry, limit)
-                   : count13_loop<false>(data, lenlut, 32 - K1, blk.trie, tid * CH_BITS, entry, limit);
+    const u32 cnt = last ? count13_loop<true>(data, lenlut, 32 - K1, blk.trie, tid * CH_BITS, entry, limit)
+                         : count13_loop<false>(data, lenlut, 32 - K1, blk.trie, tid * CH_BITS, entry, limit);
     chunk_entry[gt * DEC_THREADS + tid] = (u8)entry;
     chunk_cnt[gt * DEC_THREADS + tid] = (u16)cnt;
     const u32 tot = wave_reduce_add<u32>(cnt);
@@ -1253,7 +1226,7 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
     const u32 tab_off = SPEC_LDS_DATA;
     u8 *ex = smem + SPEC_LDS_DATA + tab_bytes;
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 K1 = blk.K1;
+    const u32 K1 = spec_window(blk.K1);                 // the counting table's window
     fill_lds16((void *)(smem + tab_off), (const void *)blk.cnt3, 2u << K1);
     {   // the region's stream from one strip before it, 16 bytes a lane; frame word f -> LDS word f + f / SPEC_SW
         const long long base = (long long)tile0 * DTILE - 4 * SPEC_SW;
@@ -2170,7 +2143,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         if (any_spec) {                                // guesses, two rounds of tile repairs, final verdict per block
             u8 *tg = ws + o_tguess, *tx = ws + o_texit, *tf = ws + o_tfix;
             u32 k1_max = 1;
-            for (int b = 0; b < nblocks; ++b) if (spec_blk[b] && tabs[b].K1 > k1_max) k1_max = tabs[b].K1;
+            for (int b = 0; b < nblocks; ++b) if (spec_blk[b] && spec_window(tabs[b].K1) > k1_max) k1_max = spec_window(tabs[b].K1);
             const u32 tabb = 2u << k1_max;
             const size_t lds_spec = (size_t)SPEC_LDS_DATA + tabb + DEC_THREADS + 16;
             const dim3 grid_s((u32)ceil_div_u64(max_tiles, SPEC_TILES), (u32)nblocks);
@@ -2217,7 +2190,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
                                    (const u64 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
                                    (u32 *)(ws + o_tcnt), tpw_dp);
             else
-                hipLaunchKernelGGL(sfd_count13<false>, grid_fd, dim3(DEC_THREADS), 0, st, dblk,
+                hipLaunchKernelGGL(sfd_count13, grid_fd, dim3(DEC_THREADS), 0, st, dblk,
                                    (const u64 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
                                    (u32 *)(ws + o_tcnt), tpw_dp);
         } else {
