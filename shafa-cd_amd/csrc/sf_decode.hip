@@ -1166,26 +1166,40 @@ constexpr int SPEC_LDS_DATA = (SPEC_STRIPS * SPEC_ROW + 3) / 4 * 16;
 // counting the codes started on the way.  The window at bit p is alignbit(W[(p-1)>>5], W[((p-1)>>5)+1], ~(p-1)): no bit
 // buffer to refill, two look-ups per step.  qb = 8 * (byte address of the row) - 1.
 // LAST: the stream ends at bit `limit` of the strip (may be negative); a code that does not end inside it is not a symbol.
+// the two stream words a window needs, kept across steps: a walk moves ~8 bits a step, so a lane needs new words
+// only every fourth step, and an LDS read costs bank cycles per ACTIVE lane
+struct SpecWin {
+    u32 hi, lo, wa;                                     // words at LDS address wa, wa + 4
+    __device__ __forceinline__ void init() { wa = 0xFFFFFFFFu; hi = lo = 0; }
+    __device__ __forceinline__ u32 at(u32 q)            // the 32 bits at bit q + 1 (q = bit address - 1)
+    {
+        const u32 a = (q >> 3) & ~3u;
+        if (a != wa) {
+            const lds_u32 *pa = (const lds_u32 *)(size_t)a;
+            hi = pa[0];
+            lo = pa[1];
+            wa = a;
+        }
+        return __builtin_amdgcn_alignbit(hi, lo, ~q);
+    }
+};
+
 template <bool LAST>
-__device__ __forceinline__ void spec_walk(u32 tab_abs, u32 K1, u32 qb, int &r, int b, int limit, u32 &cnt)
+__device__ __forceinline__ void spec_walk(u32 tab_abs, u32 K1, u32 qb, int &r, int b, int limit, u32 &cnt, SpecWin &sw)
 {
     // qb and tab_abs hold absolute LDS addresses (the dynamic segment's base folded in): no base add per look-up
     const u32 sh = 32 - K1;
     if (!LAST) {
         const int bk = b - (int)K1;
         while (r <= bk) {                               // the window holds only codes that start before b
-            const u32 q = qb + (u32)r;
-            const lds_u32 *pa = (const lds_u32 *)(size_t)((q >> 3) & ~3u);
-            const u32 win = __builtin_amdgcn_alignbit(pa[0], pa[1], ~q);
+            const u32 win = sw.at(qb + (u32)r);
             const u32 e = *(const lds_u16 *)(size_t)(tab_abs + ((win >> sh) << 1));
             r += (int)(e & 15u);
             cnt += e >> 12;
         }
     }
     while (r < b) {
-        const u32 q = qb + (u32)r;
-        const lds_u32 *pa = (const lds_u32 *)(size_t)((q >> 3) & ~3u);
-        const u32 win = __builtin_amdgcn_alignbit(pa[0], pa[1], ~q);
+        const u32 win = sw.at(qb + (u32)r);
         const int l0 = (int)((*(const lds_u16 *)(size_t)(tab_abs + ((win >> sh) << 1)) >> 4) & 15u);
         if (LAST && r + l0 > limit) { r = b + 15; break; }       // cut by the end of the stream: nothing starts after it
         r += l0;
@@ -1200,12 +1214,14 @@ __device__ __forceinline__ void spec_strip(u32 tab_abs, u32 K1, u32 qb, int limi
                                            u32 (&ent)[SPEC_STRIP], u32 (&cnt)[SPEC_STRIP], u32 &exit_)
 {
     int r = (int)ent0;
+    SpecWin sw;
+    sw.init();
 #pragma unroll
     for (int k = 0; k < SPEC_STRIP; ++k) {
         if (HAVE_OLD && k > 0 && (u32)(r - 256 * k) == ent[k]) return;  // back on the earlier walk's path
         ent[k] = (u32)(r - 256 * k);
         u32 c = 0;
-        spec_walk<LAST>(tab_abs, K1, qb, r, 256 * (k + 1), limit, c);
+        spec_walk<LAST>(tab_abs, K1, qb, r, 256 * (k + 1), limit, c, sw);
         cnt[k] = c;
     }
     exit_ = (u32)(r - 256 * SPEC_STRIP) & 15u;
@@ -1273,8 +1289,10 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
             int r = 256 * (SPEC_STRIP - 1);
             u32 dummy = 0;
             const u32 qp = qb - 8u * (4u * SPEC_ROW);
-            if (last) spec_walk<true>(tab_abs, K1, qp, r, 256 * SPEC_STRIP, limit + 256 * SPEC_STRIP, dummy);
-            else spec_walk<false>(tab_abs, K1, qp, r, 256 * SPEC_STRIP, 0, dummy);
+            SpecWin sw;
+            sw.init();
+            if (last) spec_walk<true>(tab_abs, K1, qp, r, 256 * SPEC_STRIP, limit + 256 * SPEC_STRIP, dummy, sw);
+            else spec_walk<false>(tab_abs, K1, qp, r, 256 * SPEC_STRIP, 0, dummy, sw);
             e0 = (u32)(r - 256 * SPEC_STRIP) & 15u;
         }
         if (last) spec_strip<true, false>(tab_abs, K1, qb, limit, e0, ent, cnt, exit_);
