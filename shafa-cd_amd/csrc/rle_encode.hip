@@ -54,6 +54,7 @@ struct RleShared {
     u16 E[260];     // fast path: equality masks of the threads, [0] = the 16 bytes before the tile, [257] = after
     u16 lastb[258]; // fast path: last byte of every thread, [0] = the byte before the tile (0x100: none)
     u32 dump[RLE_THREADS];      // fast path: where the byte writes of bytes that emit nothing go
+    u32 slow;                   // fast path: some wave asks for the general tile code
 };
 
 // General tile code: any input (runs of any length, ragged last tile).  Per element closed form.
@@ -266,34 +267,66 @@ struct Rle3Ctx {            // what a thread of the mask-based tile code knows a
 
 // loads + masks; returns false when the tile has to take the general code (ragged end of the block).
 // sh.E / sh.lastb filled; barrier inside.
-__device__ __forceinline__ bool rle3_masks(RleShared &sh, const RleBlk &blk, const int k, Rle3Ctx &c, const bool lookahead)
+// a tile's loads, issued for both tiles of a workgroup before either is worked on (the second tile's memory latency
+// passes while the first is processed; nothing is loaded after the first store, so no wave drains its stores for a load)
+struct Rle3Pre {
+    uint4 v;                    // the thread's 16 bytes
+    u32 qb, qa;                 // thread 0: the four bytes before the tile; thread 255: the four bytes after it
+    u32 hb[4];                  // wave 1 (lookahead): bytes tile_end + 4 lane + 0..3, 0x400 past the end of the block
+    bool full;                  // the tile (and, with lookahead, four bytes more) lies inside the block: mask code possible
+};
+__device__ __forceinline__ Rle3Pre rle3_preload(const RleBlk &blk, const int k, const bool lookahead)
+{
+    Rle3Pre p;
+    p.v = make_uint4(0, 0, 0, 0);
+    p.qb = p.qa = 0;
+    p.hb[0] = p.hb[1] = p.hb[2] = p.hb[3] = 0x400u;
+    const u64 tile_start = (u64)k * RLE_TILE, tile_end = tile_start + RLE_TILE;
+    p.full = (u32)k < blk.n_tiles && tile_end + (lookahead ? 4 : 0) <= blk.n;    // uniform
+    if (p.full) {
+        p.v = *(const uint4 *)(blk.in + tile_start + (u64)threadIdx.x * 16);
+        if (threadIdx.x == 0 && k > 0) p.qb = *(const u32 *)(blk.in + tile_start - 4);
+        if (threadIdx.x == RLE_THREADS - 1 && lookahead) p.qa = *(const u32 *)(blk.in + tile_end);
+        if (lookahead && (threadIdx.x >> 6) == 1) {     // the 256 bytes after the tile: the count of a run that leaves it
+            const u64 q = tile_end + (u64)(threadIdx.x & 63) * 4;
+            if (q + 4 <= blk.n) {
+                const u32 v = *(const u32 *)(blk.in + q);
+                p.hb[0] = v & 0xFFu; p.hb[1] = (v >> 8) & 0xFFu; p.hb[2] = (v >> 16) & 0xFFu; p.hb[3] = v >> 24;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (q + j < blk.n) p.hb[j] = (u32)blk.in[q + j];
+            }
+        }
+    }
+    return p;
+}
+
+__device__ __forceinline__ bool rle3_masks(RleShared &sh, const int k, Rle3Ctx &c, const bool lookahead, const Rle3Pre &pre)
 {
     const int tid = threadIdx.x;
-    const u64 n = blk.n;
-    const u64 tile_start = (u64)k * RLE_TILE, tile_end = tile_start + RLE_TILE;
-    if (tile_end + (lookahead ? 4 : 0) > n) return false;                // uniform
-    const uint4 v = *(const uint4 *)(blk.in + tile_start + (u64)tid * 16);
-    c.w[0] = v.x; c.w[1] = v.y; c.w[2] = v.z; c.w[3] = v.w;
+    if (!pre.full) return false;                                         // uniform
+    c.w[0] = pre.v.x; c.w[1] = pre.v.y; c.w[2] = pre.v.z; c.w[3] = pre.v.w;
     sh.lastb[tid + 1] = (u16)(c.w[3] >> 24);
     if (tid == 0) {
         u32 e0 = 0, lb = 0x100u;                       // first tile: nothing before it
         if (k > 0) {
-            const u32 q = *(const u32 *)(blk.in + tile_start - 4);      // bytes -4 .. -1
+            const u32 q = pre.qb;                      // bytes -4 .. -1
             e0 = (eqmask4(q, q << 8) >> 1) << 13;      // E of positions -3, -2, -1 in bits 13..15
             lb = q >> 24;
         }
         sh.E[0] = (u16)e0;
         sh.lastb[0] = (u16)lb;
+        sh.slow = 0;
     }
     if (tid == RLE_THREADS - 1) {
         u32 e = 0;
         if (lookahead) {
-            const u32 q = *(const u32 *)(blk.in + tile_end);            // bytes 4096 .. 4099 of the tile's frame
+            const u32 q = pre.qa;                      // bytes 4096 .. 4099 of the tile's frame
             e = eqmask4(q, (q << 8) | (c.w[3] >> 24)) & 7u;
         }
         sh.E[RLE_THREADS + 1] = (u16)e;
     }
-    __syncthreads();
+    lds_barrier();
     const u32 pb = sh.lastb[tid];
     u32 E16 = eqmask4(c.w[0], (c.w[0] << 8) | (pb & 0xFFu)) | (eqmask4(c.w[1], __builtin_amdgcn_alignbit(c.w[1], c.w[0], 24)) << 4) |
               (eqmask4(c.w[2], __builtin_amdgcn_alignbit(c.w[2], c.w[1], 24)) << 8) |
@@ -305,14 +338,12 @@ __device__ __forceinline__ bool rle3_masks(RleShared &sh, const RleBlk &blk, con
     return true;
 }
 
-__global__ __launch_bounds__(RLE_THREADS) void rle3_summary(const RleBlk *__restrict__ blks, u32 *__restrict__ tsum)
+__device__ __forceinline__ void rle3_summary_tile(RleShared &sh, const RleBlk &blk, const int k, const Rle3Pre &pre,
+                                                  u32 *__restrict__ tsum)
 {
-    __shared__ __attribute__((aligned(16))) RleShared sh;
-    const RleBlk blk = blks[blockIdx.y];
-    const int k = (int)blockIdx.x, tid = threadIdx.x, lane = lane_id(), wv = wave_id();
-    if ((u32)k >= blk.n_tiles) return;
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     Rle3Ctx c;
-    if (!rle3_masks(sh, blk, k, c, false)) {           // ragged last tile: nothing follows that needs it
+    if (!rle3_masks(sh, k, c, false, pre)) {           // ragged last tile: nothing follows that needs it
         if (tid == 0) tsum[blk.desc_base + k] = 0;
         return;
     }
@@ -325,11 +356,25 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_summary(const RleBlk *__rest
         last = (wv * 64 + l) * 16 + (31 - __builtin_clz(hv));
     }
     if (lane == 0) sh.wsum[wv] = (u32)last;
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
         int lp = -1;
         for (int ww = 0; ww < 4; ++ww) if ((int)sh.wsum[ww] >= 0) lp = (int)sh.wsum[ww];
         tsum[blk.desc_base + k] = lp < 0 ? (0x80000000u | (u32)RLE_TILE) : (u32)(RLE_TILE - lp);
+    }
+}
+
+__global__ __launch_bounds__(RLE_THREADS) void rle3_summary(const RleBlk *__restrict__ blks, u32 *__restrict__ tsum)
+{
+    __shared__ __attribute__((aligned(16))) RleShared sh;
+    const RleBlk blk = blks[blockIdx.y];
+    const int k0 = 2 * (int)blockIdx.x;                 // two tiles per workgroup, both loaded up front
+    if ((u32)k0 >= blk.n_tiles) return;
+    const Rle3Pre p0 = rle3_preload(blk, k0, false), p1 = rle3_preload(blk, k0 + 1, false);
+    rle3_summary_tile(sh, blk, k0, p0, tsum);
+    if ((u32)(k0 + 1) < blk.n_tiles) {
+        lds_barrier();
+        rle3_summary_tile(sh, blk, k0 + 1, p1, tsum);
     }
 }
 
@@ -399,23 +444,21 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_offsets(const RleBlk *__rest
 }
 
 template <int MODE>                                     // 1: sizes -> T, 2: emit at G
-__global__ __launch_bounds__(RLE_THREADS) void rle3_pass(const RleBlk *__restrict__ blks, const u32 *__restrict__ Rarr,
-                                                         u32 *__restrict__ Tarr, const u64 *__restrict__ Garr)
+__device__ __forceinline__ void rle3_pass_tile(RleShared &sh, const RleBlk &blk, const int k, const Rle3Pre &pre, const u32 Rin,
+                                               const u64 Gin, u32 *__restrict__ Tarr)
 {
-    __shared__ __attribute__((aligned(16))) RleShared sh;
-    const RleBlk blk = blks[blockIdx.y];
-    const int k = (int)blockIdx.x, tid = threadIdx.x, lane = lane_id(), wv = wave_id();
-    if ((u32)k >= blk.n_tiles) return;
-    const u32 Rin = Rarr[blk.desc_base + k];
-    const u64 Gin = MODE == 2 ? Garr[blk.desc_base + k] : 0ull;
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     Rle3Ctx c;
-    bool fast = rle3_masks(sh, blk, k, c, true);
+    bool fast = rle3_masks(sh, k, c, true, pre);
     if (fast) {
         // mask code only when no run around the tile can reach 255 bytes inside it: at most 5 threads per wave lie
         // wholly inside a run (<= 10 across a wave edge: 192 bytes with both ends) and the entering run is < 60 bytes
         const u32 transparent = (u32)__builtin_popcountll((unsigned long long)__ballot(c.E16 == 0xFFFFu));
         const bool enters = (sh.E[1] & 1u) != 0;
-        if (__syncthreads_or((transparent > 5) || (enters && Rin >= 60))) fast = false;
+        // (a barrier that does not drain the second tile's loads: flag in LDS instead of __syncthreads_or)
+        if (lane == 0 && ((transparent > 5) || (enters && Rin >= 60))) sh.slow = 1;
+        lds_barrier();
+        if (sh.slow) fast = false;
     }
     if (!fast) {
         __syncthreads();
@@ -447,15 +490,12 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_pass(const RleBlk *__restric
         const u32 h0 = (u32)__shfl((int)H16, l0, 64);
         if (lane == 0) sh.wf[wv].v += (u32)__builtin_ctz(h0);          // first head of this wave, in bytes from its start
         if (wv == 1) {                                  // halo: bytes after the tile equal to its last byte (<= 255)
-            const u64 n = blk.n, tile_end = (u64)(k + 1) * RLE_TILE;
             const u32 lastb = sh.lastb[RLE_THREADS];
-            const u64 q = tile_end + (u64)lane * 4;
             u32 cnt = 0;
             bool go = true;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const u32 cc = (q + j < n) ? (u32)blk.in[q + j] : 0x400u;
-                go &= (cc == lastb);
+                go &= (pre.hb[j] == lastb);
                 cnt += go ? 1u : 0u;
             }
             const u64 full = __ballot(cnt == 4);
@@ -467,7 +507,7 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_pass(const RleBlk *__restric
         }
         (void)above;
     }
-    __syncthreads();
+    lds_barrier();
     u32 run = 0, off = 0;
 #pragma unroll
     for (int ww = 0; ww < 4; ++ww) {
@@ -513,7 +553,7 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_pass(const RleBlk *__restric
         st8[at] = 0;
         st8[at + 2] = (u8)L;
     }
-    __syncthreads();
+    lds_barrier();
     const u64 end_b = G + Tt;
     if (end_b > blk.out_cap) {
         if (tid == 0) set_error(blk.err, SHAFA_LACK_OF_MEMORY);
@@ -532,6 +572,25 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_pass(const RleBlk *__restric
                     if (lo + q >= shift && lo + q < shift + Tt) gbase[lo + q] = (u8)(wds[q >> 2] >> (8 * (q & 3)));
             }
         }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(RLE_THREADS) void rle3_pass(const RleBlk *__restrict__ blks, const u32 *__restrict__ Rarr,
+                                                         u32 *__restrict__ Tarr, const u64 *__restrict__ Garr)
+{
+    __shared__ __attribute__((aligned(16))) RleShared sh;
+    const RleBlk blk = blks[blockIdx.y];
+    const int k0 = 2 * (int)blockIdx.x;                 // two tiles per workgroup, everything loaded up front
+    if ((u32)k0 >= blk.n_tiles) return;
+    const bool two = (u32)(k0 + 1) < blk.n_tiles;
+    const Rle3Pre p0 = rle3_preload(blk, k0, true), p1 = rle3_preload(blk, k0 + 1, true);
+    const u32 R0 = Rarr[blk.desc_base + k0], R1 = two ? Rarr[blk.desc_base + k0 + 1] : 0u;
+    const u64 G0 = MODE == 2 ? Garr[blk.desc_base + k0] : 0ull, G1 = (MODE == 2 && two) ? Garr[blk.desc_base + k0 + 1] : 0ull;
+    rle3_pass_tile<MODE>(sh, blk, k0, p0, R0, G0, Tarr);
+    if (two) {
+        lds_barrier();
+        rle3_pass_tile<MODE>(sh, blk, k0 + 1, p1, R1, G1, Tarr);
     }
 }
 
@@ -582,7 +641,7 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
     HIP_TRY(hipMemcpyAsync(ws + o_blk, hb, (size_t)nblocks * sizeof(RleBlk), hipMemcpyHostToDevice, st));
     if (max_tiles) {
         const RleBlk *dblk = (const RleBlk *)(ws + o_blk);
-        const dim3 grid_t(max_tiles, (u32)nblocks), grid_b((u32)nblocks);
+        const dim3 grid_t((max_tiles + 1) / 2, (u32)nblocks), grid_b((u32)nblocks);     // two tiles per workgroup
         u32 *tsum = (u32 *)(ws + o_tsum), *Rr = (u32 *)(ws + o_R), *Tt = (u32 *)(ws + o_T);
         u64 *Gg = (u64 *)(ws + o_sum);
         hipLaunchKernelGGL(rle3_summary, grid_t, dim3(RLE_THREADS), 0, st, dblk, tsum);
