@@ -252,11 +252,14 @@ __device__ __forceinline__ u32 eqmask4(u32 a, u32 b)
 }
 
 // ================================================================================================
-// Three independent passes (no tickets, no look-backs): every workgroup of every pass is independent.
-//   rle3_summary : per tile {is the whole tile one run that continues the previous byte, trailing run length}
+// Independent passes (no tickets, no look-backs): every workgroup of every pass is independent.
+//   rle3_first   : per tile {is the whole tile one run that continues the previous byte, trailing run length} AND the
+//                  emitted bytes of the mask code (which do not depend on the entering run), flagged
 //   rle3_carry   : per block, segmented scan -> run length that ends at the last byte before every tile
-//   rle3_pass<1> : per tile, emitted bytes          rle3_offsets : per block, exclusive scan + block size
+//   rle3_fix     : emitted bytes of the few tiles that need the general code (flags + carries)
+//   rle3_offsets : per block, exclusive scan + block size
 //   rle3_pass<2> : per tile, tokens -> LDS -> aligned stores
+// Two tiles per workgroup, all their loads issued before either is worked on, barriers that order LDS only.
 // The passes use the mask-based tile code when every run around the tile is short enough that the 255-byte
 // segmentation cannot matter inside it, the per-element general code otherwise.
 // ================================================================================================
@@ -364,17 +367,69 @@ __device__ __forceinline__ void rle3_summary_tile(RleShared &sh, const RleBlk &b
     }
 }
 
-__global__ __launch_bounds__(RLE_THREADS) void rle3_summary(const RleBlk *__restrict__ blks, u32 *__restrict__ tsum)
+// First pass, summary and sizes in one read of the input: the mask code's emitted size of a tile does not depend on the
+// run that enters it — only WHETHER the mask code may be used does (entering run >= 60 bytes) — so the size is computed
+// here, before the carries exist, and flagged: bit 31 = the tile needs the general code whatever enters (ragged, long
+// runs inside), bit 30 = a run enters (rle3_fix recomputes the size once the carry says it is long).
+constexpr u32 T_GENERAL = 0x80000000u, T_ENTERS = 0x40000000u, T_SIZE = 0xFFFFu;
+
+__device__ __forceinline__ void rle3_first_tile(RleShared &sh, const RleBlk &blk, const int k, const Rle3Pre &pre,
+                                                u32 *__restrict__ tsum, u32 *__restrict__ Tarr)
+{
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    Rle3Ctx c;
+    if (!rle3_masks(sh, k, c, true, pre)) {             // ragged tile, or the last full one: summary alone, size by rle3_fix
+        const Rle3Pre q = rle3_preload(blk, k, false);
+        rle3_summary_tile(sh, blk, k, q, tsum);
+        if (tid == 0) Tarr[blk.desc_base + k] = T_GENERAL;
+        return;
+    }
+    const u32 E16 = c.E16, Z16 = c.Z16, H16 = ~E16 & 0xFFFFu;
+    const u64 hm = __ballot(H16 != 0);
+    int last = -1;                                      // tile-local position of the wave's last run head
+    if (hm) {
+        const int l = 63 - __builtin_clzll((unsigned long long)hm);
+        const u32 hv = (u32)__shfl((int)H16, l, 64);
+        last = (wv * 64 + l) * 16 + (31 - __builtin_clz(hv));
+    }
+    const u32 transparent = (u32)__builtin_popcountll((unsigned long long)__ballot(E16 == 0xFFFFu));
+    if (lane == 0) {
+        sh.wsum[wv] = (u32)last;
+        if (transparent > 5) sh.slow = 1;               // a run could reach 255 bytes inside the tile
+    }
+    lds_barrier();                                      // the neighbours' E masks, the waves' last heads and `slow` are in LDS
+    if (tid == 0) {
+        int lp = -1;
+        for (int ww = 0; ww < 4; ++ww) if ((int)sh.wsum[ww] >= 0) lp = (int)sh.wsum[ww];
+        tsum[blk.desc_base + k] = lp < 0 ? (0x80000000u | (u32)RLE_TILE) : (u32)(RLE_TILE - lp);
+    }
+    const bool slow = sh.slow != 0;
+    const bool enters = (sh.E[1] & 1u) != 0;
+    const u32 B = ((u32)sh.E[tid] >> 13) | (E16 << 3) | (((u32)sh.E[tid + 2] & 7u) << 19);   // positions -3 .. 18
+    const u32 Tm = B & (B >> 1) & (B >> 2);
+    const u32 LC = (((Tm >> 1) | Tm | (Tm << 1) | (Tm << 2)) >> 3) & 0xFFFFu;                 // bytes of runs of >= 4
+    const u32 Lit = ~Z16 & ~LC & 0xFFFFu;
+    const u32 T3 = H16 & (Z16 | LC);
+    const u32 tot = (u32)__builtin_popcount(Lit) + 3u * (u32)__builtin_popcount(T3);
+    const u32 wtot = wave_reduce_add<u32>(tot);
+    lds_barrier();                                      // wsum is read: reuse it for the sizes
+    if (lane == 0) sh.wsum[wv] = wtot;
+    lds_barrier();
+    if (tid == 0)
+        Tarr[blk.desc_base + k] = slow ? T_GENERAL : ((sh.wsum[0] + sh.wsum[1] + sh.wsum[2] + sh.wsum[3]) | (enters ? T_ENTERS : 0u));
+}
+
+__global__ __launch_bounds__(RLE_THREADS) void rle3_first(const RleBlk *__restrict__ blks, u32 *__restrict__ tsum, u32 *__restrict__ Tarr)
 {
     __shared__ __attribute__((aligned(16))) RleShared sh;
     const RleBlk blk = blks[blockIdx.y];
     const int k0 = 2 * (int)blockIdx.x;                 // two tiles per workgroup, both loaded up front
     if ((u32)k0 >= blk.n_tiles) return;
-    const Rle3Pre p0 = rle3_preload(blk, k0, false), p1 = rle3_preload(blk, k0 + 1, false);
-    rle3_summary_tile(sh, blk, k0, p0, tsum);
+    const Rle3Pre p0 = rle3_preload(blk, k0, true), p1 = rle3_preload(blk, k0 + 1, true);
+    rle3_first_tile(sh, blk, k0, p0, tsum, Tarr);
     if ((u32)(k0 + 1) < blk.n_tiles) {
         lds_barrier();
-        rle3_summary_tile(sh, blk, k0 + 1, p1, tsum);
+        rle3_first_tile(sh, blk, k0 + 1, p1, tsum, Tarr);
     }
 }
 
@@ -429,7 +484,7 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_offsets(const RleBlk *__rest
     __syncthreads();
     for (u32 t0 = 0; t0 < blk.n_tiles; t0 += RLE_THREADS) {
         const u32 t = t0 + tid;
-        const u64 cnt = t < blk.n_tiles ? (u64)T[blk.desc_base + t] : 0ull;
+        const u64 cnt = t < blk.n_tiles ? (u64)(T[blk.desc_base + t] & T_SIZE) : 0ull;     // flags of rle3_first masked off
         const u64 incl = wave_incl_scan_add<u64>(cnt);
         if (lane == 63) wtot[wv] = incl;
         __syncthreads();
@@ -594,6 +649,34 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_pass(const RleBlk *__restric
     }
 }
 
+// Sizes of the tiles that rle3_first left to the general code: one workgroup looks at 64 tiles' flags (almost none set)
+__global__ __launch_bounds__(RLE_THREADS) void rle3_fix(const RleBlk *__restrict__ blks, const u32 *__restrict__ Rarr,
+                                                        u32 *__restrict__ Tarr)
+{
+    __shared__ __attribute__((aligned(16))) RleShared sh;
+    __shared__ u64 todo;
+    const RleBlk blk = blks[blockIdx.y];
+    const u32 k0 = blockIdx.x * 64u;
+    if (k0 >= blk.n_tiles) return;
+    if (threadIdx.x < 64) {
+        const u32 k = k0 + threadIdx.x;
+        bool need = false;
+        if (k < blk.n_tiles) {
+            const u32 t = Tarr[blk.desc_base + k];
+            need = (t & T_GENERAL) != 0 || ((t & T_ENTERS) != 0 && Rarr[blk.desc_base + k] >= 60);
+        }
+        const u64 m = __ballot(need);
+        if (threadIdx.x == 0) todo = m;
+    }
+    __syncthreads();
+    for (u64 m = todo; m; m &= m - 1) {                 // uniform
+        const int k = (int)k0 + __builtin_ctzll((unsigned long long)m);
+        const Rle3Pre pre = rle3_preload(blk, k, true);
+        __syncthreads();
+        rle3_pass_tile<1>(sh, blk, k, pre, Rarr[blk.desc_base + k], 0ull, Tarr);
+    }
+}
+
 }  // namespace
 
 int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
@@ -644,9 +727,9 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
         const dim3 grid_t((max_tiles + 1) / 2, (u32)nblocks), grid_b((u32)nblocks);     // two tiles per workgroup
         u32 *tsum = (u32 *)(ws + o_tsum), *Rr = (u32 *)(ws + o_R), *Tt = (u32 *)(ws + o_T);
         u64 *Gg = (u64 *)(ws + o_sum);
-        hipLaunchKernelGGL(rle3_summary, grid_t, dim3(RLE_THREADS), 0, st, dblk, tsum);
+        hipLaunchKernelGGL(rle3_first, grid_t, dim3(RLE_THREADS), 0, st, dblk, tsum, Tt);
         hipLaunchKernelGGL(rle3_carry, grid_b, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)tsum, Rr);
-        hipLaunchKernelGGL(rle3_pass<1>, grid_t, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Rr, Tt, (const u64 *)Gg);
+        hipLaunchKernelGGL(rle3_fix, dim3((max_tiles + 63) / 64, (u32)nblocks), dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Rr, Tt);
         hipLaunchKernelGGL(rle3_offsets, grid_b, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Tt, Gg);
         hipLaunchKernelGGL(rle3_pass<2>, grid_t, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Rr, Tt, (const u64 *)Gg);
         HIP_TRY(hipGetLastError());

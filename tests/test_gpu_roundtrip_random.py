@@ -71,3 +71,40 @@ def test_random_round_trips(oracle, shafa, seed):
                 bad.append(f"seed {seed} block {i} n={b.size}: rle_decode {first_diff(back, b)}")
     shafa.set_option("sf_decode_speculate", 1)
     assert not bad, "\n".join(bad[:12])
+
+
+def test_rle_encode_many_blocks_per_launch(oracle, shafa):
+    """A launch of many multi-tile blocks, repeated: every block's RLE bytes and fused histogram against the oracle
+    (a missing barrier in the first pass once showed only here, in one block of 32, one launch in three)."""
+    import torch
+    import golden.make_golden as mg
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    nb, bs = 32, 4 << 20
+    zt = shafa.zipf_table(1.2)
+    blocks = [mg.runs_stream(70 + (b % 4), bs, zt) for b in range(4)]
+    want = [oracle.rle_encode(x) for x in blocks]
+    wfreq = [oracle.hist256(w) for w in want]
+    d_in = torch.cat([torch.from_numpy(blocks[b % 4]) for b in range(nb)]).to(dev)
+    rcap = 2 * bs + 64
+    d_rle = torch.empty(nb * rcap, dtype=torch.uint8, device=dev)
+    d_n = torch.zeros(nb, dtype=torch.int64, device=dev)
+    d_freq = torch.zeros(nb * 256, dtype=torch.int64, device=dev)
+    bt = shafa.Batch(nb, rcap)
+    bad = []
+    for it in range(6):
+        torch.cuda.synchronize()
+        bt.rle_encode(st, d_in, [b * bs for b in range(nb)], [bs] * nb, d_rle, [b * rcap for b in range(nb)], [rcap] * nb, d_n, d_freq)
+        bt.finish(st, nb)
+        ns = d_n.cpu().numpy()
+        fr = d_freq.cpu().numpy().reshape(nb, 256)
+        out = d_rle.cpu().numpy()
+        for b in range(nb):
+            w = want[b % 4]
+            got = out[b * rcap:b * rcap + int(ns[b])]
+            if got.size != w.size or got.tobytes() != w.tobytes():
+                bad.append(f"launch {it} block {b}: {first_diff(got, w)}")
+            elif not (fr[b] == wfreq[b % 4]).all():
+                bad.append(f"launch {it} block {b}: histogram of the RLE bytes differs")
+    bt.close()
+    assert not bad, "\n".join(bad[:10])
