@@ -212,7 +212,7 @@ int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u3
 // many chains (<= ~10 workgroups per block) a tile's look-back stays inside one 64-entry descriptor window.  Measured
 // on 64 MiB Zipf blocks, GiB/s one-pass vs count/scan/pack: 16 blocks 588 / 1240, 32: 1112 / 1298, 64: 1407 / 1457,
 // 128: 1900 / 1632 (sf_encode4.hip).
-static int g_sfe4_min_blocks = 96;
+static int g_sfe4_min_blocks = 80;
 void sfenc_configure(int sfe4_min_blocks) { g_sfe4_min_blocks = sfe4_min_blocks; }
 
 static u32 code_value(const shafa_code_table &t, int s)

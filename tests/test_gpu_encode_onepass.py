@@ -14,7 +14,7 @@ def one_pass(shafa):
     shafa.lib().shafa_hip_init(0)
     shafa.set_option("sf_encode_one_pass_min_blocks", 1)
     yield
-    shafa.set_option("sf_encode_one_pass_min_blocks", 96)
+    shafa.set_option("sf_encode_one_pass_min_blocks", 80)
 
 
 def run_batch(shafa, oracle, blocks, tables, caps=None, expect_err=None):
@@ -88,7 +88,7 @@ def test_one_pass_matches_oracle_ragged_sizes(shafa, oracle, one_pass):
 
 
 def test_one_pass_and_three_kernel_agree_on_a_big_launch(shafa, oracle):
-    """128 blocks of 0.5 MiB + ragged tails through the default dispatch (one pass: >= 96 blocks)."""
+    """128 blocks of 0.5 MiB + ragged tails through the default dispatch (one pass: >= 80 blocks)."""
     sizes = [(1 << 19) + 13 * i for i in range(128)]
     blocks, tables = zipf_blocks(shafa, oracle, sizes, seed0=500)
     shafa.lib().shafa_hip_init(0)
@@ -97,7 +97,7 @@ def test_one_pass_and_three_kernel_agree_on_a_big_launch(shafa, oracle):
     try:
         run_batch(shafa, oracle, blocks, tables)
     finally:
-        shafa.set_option("sf_encode_one_pass_min_blocks", 96)
+        shafa.set_option("sf_encode_one_pass_min_blocks", 80)
 
 
 @pytest.mark.parametrize("kind", ["uniform", "two", "few", "lmax16", "lmax13", "single_long_chain"])
