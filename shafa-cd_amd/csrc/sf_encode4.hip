@@ -366,6 +366,11 @@ __global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *
             lds_barrier();                                                             // A
             E4_T(3);
             const u32 n3 = sh.tick;
+            // waves 1..3 store the resolved tile's window FIRST: their next use of a loaded register (the input rotation in
+            // the next iteration) has to wait for these stores, so they go out as early as the iteration allows
+            if (wv != 0 && have_p)
+                store_window(pwin, bp->out, bp->out_cap, bp->err, sh.prefix, p_T, !ragged && p_tile == nfull - 1, tid - 64,
+                             E4_THREADS - 64);
             u32 c_T = 0;
             if (cur_ok) {
                 u32 roff[4];
@@ -388,9 +393,6 @@ __global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *
                     first_w = desc_load(bdesc + (idx > 0 ? idx : 0));
                     if (lane < 32) pv_w = gload_off<u8>(in + (u64)q_tile * E4_TILE - 32, 31u - (u32)lane);
                 }
-            } else if (have_p) {                       // waves 1..3 store the resolved tile's window
-                store_window(pwin, bp->out, bp->out_cap, bp->err, sh.prefix, p_T, !ragged && p_tile == nfull - 1, tid - 64,
-                             E4_THREADS - 64);
             }
             E4_T(5);
             lds_barrier();                                                             // B
