@@ -43,6 +43,9 @@ constexpr int LUT2_MAX = 4096;                     // level-2 entries kept in LD
 constexpr int SPEC_MINW = 1;                       // narrowest window of the counting table of sfd_spec (1 = the longest code's
                                                    // length; measured on Lmax = 10 data: 11 bits no gain, 12 bits 3 % slower:
                                                    // fewer steps, but an 8 KiB table costs two workgroups per CU)
+constexpr int SYM3_MINW = 1;                       // narrowest window of the three-symbols table of sfd_wstage (1 = the longest
+                                                   // code; 12 on Lmax = 10 data: 14 % fewer look-ups, but a 16 KiB table leaves
+                                                   // four workgroups per CU instead of six: decode 10.1 -> 11.1 ms)
 constexpr int SYM3_MAXK = 12;                      // widest window of the three-codes table of sfd_wstage: 16 KiB
 constexpr int LDS_DATA = (DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
 constexpr int LONG_PFX = 128;                      // codes longer than SYM3_MAXK bits, grouped by their first SYM3_MAXK bits
@@ -84,6 +87,12 @@ struct DecBlk {
 
 // window of the code-counting table of sfd_spec: wider than the longest code when that is short (more bits per look-up)
 __host__ __device__ __forceinline__ u32 spec_window(u32 K1) { return K1 < (u32)SPEC_MINW ? (u32)SPEC_MINW : K1; }
+// window of the three-symbols table of sfd_wstage
+__host__ __device__ __forceinline__ u32 sym3_window(u32 K1)
+{
+    const u32 k = K1 < (u32)SYM3_MINW ? (u32)SYM3_MINW : K1;
+    return k < (u32)SYM3_MAXK ? k : (u32)SYM3_MAXK;
+}
 
 // the exact kernels of a launch that also runs the speculative ones: skip the blocks that verified
 __device__ __forceinline__ bool dp_skipped(const DecBlk &blk)
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
     const u32 K1 = blk.K1, mask = (1u << K1) - 1;
     for (u32 i = threadIdx.x; blk.pairlut && i < (2u << K1); i += DEC_THREADS)
         blk.pairlut[i] = (u8)((blk.lenlut[i >> 1] - 1u) | ((blk.lenlut[i & mask] - 1u) << 4));
-    const u32 K3 = K1 < (u32)SYM3_MAXK ? K1 : (u32)SYM3_MAXK;
+    const u32 K3 = sym3_window(K1);
     const u32 KW = spec_window(K1), maskw = (1u << KW) - 1;      // the counting window may be wider than the longest code
     for (u32 i = threadIdx.x; i <= maskw; i += DEC_THREADS) {
         u32 pos = 0, n = 0, l0 = 0;
@@ -393,7 +402,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
     for (u32 i = threadIdx.x; i < (1u << K3); i += DEC_THREADS) {   // K3-bit window; n = 0: first code is longer
         u32 pos = 0, n = 0, syms = 0;
         for (; n < 3; ++n) {
-            const u32 e = blk.lut13[((i << (K1 - K3)) << pos) & mask];
+            const u32 e = blk.lut13[K3 >= K1 ? (((i << pos) & ((1u << K3) - 1u)) >> (K3 - K1)) : (((i << (K1 - K3)) << pos) & mask)];
             const u32 L = e >> 8;
             if (L == 0 || L > K3 - pos) break;
             syms |= (e & 0xFFu) << (8 * n);
@@ -1515,7 +1524,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
     u32 *wsum = dump + DEC_THREADS;
     u32 *next = wsum + 4;
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 K1 = blk.K1, K3 = K1 < (u32)SYM3_MAXK ? K1 : (u32)SYM3_MAXK;
+    const u32 K1 = blk.K1, K3 = sym3_window(K1);
     const u32 sh = 32 - K1, sh3 = 32 - K3;
     fill_lds16(smem + tab_off, (const void *)blk.sym3, 4u << K3);
     if (LONG) {
@@ -2237,7 +2246,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
                        (u64 *)(ws + o_toff));
     u32 ws_tab = 16;                                   // sym3 bytes of the widest table of the launch
     for (int b = 0; b < nblocks; ++b) {
-        const u32 k3 = tabs[b].K1 < (u32)SYM3_MAXK ? tabs[b].K1 : (u32)SYM3_MAXK;
+        const u32 k3 = sym3_window(tabs[b].K1);
         if ((4u << k3) > ws_tab) ws_tab = 4u << k3;
     }
     // image: the densest block's average symbols per tile + 1/8 + 1 KiB, 4 .. 40 KiB
