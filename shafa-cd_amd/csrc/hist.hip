@@ -33,18 +33,27 @@ __global__ __launch_bounds__(HIST_THREADS) void hist256_kernel(const HistBlk *__
     __syncthreads();
 
     const u32 rep = tid & (HIST_REP - 1);
-    for (u64 p = start + (u64)tid * 16; p < end; p += HIST_THREADS * 16) {
-        if (p + 16 <= end) {
-            const uint4 v = *(const uint4 *)(blk.in + p);
-            const u32 w[4] = {v.x, v.y, v.z, v.w};
+    auto count16 = [&](const uint4 v) {
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const u32 sym = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                atomicAdd(&h[sym * HIST_REP + rep], 1u);
-            }
-        } else {
-            for (u64 q = p; q < end; ++q) atomicAdd(&h[(u32)blk.in[q] * HIST_REP + rep], 1u);
+        for (int j = 0; j < 16; ++j) {
+            const u32 sym = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            atomicAdd(&h[sym * HIST_REP + rep], 1u);
         }
+    };
+    constexpr u64 STEP = (u64)HIST_THREADS * 16;
+    u64 p = start + (u64)tid * 16;
+    for (; p + 3 * STEP + 16 <= end; p += 4 * STEP) {   // four loads in flight per lane
+        const uint4 v0 = gload_nt<uint4>(blk.in + p), v1 = gload_nt<uint4>(blk.in + p + STEP);
+        const uint4 v2 = gload_nt<uint4>(blk.in + p + 2 * STEP), v3 = gload_nt<uint4>(blk.in + p + 3 * STEP);
+        count16(v0);
+        count16(v1);
+        count16(v2);
+        count16(v3);
+    }
+    for (; p < end; p += STEP) {
+        if (p + 16 <= end) count16(*(const uint4 *)(blk.in + p));
+        else for (u64 q = p; q < end; ++q) atomicAdd(&h[(u32)blk.in[q] * HIST_REP + rep], 1u);
     }
     __syncthreads();
     u32 c = 0;
