@@ -423,14 +423,20 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_first(const RleBlk *__restri
 {
     __shared__ __attribute__((aligned(16))) RleShared sh;
     const RleBlk blk = blks[blockIdx.y];
-    const int k0 = 2 * (int)blockIdx.x;                 // two tiles per workgroup, both loaded up front
+    const int k0 = 4 * (int)blockIdx.x;                 // four tiles per workgroup, all loaded up front (no stores here)
     if ((u32)k0 >= blk.n_tiles) return;
     const Rle3Pre p0 = rle3_preload(blk, k0, true), p1 = rle3_preload(blk, k0 + 1, true);
+    const Rle3Pre p2 = rle3_preload(blk, k0 + 2, true), p3 = rle3_preload(blk, k0 + 3, true);
     rle3_first_tile(sh, blk, k0, p0, tsum, Tarr);
-    if ((u32)(k0 + 1) < blk.n_tiles) {
-        lds_barrier();
-        rle3_first_tile(sh, blk, k0 + 1, p1, tsum, Tarr);
-    }
+    if ((u32)(k0 + 1) >= blk.n_tiles) return;
+    lds_barrier();
+    rle3_first_tile(sh, blk, k0 + 1, p1, tsum, Tarr);
+    if ((u32)(k0 + 2) >= blk.n_tiles) return;
+    lds_barrier();
+    rle3_first_tile(sh, blk, k0 + 2, p2, tsum, Tarr);
+    if ((u32)(k0 + 3) >= blk.n_tiles) return;
+    lds_barrier();
+    rle3_first_tile(sh, blk, k0 + 3, p3, tsum, Tarr);
 }
 
 // R[t] = length of the run that ends at the last byte of tile t - 1
@@ -727,7 +733,7 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
         const dim3 grid_t((max_tiles + 1) / 2, (u32)nblocks), grid_b((u32)nblocks);     // two tiles per workgroup
         u32 *tsum = (u32 *)(ws + o_tsum), *Rr = (u32 *)(ws + o_R), *Tt = (u32 *)(ws + o_T);
         u64 *Gg = (u64 *)(ws + o_sum);
-        hipLaunchKernelGGL(rle3_first, grid_t, dim3(RLE_THREADS), 0, st, dblk, tsum, Tt);
+        hipLaunchKernelGGL(rle3_first, dim3((max_tiles + 3) / 4, (u32)nblocks), dim3(RLE_THREADS), 0, st, dblk, tsum, Tt);
         hipLaunchKernelGGL(rle3_carry, grid_b, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)tsum, Rr);
         hipLaunchKernelGGL(rle3_fix, dim3((max_tiles + 63) / 64, (u32)nblocks), dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Rr, Tt);
         hipLaunchKernelGGL(rle3_offsets, grid_b, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Tt, Gg);
