@@ -636,22 +636,222 @@ __device__ __forceinline__ void rle3_pass_tile(RleShared &sh, const RleBlk &blk,
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(RLE_THREADS) void rle3_pass(const RleBlk *__restrict__ blks, const u32 *__restrict__ Rarr,
+// ================================================================================================
+// rle3_emit: the emit pass on PAIRS of tiles.  When the pair (8 KiB) is full, at most two 32-byte lanes of a wave lie
+// wholly inside a run and the run that enters is shorter than 60 bytes (no run can reach 255 bytes inside the pair), the
+// mask code runs on 32 bytes per lane — half the scans, ballots and flush bookkeeping per byte of the 16-byte code:
+// E / Z masks, runs of >= 4 from three consecutive E bits, per-byte sizes by SWAR, literals as byte writes at running
+// positions, the symbol of a triple written by the same loop, {0, length} by a loop over the lane's triple heads, the
+// image aligned like the output address, aligned non-temporal 16-byte stores.  Otherwise the two tiles take
+// rle3_pass_tile<2> one after the other.
+// ================================================================================================
+constexpr int R8_BPL = 32;
+constexpr int R8_TILE = RLE_THREADS * R8_BPL;      // a pair of tiles
+constexpr int R8_IMG = 2 * R8_TILE + 64;           // the mask code emits at most two bytes per byte; + alignment shift
+
+struct R8Fast {
+    u8 img[R8_IMG];
+    u32 E[RLE_THREADS + 2];        // E masks of the lanes; [0] bits 29..31: the three bytes before the pair, [257] bits 0..2: after
+    u32 dump[RLE_THREADS];
+    u32 wsum[4];
+    u32 wfirst[4];                 // bytes from the start of a wave to its first run head
+    u32 wlast[4];                  // last byte of each wave
+    u32 slow;
+    u32 H;                         // bytes after the pair equal to its last byte (<= 255)
+};
+union R8Shared {
+    RleShared gen;
+    R8Fast f;
+};
+
+// 4-bit mask of the zero bytes of d (exact)
+__device__ __forceinline__ u32 zmask4(u32 d)
+{
+    const u32 t = ((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d;
+    const u32 f = (~t >> 7) & 0x01010101u;
+    return ((__umul24(f, 0x00204081u) >> 21) & 7u) | ((f >> 21) & 8u);
+}
+
+__device__ __forceinline__ bool rle3_emit8k(R8Fast &sh, const RleBlk &blk, const int kp, const u32 Rin, const u64 G)
+{
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const u64 n = blk.n;
+    const u64 tile_start = (u64)kp * R8_TILE, tile_end = tile_start + R8_TILE;
+    if (tile_end + 4 > n) return false;                // ragged / last pair (uniform)
+    u8 *smem = (u8 *)&sh;
+    const u64 pos = tile_start + (u64)tid * R8_BPL;
+    u32 w[8];
+    {
+        const uint4 v0 = gload_nt<uint4>(blk.in + pos), v1 = gload_nt<uint4>(blk.in + pos + 16);
+        w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
+    }
+    // everything else the pair needs from memory is requested now as well
+    u32 hq[4] = {0x400u, 0x400u, 0x400u, 0x400u};      // wave 2: bytes tile_end + 4 lane + 0..3 (0x400 past the block)
+    u32 qb = 0, qa = 0;
+    if (wv == 2) {
+        const u64 q = tile_end + (u64)lane * 4;
+        if (q + 4 <= n) {
+            const u32 v = *(const u32 *)(blk.in + q);
+            hq[0] = v & 0xFFu; hq[1] = (v >> 8) & 0xFFu; hq[2] = (v >> 16) & 0xFFu; hq[3] = v >> 24;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (q + j < n) hq[j] = (u32)blk.in[q + j];
+        }
+    }
+    if (tid == 0 && kp > 0) qb = *(const u32 *)(blk.in + tile_start - 4);          // bytes -4 .. -1
+    if (tid == RLE_THREADS - 1) qa = *(const u32 *)(blk.in + tile_end);            // the four bytes after the pair
+    if (lane == 63) sh.wlast[wv] = w[7] >> 24;
+    u32 pb0 = 0x100u;                                  // lane 0: the byte before the pair (0x100: none)
+    if (tid == 0) {
+        u32 e0 = 0;
+        if (kp > 0) {
+            e0 = (zmask4(qb ^ (qb << 8)) >> 1) << 29;  // E of positions -3, -2, -1 in bits 29..31
+            pb0 = qb >> 24;
+        }
+        sh.E[0] = e0;
+        sh.slow = 0;
+    }
+    if (tid == RLE_THREADS - 1) sh.E[RLE_THREADS + 1] = zmask4(qa ^ ((qa << 8) | (w[7] >> 24))) & 7u;
+    lds_barrier();
+    u32 pb = (u32)__shfl_up((int)(w[7] >> 24), 1, 64);
+    if (lane == 0) pb = wv ? sh.wlast[wv - 1] : pb0;
+    u32 E = zmask4(w[0] ^ ((w[0] << 8) | (pb & 0xFFu))), Z = zmask4(w[0]);
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        E |= zmask4(w[i] ^ __builtin_amdgcn_alignbit(w[i], w[i - 1], 24)) << (4 * i);
+        Z |= zmask4(w[i]) << (4 * i);
+    }
+    if (pb > 0xFFu) E &= ~1u;
+    sh.E[tid + 1] = E;
+    const u32 H = ~E;                                   // run heads
+    const u64 hm = __ballot(H != 0);
+    {
+        // lanes wholly inside a run: more than two in a wave and a run could reach 255 bytes here
+        const u32 transparent = (u32)__builtin_popcountll((unsigned long long)__ballot(E == 0xFFFFFFFFu));
+        const bool enters = wv == 0 && (__shfl((int)E, 0, 64) & 1) != 0;
+        if (lane == 0 && (transparent > 2 || (enters && Rin >= 60))) sh.slow = 1;
+        if (hm) {
+            const int l0 = __builtin_ctzll((unsigned long long)hm);
+            const u32 h0 = (u32)__shfl((int)H, l0, 64);
+            if (lane == 0) sh.wfirst[wv] = 32u * (u32)l0 + (u32)__builtin_ctz(h0);
+        }
+        if (wv == 2) {                                  // halo: bytes after the pair equal to its last byte (<= 255)
+            const u32 lastb = sh.wlast[3];
+            u32 cnt = 0;
+            bool go = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                go &= (hq[j] == lastb);
+                cnt += go ? 1u : 0u;
+            }
+            const u64 full = __ballot(cnt == 4);
+            const int f0 = (~full) ? (__ffsll((unsigned long long)~full) - 1) : 64;
+            const u32 c0 = (f0 < 64) ? (u32)__shfl((int)cnt, f0, 64) : 0u;
+            u32 Hh = (u32)f0 * 4 + c0;
+            if (Hh > 255) Hh = 255;
+            if (lane == 0) sh.H = Hh;
+        }
+    }
+    lds_barrier();
+    if (sh.slow) return false;
+
+    // ---- classification: bytes of runs of >= 4, literals, triple heads ----------------------------------------
+    const u64 B = (u64)(sh.E[tid] >> 29) | ((u64)E << 3) | ((u64)(sh.E[tid + 2] & 7u) << 35);   // positions -3 .. 34
+    const u64 T = B & (B >> 1) & (B >> 2);
+    const u32 LC = (u32)(((T >> 1) | T | (T << 1) | (T << 2)) >> 3);
+    const u32 Lit = ~Z & ~LC;
+    const u32 T3 = H & (Z | LC);
+    const u32 tot = (u32)__builtin_popcount(Lit) + 3u * (u32)__builtin_popcount(T3);
+    const u32 incl = wave_incl_scan_add<u32>(tot);
+    if (lane == 63) sh.wsum[wv] = incl;
+    // bytes from the end of this lane to the next run head (for the count of a run that leaves the lane)
+    u32 after;
+    {
+        const u64 above = lane == 63 ? 0ull : hm & ~((2ull << lane) - 1);
+        const int l2 = above ? __builtin_ctzll((unsigned long long)above) : 0;
+        const u32 hv = (u32)__shfl((int)H, l2, 64);
+        after = above ? 32u * (u32)(l2 - lane - 1) + (u32)__builtin_ctz(hv) : 0xFFFFFFFFu;
+    }
+    lds_barrier();
+    u32 run = 0, off = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q == wv) off = run + incl - tot;
+        run += sh.wsum[q];
+    }
+    const u32 Tt = run;
+    if (after == 0xFFFFFFFFu) after = 32u * (u32)(63 - lane) + (wv < 3 ? sh.wfirst[wv + 1] : sh.H);
+
+    // ---- tokens into the image, which is aligned like the output address ---------------------------------------
+    const u32 shift = (u32)((uintptr_t)(blk.out + G) & 15u);
+    const u32 p0 = (u32)offsetof(R8Fast, img) + shift + off;
+    {   // every byte is written somewhere, no branches: a literal at the running position, the symbol of a triple in the
+        // triple's second place, a byte that emits nothing into the lane's dump word
+        u32 p = p0;
+        const u32 dump = (u32)offsetof(R8Fast, dump) + 4u * (u32)tid;
+#pragma unroll
+        for (int q = 0; q < R8_BPL / 4; ++q) {
+            const u32 ft = nibf(T3, q), sz = nibf(Lit, q) | ft | (ft << 1);      // per byte: 1 at a literal, 3 at a triple head
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const u32 at = (Lit >> (4 * q + c)) & 1u ? p : ((T3 >> (4 * q + c)) & 1u ? p + 1 : dump);
+                smem[at] = (u8)(w[q] >> (8 * c));
+                p += (sz >> (8 * c)) & 0xFFu;
+            }
+        }
+    }
+    for (u32 t = T3; t; t &= t - 1) {                   // triples: the lane's heads in order
+        const u32 j = (u32)__builtin_ctz(t), below = (1u << j) - 1u;
+        const u32 hn = j < 31 ? H >> (j + 1) : 0u;
+        u32 L = hn ? (u32)__builtin_ctz(hn) + 1u : (32u - j) + after;   // to the next head: in this lane / beyond it
+        L = L > 255u ? 255u : L;
+        const u32 at = p0 + (u32)__builtin_popcount(Lit & below) + 3u * (u32)__builtin_popcount(T3 & below);
+        smem[at] = 0;
+        smem[at + 2] = (u8)L;
+    }
+    lds_barrier();
+    const u64 end_b = G + Tt;
+    if (end_b > blk.out_cap) {
+        if (tid == 0) set_error(blk.err, SHAFA_LACK_OF_MEMORY);
+        return true;
+    }
+    u8 *gbase = blk.out + G - shift;                    // aligned 16-byte pieces, non-temporal
+    const u32 npieces = (shift + Tt + 15) >> 4;
+    for (u32 u = tid; u < npieces; u += RLE_THREADS) {
+        const uint4 v = ((const uint4 *)sh.img)[u];
+        const u32 lo = 16 * u;
+        if (lo >= shift && lo + 16 <= shift + Tt) {
+            gstore_nt<uint4>(gbase + lo, v);
+        } else {
+            const u32 wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (u32 q = 0; q < 16; ++q)
+                if (lo + q >= shift && lo + q < shift + Tt) gbase[lo + q] = (u8)(wds[q >> 2] >> (8 * (q & 3)));
+        }
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(RLE_THREADS) void rle3_emit(const RleBlk *__restrict__ blks, const u32 *__restrict__ Rarr,
                                                          u32 *__restrict__ Tarr, const u64 *__restrict__ Garr)
 {
-    __shared__ __attribute__((aligned(16))) RleShared sh;
+    __shared__ __attribute__((aligned(16))) R8Shared sh;
     const RleBlk blk = blks[blockIdx.y];
-    const int k0 = 2 * (int)blockIdx.x;                 // two tiles per workgroup, everything loaded up front
+    const int k0 = 2 * (int)blockIdx.x;
     if ((u32)k0 >= blk.n_tiles) return;
     const bool two = (u32)(k0 + 1) < blk.n_tiles;
+    const u32 R0 = Rarr[blk.desc_base + k0];
+    const u64 G0 = Garr[blk.desc_base + k0];
+    if (rle3_emit8k(sh.f, blk, (int)blockIdx.x, R0, G0)) return;
+    // the pair needs the 16-byte code (or the general code): tile by tile
+    lds_barrier();
     const Rle3Pre p0 = rle3_preload(blk, k0, true), p1 = rle3_preload(blk, k0 + 1, true);
-    const u32 R0 = Rarr[blk.desc_base + k0], R1 = two ? Rarr[blk.desc_base + k0 + 1] : 0u;
-    const u64 G0 = MODE == 2 ? Garr[blk.desc_base + k0] : 0ull, G1 = (MODE == 2 && two) ? Garr[blk.desc_base + k0 + 1] : 0ull;
-    rle3_pass_tile<MODE>(sh, blk, k0, p0, R0, G0, Tarr);
+    const u32 R1 = two ? Rarr[blk.desc_base + k0 + 1] : 0u;
+    const u64 G1 = two ? Garr[blk.desc_base + k0 + 1] : 0ull;
+    rle3_pass_tile<2>(sh.gen, blk, k0, p0, R0, G0, Tarr);
     if (two) {
         lds_barrier();
-        rle3_pass_tile<MODE>(sh, blk, k0 + 1, p1, R1, G1, Tarr);
+        rle3_pass_tile<2>(sh.gen, blk, k0 + 1, p1, R1, G1, Tarr);
     }
 }
 
@@ -737,7 +937,7 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
         hipLaunchKernelGGL(rle3_carry, grid_b, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)tsum, Rr);
         hipLaunchKernelGGL(rle3_fix, dim3((max_tiles + 63) / 64, (u32)nblocks), dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Rr, Tt);
         hipLaunchKernelGGL(rle3_offsets, grid_b, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Tt, Gg);
-        hipLaunchKernelGGL(rle3_pass<2>, grid_t, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Rr, Tt, (const u64 *)Gg);
+        hipLaunchKernelGGL(rle3_emit, grid_t, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Rr, Tt, (const u64 *)Gg);
         HIP_TRY(hipGetLastError());
     }
     if (d_freq) {   // make_freq of the RLE bytes (f.c:310): sizes are on the device
