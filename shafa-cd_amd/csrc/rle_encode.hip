@@ -419,26 +419,6 @@ __device__ __forceinline__ void rle3_first_tile(RleShared &sh, const RleBlk &blk
         Tarr[blk.desc_base + k] = slow ? T_GENERAL : ((sh.wsum[0] + sh.wsum[1] + sh.wsum[2] + sh.wsum[3]) | (enters ? T_ENTERS : 0u));
 }
 
-__global__ __launch_bounds__(RLE_THREADS) void rle3_first(const RleBlk *__restrict__ blks, u32 *__restrict__ tsum, u32 *__restrict__ Tarr)
-{
-    __shared__ __attribute__((aligned(16))) RleShared sh;
-    const RleBlk blk = blks[blockIdx.y];
-    const int k0 = 4 * (int)blockIdx.x;                 // four tiles per workgroup, all loaded up front (no stores here)
-    if ((u32)k0 >= blk.n_tiles) return;
-    const Rle3Pre p0 = rle3_preload(blk, k0, true), p1 = rle3_preload(blk, k0 + 1, true);
-    const Rle3Pre p2 = rle3_preload(blk, k0 + 2, true), p3 = rle3_preload(blk, k0 + 3, true);
-    rle3_first_tile(sh, blk, k0, p0, tsum, Tarr);
-    if ((u32)(k0 + 1) >= blk.n_tiles) return;
-    lds_barrier();
-    rle3_first_tile(sh, blk, k0 + 1, p1, tsum, Tarr);
-    if ((u32)(k0 + 2) >= blk.n_tiles) return;
-    lds_barrier();
-    rle3_first_tile(sh, blk, k0 + 2, p2, tsum, Tarr);
-    if ((u32)(k0 + 3) >= blk.n_tiles) return;
-    lds_barrier();
-    rle3_first_tile(sh, blk, k0 + 3, p3, tsum, Tarr);
-}
-
 // R[t] = length of the run that ends at the last byte of tile t - 1
 __global__ __launch_bounds__(RLE_THREADS) void rle3_carry(const RleBlk *__restrict__ blks, const u32 *__restrict__ tsum,
                                                           u32 *__restrict__ R)
@@ -852,6 +832,120 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_emit(const RleBlk *__restric
     if (two) {
         lds_barrier();
         rle3_pass_tile<2>(sh.gen, blk, k0 + 1, p1, R1, G1, Tarr);
+    }
+}
+
+// the first pass on a pair of tiles, 32 bytes per lane: both tiles' run summaries and mask-code sizes (same validity rule
+// as rle3_emit8k, minus the entering run, which is not known yet: that is what T_ENTERS is for)
+struct R8In {
+    u32 w[8];
+    u32 qb, qa;
+    bool full;
+};
+__device__ __forceinline__ R8In rle3_preload8k(const RleBlk &blk, const int kp)
+{
+    R8In p;
+    const u64 tile_start = (u64)kp * R8_TILE, tile_end = tile_start + R8_TILE;
+    p.full = tile_end + 4 <= blk.n;                     // uniform
+    p.qb = p.qa = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p.w[i] = 0;
+    if (p.full) {
+        const u64 pos = tile_start + (u64)threadIdx.x * R8_BPL;
+        const uint4 v0 = gload_nt<uint4>(blk.in + pos), v1 = gload_nt<uint4>(blk.in + pos + 16);
+        p.w[0] = v0.x; p.w[1] = v0.y; p.w[2] = v0.z; p.w[3] = v0.w; p.w[4] = v1.x; p.w[5] = v1.y; p.w[6] = v1.z; p.w[7] = v1.w;
+        if (threadIdx.x == 0 && kp > 0) p.qb = *(const u32 *)(blk.in + tile_start - 4);
+        if (threadIdx.x == RLE_THREADS - 1) p.qa = *(const u32 *)(blk.in + tile_end);
+    }
+    return p;
+}
+
+__device__ __forceinline__ bool rle3_first8k(R8Fast &sh, const RleBlk &blk, const int kp, const R8In &in, u32 *__restrict__ tsum,
+                                             u32 *__restrict__ Tarr)
+{
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    if (!in.full) return false;                         // uniform
+    const u32 *w = in.w;
+    if (lane == 63) sh.wlast[wv] = w[7] >> 24;
+    u32 pb0 = 0x100u;
+    if (tid == 0) {
+        u32 e0 = 0;
+        if (kp > 0) {
+            e0 = (zmask4(in.qb ^ (in.qb << 8)) >> 1) << 29;
+            pb0 = in.qb >> 24;
+        }
+        sh.E[0] = e0;
+        sh.slow = 0;
+    }
+    if (tid == RLE_THREADS - 1) sh.E[RLE_THREADS + 1] = zmask4(in.qa ^ ((in.qa << 8) | (w[7] >> 24))) & 7u;
+    lds_barrier();
+    u32 pb = (u32)__shfl_up((int)(w[7] >> 24), 1, 64);
+    if (lane == 0) pb = wv ? sh.wlast[wv - 1] : pb0;
+    u32 E = zmask4(w[0] ^ ((w[0] << 8) | (pb & 0xFFu))), Z = zmask4(w[0]);
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        E |= zmask4(w[i] ^ __builtin_amdgcn_alignbit(w[i], w[i - 1], 24)) << (4 * i);
+        Z |= zmask4(w[i]) << (4 * i);
+    }
+    if (pb > 0xFFu) E &= ~1u;
+    sh.E[tid + 1] = E;
+    const u32 H = ~E;
+    const u64 hm = __ballot(H != 0);
+    const u32 transparent = (u32)__builtin_popcountll((unsigned long long)__ballot(E == 0xFFFFFFFFu));
+    if (lane == 0) {
+        if (transparent > 2) sh.slow = 1;
+        int last = -1;                                  // position of the wave's last run head inside its 4 KiB tile
+        if (hm) {
+            const int l = 63 - __builtin_clzll((unsigned long long)hm);
+            last = l;                                   // lane; its head position is added below
+        }
+        sh.wfirst[wv] = (u32)last;
+    }
+    {
+        const int l = hm ? 63 - __builtin_clzll((unsigned long long)hm) : 0;
+        const u32 hv = (u32)__shfl((int)H, l, 64);
+        if (lane == 0 && hm) sh.wfirst[wv] = (u32)(((wv & 1) * 64 + l) * R8_BPL + (31 - __builtin_clz(hv)));
+    }
+    lds_barrier();                                      // the neighbours' E masks, the waves' last heads and `slow` are in LDS
+    if (sh.slow) return false;
+    const u64 B = (u64)(sh.E[tid] >> 29) | ((u64)E << 3) | ((u64)(sh.E[tid + 2] & 7u) << 35);   // positions -3 .. 34
+    const u64 T = B & (B >> 1) & (B >> 2);
+    const u32 LC = (u32)(((T >> 1) | T | (T << 1) | (T << 2)) >> 3);
+    const u32 Lit = ~Z & ~LC;
+    const u32 T3 = H & (Z | LC);
+    const u32 wtot = wave_reduce_add<u32>((u32)__builtin_popcount(Lit) + 3u * (u32)__builtin_popcount(T3));
+    if (lane == 0) sh.wsum[wv] = wtot;
+    const bool ent0 = (sh.E[1] & 1u) != 0, ent1 = (sh.E[129] & 1u) != 0;
+    lds_barrier();
+    if (tid < 2) {                                      // thread t writes the summary and the size of tile 2 kp + t
+        const int k = 2 * kp + tid;
+        const int lp = (int)sh.wfirst[2 * tid + 1] >= 0 ? (int)sh.wfirst[2 * tid + 1] : (int)sh.wfirst[2 * tid];
+        tsum[blk.desc_base + k] = lp < 0 ? (0x80000000u | (u32)RLE_TILE) : (u32)(RLE_TILE - lp);
+        Tarr[blk.desc_base + k] = (sh.wsum[2 * tid] + sh.wsum[2 * tid + 1]) | ((tid ? ent1 : ent0) ? T_ENTERS : 0u);
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(RLE_THREADS) void rle3_first(const RleBlk *__restrict__ blks, u32 *__restrict__ tsum, u32 *__restrict__ Tarr)
+{
+    __shared__ __attribute__((aligned(16))) R8Shared sh;
+    const RleBlk blk = blks[blockIdx.y];
+    const int kp0 = 2 * (int)blockIdx.x;                // two pairs of tiles per workgroup, both loaded up front
+    if ((u32)(2 * kp0) >= blk.n_tiles) return;
+    const R8In a = rle3_preload8k(blk, kp0), b = rle3_preload8k(blk, kp0 + 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int kp = kp0 + i, k0 = 2 * kp;
+        if ((u32)k0 >= blk.n_tiles) break;
+        if (i) lds_barrier();
+        if (rle3_first8k(sh.f, blk, kp, i ? b : a, tsum, Tarr)) continue;
+        lds_barrier();                                  // the pair takes the 16-byte code, tile by tile
+        const Rle3Pre p0 = rle3_preload(blk, k0, true), p1 = rle3_preload(blk, k0 + 1, true);
+        rle3_first_tile(sh.gen, blk, k0, p0, tsum, Tarr);
+        if ((u32)(k0 + 1) < blk.n_tiles) {
+            lds_barrier();
+            rle3_first_tile(sh.gen, blk, k0 + 1, p1, tsum, Tarr);
+        }
     }
 }
 
