@@ -428,10 +428,12 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_carry(const RleBlk *__restri
     const RleBlk blk = blks[blockIdx.x];
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     if (tid == 0) carry = Seg{0u, 0u};
-    __syncthreads();
+    lds_barrier();
+    u32 xn = (u32)tid < blk.n_tiles ? tsum[blk.desc_base + tid] : 0u;     // one iteration ahead
     for (u32 t0 = 0; t0 < blk.n_tiles; t0 += RLE_THREADS) {
         const u32 t = t0 + tid;
-        const u32 x = t < blk.n_tiles ? tsum[blk.desc_base + t] : 0u;
+        const u32 x = xn;
+        xn = t + RLE_THREADS < blk.n_tiles ? tsum[blk.desc_base + t + RLE_THREADS] : 0u;
         Seg f = Seg{x >> 31, x & 0x7FFFFFFFu};
         const Seg own = f;
 #pragma unroll
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_carry(const RleBlk *__restri
             if (lane >= d) f = comb_f(y, f);
         }
         if (lane == 63) wtot[wv] = f;
-        __syncthreads();
+        lds_barrier();
         Seg pre = carry;                                // everything before this wave
         for (int ww = 0; ww < wv; ++ww) pre = comb_f(pre, wtot[ww]);
         // exclusive value = run ending just before tile t
@@ -449,13 +451,13 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_carry(const RleBlk *__restri
         const Seg before = comb_f(pre, ex);
         (void)own;
         if (t < blk.n_tiles) R[blk.desc_base + t] = before.v;
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) {
             Seg c2 = carry;
             for (int ww = 0; ww < 4; ++ww) c2 = comb_f(c2, wtot[ww]);
             carry = c2;
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -467,19 +469,21 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_offsets(const RleBlk *__rest
     const RleBlk blk = blks[blockIdx.x];
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) carry = 0;
-    __syncthreads();
+    lds_barrier();
+    u32 tn = tid < blk.n_tiles ? T[blk.desc_base + tid] : 0u;             // one iteration ahead
     for (u32 t0 = 0; t0 < blk.n_tiles; t0 += RLE_THREADS) {
         const u32 t = t0 + tid;
-        const u64 cnt = t < blk.n_tiles ? (u64)(T[blk.desc_base + t] & T_SIZE) : 0ull;     // flags of rle3_first masked off
+        const u64 cnt = (u64)(tn & T_SIZE);             // flags of rle3_first masked off
+        tn = t + RLE_THREADS < blk.n_tiles ? T[blk.desc_base + t + RLE_THREADS] : 0u;
         const u64 incl = wave_incl_scan_add<u64>(cnt);
         if (lane == 63) wtot[wv] = incl;
-        __syncthreads();
+        lds_barrier();
         u64 base = carry;
         for (u32 ww = 0; ww < wv; ++ww) base += wtot[ww];
         if (t < blk.n_tiles) G[blk.desc_base + t] = base + incl - cnt;
-        __syncthreads();
+        lds_barrier();
         if (tid == 0) carry += wtot[0] + wtot[1] + wtot[2] + wtot[3];
-        __syncthreads();
+        lds_barrier();
     }
     if (tid == 0) *blk.out_n = carry;
 }
