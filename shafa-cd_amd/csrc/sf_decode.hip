@@ -1253,15 +1253,25 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 K1 = spec_window(blk.K1);                 // the counting table's window
     fill_lds16((void *)(smem + tab_off), (const void *)blk.cnt3, 2u << K1);
-    {   // the region's stream from one strip before it, 16 bytes a lane; frame word f -> LDS word f + f / SPEC_SW
+    {   // the region's stream from one strip before it, 16 bytes a lane; frame word f -> LDS word f + f / SPEC_SW.
+        // All of a lane's pieces are requested before the first is used (five loads in flight, not five round trips).
         const long long base = (long long)tile0 * DTILE - 4 * SPEC_SW;
-        for (u32 i = tid; i < (u32)(SPEC_STRIPS * SPEC_SW / 4 + 1); i += DEC_THREADS) {
+        constexpr u32 UNITS = (u32)(SPEC_STRIPS * SPEC_SW / 4 + 1), NIT = (UNITS + DEC_THREADS - 1) / DEC_THREADS;
+        uint4 v[NIT];
+#pragma unroll
+        for (u32 it = 0; it < NIT; ++it) {
+            const u32 i = tid + it * DEC_THREADS;
             const long long off = base + (long long)i * 16;
-            u32 w[4] = {0, 0, 0, 0};
-            if (off >= 0 && (u64)off + 16 <= blk.in_n) {
-                const uint4 v = gload<uint4>(blk.in + off);
-                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            } else if (off >= 0 && (u64)off < blk.in_n) {
+            v[it] = make_uint4(0, 0, 0, 0);
+            if (i < UNITS && off >= 0 && (u64)off + 16 <= blk.in_n) v[it] = gload<uint4>(blk.in + off);
+        }
+#pragma unroll
+        for (u32 it = 0; it < NIT; ++it) {
+            const u32 i = tid + it * DEC_THREADS;
+            if (i >= UNITS) break;
+            const long long off = base + (long long)i * 16;
+            u32 w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+            if (off >= 0 && (u64)off < blk.in_n && (u64)off + 16 > blk.in_n) {      // the piece the stream ends in
                 const int nv = (int)(blk.in_n - (u64)off);
 #pragma unroll
                 for (int q = 0; q < 16; ++q)
@@ -1270,7 +1280,7 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
             const u32 f = 4 * i, at = f + f / SPEC_SW;
             const u32 w0 = bswap32(w[0]);
             if (f % SPEC_SW == 0 && f > 0) data[at - 1] = w0;       // the previous row's look-ahead word
-            if (i < (u32)(SPEC_STRIPS * SPEC_SW / 4)) {
+            if (i < UNITS - 1) {
                 data[at] = w0;
                 data[at + 1] = bswap32(w[1]);
                 data[at + 2] = bswap32(w[2]);
