@@ -141,14 +141,24 @@ __device__ __forceinline__ Code code_at(const u32 *data, const u16 *lut, const u
 // stage one tile (+halo) of the stream into LDS as big-endian words; bytes past in_n read as zero
 __device__ __forceinline__ void load_tile(u32 *data, const DecBlk &blk, u32 tile, u32 t = threadIdx.x)
 {
+    // all of a lane's pieces are requested before the first is used (three loads in flight, not three round trips)
     const u64 base = (u64)tile * DTILE;
-    for (u32 i = t; i < DATA_WORDS / 4; i += DEC_THREADS) {
+    constexpr u32 UNITS = DATA_WORDS / 4, NIT = (UNITS + DEC_THREADS - 1) / DEC_THREADS;
+    uint4 v[NIT];
+#pragma unroll
+    for (u32 it = 0; it < NIT; ++it) {
+        const u32 i = t + it * DEC_THREADS;
         const u64 off = base + (u64)i * 16;
-        u32 w[4] = {0, 0, 0, 0};
-        if (off + 16 <= blk.in_n) {
-            const uint4 v = gload<uint4>(blk.in + off);
-            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-        } else if (off < blk.in_n) {
+        v[it] = make_uint4(0, 0, 0, 0);
+        if (i < UNITS && off + 16 <= blk.in_n) v[it] = gload<uint4>(blk.in + off);
+    }
+#pragma unroll
+    for (u32 it = 0; it < NIT; ++it) {
+        const u32 i = t + it * DEC_THREADS;
+        if (i >= UNITS) break;
+        const u64 off = base + (u64)i * 16;
+        u32 w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+        if (off < blk.in_n && off + 16 > blk.in_n) {    // the piece the stream ends in
             const int nv = (int)(blk.in_n - off);
 #pragma unroll
             for (int q = 0; q < 16; ++q)
