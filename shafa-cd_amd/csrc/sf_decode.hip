@@ -64,7 +64,8 @@ struct DecBlk {
                            //   group (next nb bits index lut2[base..]) ; 0 = go to the trie
     const u16 *lut2;       // level 2 (codes of K+1 .. K+8 bits): sym | len << 8 ; 0 = go to the trie
     const u8 *lenlut;      // 2^K1 entries: len only (DP of the packed path); 0 = longer than K1 bits
-    u16 *cnt3;             // 2^spec_window(K1) entries: the whole codes in a window: total bits | len0 << 4 | n << 12
+    u16 *cnt3;             // sfd_spec's tables, 2^spec_window(K1) bytes each: [total bits | codes << 4 of the whole codes in a
+                           // window] then [length of the window's first code]
     u32 *sym3;             // 2^K3 entries: sym0 | sym1 << 8 | sym2 << 16 | total bits << 24 (6 bits) | n << 30
     u8 *pairlut;           // 2^(K1+1) entries: (len(p)-1) | (len(p+1)-1) << 4 from a K1+1-bit window (complete codes)
     const u16 *lut13;      // 2^K1 entries: sym | len << 8, single level (only when Lmax <= 13), else NULL
@@ -407,7 +408,8 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
             if (n == 0) l0 = L;
             pos += L;
         }
-        blk.cnt3[i] = (u16)(pos | (l0 << 4) | (n << 12));
+        ((u8 *)blk.cnt3)[i] = (u8)(pos | (n << 4));
+        ((u8 *)blk.cnt3)[(1u << KW) + i] = (u8)l0;
     }
     for (u32 i = threadIdx.x; i < (1u << K3); i += DEC_THREADS) {   // K3-bit window; n = 0: first code is longer
         u32 pos = 0, n = 0, syms = 0;
@@ -1170,6 +1172,7 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) __attribute__((amdgpu_waves_per
 // ================================================================================================
 typedef __attribute__((address_space(3))) u32 lds_u32;
 typedef __attribute__((address_space(3))) u16 lds_u16;
+typedef __attribute__((address_space(3))) u8 lds_u8;
 constexpr int SPEC_STRIP = 2;                      // chunks per lane: the 256-bit run-up is paid once per strip
                                                    // (4: a fifth fewer steps, but twice the LDS per walk in flight: slower)
 constexpr int SPEC_TILES = SPEC_STRIP;             // a workgroup covers SPEC_STRIP tiles
@@ -1212,14 +1215,14 @@ __device__ __forceinline__ void spec_walk(u32 tab_abs, u32 K1, u32 qb, int &r, i
         const int bk = b - (int)K1;
         while (r <= bk) {                               // the window holds only codes that start before b
             const u32 win = sw.at(qb + (u32)r);
-            const u32 e = *(const lds_u16 *)(size_t)(tab_abs + ((win >> sh) << 1));
+            const u32 e = *(const lds_u8 *)(size_t)(tab_abs + (win >> sh));
             r += (int)(e & 15u);
-            cnt += e >> 12;
+            cnt += e >> 4;
         }
     }
     while (r < b) {
         const u32 win = sw.at(qb + (u32)r);
-        const int l0 = (int)((*(const lds_u16 *)(size_t)(tab_abs + ((win >> sh) << 1)) >> 4) & 15u);
+        const int l0 = (int)*(const lds_u8 *)(size_t)(tab_abs + (1u << K1) + (win >> sh));
         if (LAST && r + l0 > limit) { r = b + 15; break; }       // cut by the end of the stream: nothing starts after it
         r += l0;
         ++cnt;
