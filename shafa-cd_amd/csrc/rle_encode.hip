@@ -6,9 +6,9 @@
 //     r == 0 : emit {0, s, e} if s == 0 or e >= 4, else the literal s
 //     r  > 0 : emit the literal s if s != 0 and r + e < 4, else nothing
 // r needs the run length that enters a tile from the left, e needs at most 255 bytes of look-ahead (a halo read), the
-// output offset of a tile the sizes of all tiles before it.  Three passes of independent workgroups and two tiny
-// per-block scans deliver them (rle3_* below: no tickets, no look-backs); tokens are staged in LDS and stored as
-// aligned words.  (A single chained pass — one read of the input — was built twice, rounds 1 and 2: on inputs that
+// output offset of a tile the sizes of all tiles before it.  Two passes over the input by independent workgroups and
+// three tiny launches in between deliver them (rle3_* below: no tickets, no look-backs); tokens are staged in LDS and
+// stored as aligned 16-byte pieces.  (A single chained pass — one read of the input — was built twice, rounds 1 and 2: on inputs that
 // take the mask code it is no faster, a workgroup spends 10 of its 15 us waiting for its ticket, its loads and its two
 // look-backs, and on long runs its general tile code is 40 times slower; it needs the deferred look-backs of a
 // persistent pipeline like sfe4's to pay)
@@ -258,8 +258,10 @@ __device__ __forceinline__ u32 eqmask4(u32 a, u32 b)
 //   rle3_carry   : per block, segmented scan -> run length that ends at the last byte before every tile
 //   rle3_fix     : emitted bytes of the few tiles that need the general code (flags + carries)
 //   rle3_offsets : per block, exclusive scan + block size
-//   rle3_pass<2> : per tile, tokens -> LDS -> aligned stores
-// Two tiles per workgroup, all their loads issued before either is worked on, barriers that order LDS only.
+//   rle3_emit    : tokens -> LDS image -> aligned 16-byte stores
+// rle3_first and rle3_emit work on pairs of tiles with 32 bytes per lane when the mask code is valid for the pair, else
+// tile by tile with 16 (rle3_first_tile / rle3_pass_tile<2>); all loads are issued before the first tile is worked on,
+// barriers order LDS only.
 // The passes use the mask-based tile code when every run around the tile is short enough that the 255-byte
 // segmentation cannot matter inside it, the per-element general code otherwise.
 // ================================================================================================
