@@ -40,6 +40,13 @@ __device__ __forceinline__ u64 desc_load(const u64 *p)
 // hanging the GPU.
 #define SPIN_LIMIT (1u << 22)
 
+// LDS byte address of a __shared__ object.  Through the LDS address space, not the flat one: the cast of a flat
+// pointer carries a null check (s_cselect) that keeps the segment's base out of the ds instructions' offset field.
+__device__ __forceinline__ u32 lds_addr(const void *p)
+{
+    return (u32)(size_t)(const __attribute__((address_space(3))) u8 *)p;
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave / workgroup primitives (wave = 64 lanes)
 // ---------------------------------------------------------------------------------------------
@@ -52,6 +59,19 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// workgroup-wide OR of a predicate through LDS flags (256 threads).  hip's __syncthreads_or puts 256 bytes of static
+// LDS in front of the dynamic segment, whose base then costs an add in every look-up that could have used the ds
+// offset field.  flags: 2 x 4 words; the sets alternate between calls (`turn`), so one barrier a call is enough.
+__device__ __forceinline__ bool wg_any(bool p, u32 *flags, u32 &turn)
+{
+    u32 *f = flags + 4u * (turn & 1u);
+    ++turn;
+    const bool w = __any(p) != 0;
+    if ((threadIdx.x & 63u) == 0) f[threadIdx.x >> 6] = w;
+    lds_barrier();
+    return (f[0] | f[1] | f[2] | f[3]) != 0;
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
@@ -95,6 +115,8 @@ __device__ __forceinline__ T wave_reduce_add(T v)
 }
 
 __device__ __forceinline__ u32 bswap32(u32 x) { return __builtin_bswap32(x); }
+// every byte of x bit-reversed, bytes in place: an MSB-first bit stream loaded little-endian becomes LSB first
+__device__ __forceinline__ u32 rev_bytes(u32 x) { return __builtin_bitreverse32(__builtin_bswap32(x)); }
 
 // (hi:lo) >> sh, low 32 bits; sh in [0,31]
 __device__ __forceinline__ u32 funnel_r(u32 hi, u32 lo, u32 sh)

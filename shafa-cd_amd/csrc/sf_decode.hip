@@ -408,8 +408,9 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
             if (n == 0) l0 = L;
             pos += L;
         }
-        ((u8 *)blk.cnt3)[i] = (u8)(pos | (n << 4));
-        ((u8 *)blk.cnt3)[(1u << KW) + i] = (u8)l0;
+        const u32 j = __builtin_bitreverse32(i) >> (32 - KW);    // sfd_spec reads its windows LSB first
+        ((u8 *)blk.cnt3)[j] = (u8)(pos | (n << 4));
+        ((u8 *)blk.cnt3)[(1u << KW) + j] = (u8)l0;
     }
     for (u32 i = threadIdx.x; i < (1u << K3); i += DEC_THREADS) {   // K3-bit window; n = 0: first code is longer
         u32 pos = 0, n = 0, syms = 0;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
             syms |= (e & 0xFFu) << (8 * n);
             pos += L;
         }
-        blk.sym3[i] = syms | (pos << 24) | (n << 30);
+        blk.sym3[__builtin_bitreverse32(i) >> (32 - K3)] = syms | (pos << 24) | (n << 30);    // sfd_wstage reads its windows LSB first
     }
     // counting automaton: state = internal trie node (0 = root = between two codes); consuming a nibble (or a bit)
     // moves to the next state and completes 0..4 codes.  next state is stored as the byte offset of its row.
@@ -1184,72 +1185,77 @@ constexpr int SPEC_ROW = SPEC_SW + 1;              // LDS words per strip: the s
 constexpr int SPEC_STRIPS = DEC_THREADS + 1;
 constexpr int SPEC_LDS_DATA = (SPEC_STRIPS * SPEC_ROW + 3) / 4 * 16;
 
-// one walk inside strip j (LDS row j): from bit r of the strip (a code start, by assumption) to the first code start >= b,
-// counting the codes started on the way.  The window at bit p is alignbit(W[(p-1)>>5], W[((p-1)>>5)+1], ~(p-1)): no bit
-// buffer to refill, two look-ups per step.  qb = 8 * (byte address of the row) - 1.
-// LAST: the stream ends at bit `limit` of the strip (may be negative); a code that does not end inside it is not a symbol.
-// the two stream words a window needs, kept across steps: a walk moves ~8 bits a step, so a lane needs new words
-// only every fourth step, and an LDS read costs bank cycles per ACTIVE lane
+// The frame holds the stream LSB first (bit-reversed bytes): stream bit p of the frame is bit p & 31 of word p >> 5, so
+// the window at LDS bit address q is alignbit(W[(q>>5)+1], W[q>>5], q) & mask — no negation, no shift down to the
+// table index — and the tables are indexed by the window read that way (first stream bit = bit 0).
+// The two stream words a window needs are kept across steps: a walk moves ~8 bits a step, so a lane needs new words
+// only every fourth step, and an LDS read costs bank cycles per ACTIVE lane.
 struct SpecWin {
-    u32 hi, lo, wa;                                     // words at LDS address wa, wa + 4
+    u32 lo, hi, wa;                                     // words at LDS address wa, wa + 4
     __device__ __forceinline__ void init() { wa = 0xFFFFFFFFu; hi = lo = 0; }
-    __device__ __forceinline__ u32 at(u32 q)            // the 32 bits at bit q + 1 (q = bit address - 1)
+    __device__ __forceinline__ u32 at(u32 q)            // the 32 stream bits from LDS bit address q on
     {
         const u32 a = (q >> 3) & ~3u;
         if (a != wa) {
             const lds_u32 *pa = (const lds_u32 *)(size_t)a;
-            hi = pa[0];
-            lo = pa[1];
+            lo = pa[0];
+            hi = pa[1];
             wa = a;
         }
-        return __builtin_amdgcn_alignbit(hi, lo, ~q);
+        return __builtin_amdgcn_alignbit(hi, lo, q);
     }
 };
 
+// one walk: from LDS bit address q (a code start, by assumption) to the first code start >= qe, counting the codes
+// started on the way.  tab: [total bits | codes << 4 of the whole codes in a K1-bit window] then [length of the window's
+// first code], 1 << K1 bytes each.
+// LAST: the stream ends at bit address `qlimit` (may lie in front of q); a code that does not end inside it is not a symbol.
 template <bool LAST>
-__device__ __forceinline__ void spec_walk(u32 tab_abs, u32 K1, u32 qb, int &r, int b, int limit, u32 &cnt, SpecWin &sw)
+__device__ __forceinline__ void spec_walk(const lds_u8 *tab, u32 K1, u32 &q, u32 qe, int qlimit, u32 &cnt, SpecWin &sw)
 {
-    // qb and tab_abs hold absolute LDS addresses (the dynamic segment's base folded in): no base add per look-up
-    const u32 sh = 32 - K1;
+    const u32 mask = (1u << K1) - 1u;
     if (!LAST) {
-        const int bk = b - (int)K1;
-        while (r <= bk) {                               // the window holds only codes that start before b
-            const u32 win = sw.at(qb + (u32)r);
-            const u32 e = *(const lds_u8 *)(size_t)(tab_abs + (win >> sh));
-            r += (int)(e & 15u);
-            cnt += e >> 4;
+        const u32 qk = qe - K1, q0 = q;                 // up to qk the window holds only codes that start before qe
+        u32 acc = 0;                                    // sum of the entries = bits walked + 16 * codes: one add a step
+        while (q <= qk) {
+            const u32 e = tab[sw.at(q) & mask];
+            q += e & 15u;
+            acc += e;
         }
+        cnt += (acc - (q - q0)) >> 4;
     }
-    while (r < b) {
-        const u32 win = sw.at(qb + (u32)r);
-        const int l0 = (int)*(const lds_u8 *)(size_t)(tab_abs + (1u << K1) + (win >> sh));
-        if (LAST && r + l0 > limit) { r = b + 15; break; }       // cut by the end of the stream: nothing starts after it
-        r += l0;
+    const lds_u8 *len0 = tab + (1u << K1);
+    while (q < qe) {
+        const u32 l0 = len0[sw.at(q) & mask];
+        if (LAST && (int)(q + l0) > qlimit) { q = qe + 15u; break; }     // cut by the end of the stream: nothing starts after it
+        q += l0;
         ++cnt;
     }
 }
 
-// a strip from entry `ent0` of its first chunk: entries and counts of its SPEC_STRIP chunks, exit of the last one.
-// HAVE_OLD: ent[] holds the entries of an earlier walk of the same strip: once this walk meets it the rest is unchanged.
+// a strip (LDS bit address qrow) from entry `ent0` of its first chunk: entries and counts of its SPEC_STRIP chunks, exit
+// of the last one.  HAVE_OLD: ent[] holds the entries of an earlier walk of the same strip: once this walk meets it the
+// rest is unchanged.
 template <bool LAST, bool HAVE_OLD>
-__device__ __forceinline__ void spec_strip(u32 tab_abs, u32 K1, u32 qb, int limit, u32 ent0,
+__device__ __forceinline__ void spec_strip(const lds_u8 *tab, u32 K1, u32 qrow, int qlimit, u32 ent0,
                                            u32 (&ent)[SPEC_STRIP], u32 (&cnt)[SPEC_STRIP], u32 &exit_)
 {
-    int r = (int)ent0;
+    u32 q = qrow + ent0;
     SpecWin sw;
     sw.init();
 #pragma unroll
     for (int k = 0; k < SPEC_STRIP; ++k) {
-        if (HAVE_OLD && k > 0 && (u32)(r - 256 * k) == ent[k]) return;  // back on the earlier walk's path
-        ent[k] = (u32)(r - 256 * k);
+        const u32 r = q - (qrow + 256u * k);
+        if (HAVE_OLD && k > 0 && r == ent[k]) return;   // back on the earlier walk's path
+        ent[k] = r;
         u32 c = 0;
-        spec_walk<LAST>(tab_abs, K1, qb, r, 256 * (k + 1), limit, c, sw);
+        spec_walk<LAST>(tab, K1, q, qrow + 256u * (k + 1), qlimit, c, sw);
         cnt[k] = c;
     }
-    exit_ = (u32)(r - 256 * SPEC_STRIP) & 15u;
+    exit_ = (q - (qrow + 256u * SPEC_STRIP)) & 15u;
 }
 
-// dynamic LDS: stream frame | cnt3 (2 << K1max bytes) | exits[256] | wsum[4]
+// dynamic LDS: stream frame | cnt3 (2 << K1max bytes) | exits[256] | wsum[4] | flags[8]
 constexpr int SPEC_FIX_REGIONS = 32;               // regions a workgroup of a repair launch looks at (almost none needs work)
 
 template <bool FIX>
@@ -1291,13 +1297,13 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
                     if (q < nv) w[q >> 2] |= (u32)gload<u8>(blk.in + off + q) << (8 * (q & 3));
             }
             const u32 f = 4 * i, at = f + f / SPEC_SW;
-            const u32 w0 = bswap32(w[0]);
+            const u32 w0 = rev_bytes(w[0]);
             if (f % SPEC_SW == 0 && f > 0) data[at - 1] = w0;       // the previous row's look-ahead word
             if (i < UNITS - 1) {
                 data[at] = w0;
-                data[at + 1] = bswap32(w[1]);
-                data[at + 2] = bswap32(w[2]);
-                data[at + 3] = bswap32(w[3]);
+                data[at + 1] = rev_bytes(w[1]);
+                data[at + 2] = rev_bytes(w[2]);
+                data[at + 3] = rev_bytes(w[3]);
             }
         }
     }
@@ -1308,8 +1314,14 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
     const u64 capb = (u64)SPEC_TILES * DTILE + 4;
     const bool last = left < capb;                      // the stream ends inside this frame
     const int limit = last ? (int)(left * 8) - (int)(256u * SPEC_STRIP * tid) : 0;
-    const u32 sbase = (u32)(size_t)smem;               // LDS offset of the dynamic segment (low half of its flat address)
-    const u32 qb = 8u * (sbase + (4u * SPEC_ROW) * (tid + 1)) - 1u, tab_abs = sbase + tab_off;
+    // LDS bit address of the strip's first bit; addresses are absolute (the segment's base folded into the constants)
+    const u32 qrow = 8u * (lds_addr(smem) + (4u * SPEC_ROW) * (tid + 1));
+    const int qlimit = (int)qrow + limit;
+    // the table's LDS address as a literal: the kernel has no static LDS, its dynamic segment starts at 0 (checked:
+    // the comparison folds at compile time), and a literal goes into the ds offset field where "smem + offset" leaves
+    // an add per look-up
+    if (lds_addr(smem) != 0) __builtin_trap();
+    const lds_u8 *tab = (const lds_u8 *)(size_t)tab_off;
     u32 ent[SPEC_STRIP], cnt[SPEC_STRIP], exit_ = 0;
     {
         u32 e0;
@@ -1318,36 +1330,37 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
         if (exact0) e0 = 0;
         else if (forced) e0 = (u32)tile_exit[gt0 - 1];
         else {                                          // run-up: the last chunk of the strip in front, from its first bit
-            int r = 256 * (SPEC_STRIP - 1);
-            u32 dummy = 0;
-            const u32 qp = qb - 8u * (4u * SPEC_ROW);
+            const u32 qprow = qrow - 8u * (4u * SPEC_ROW), qe = qprow + 256u * SPEC_STRIP;
+            u32 q = qe - 256u, dummy = 0;
             SpecWin sw;
             sw.init();
-            if (last) spec_walk<true>(tab_abs, K1, qp, r, 256 * SPEC_STRIP, limit + 256 * SPEC_STRIP, dummy, sw);
-            else spec_walk<false>(tab_abs, K1, qp, r, 256 * SPEC_STRIP, 0, dummy, sw);
-            e0 = (u32)(r - 256 * SPEC_STRIP) & 15u;
+            if (last) spec_walk<true>(tab, K1, q, qe, qlimit, dummy, sw);
+            else spec_walk<false>(tab, K1, q, qe, 0, dummy, sw);
+            e0 = (q - qe) & 15u;
         }
-        if (last) spec_strip<true, false>(tab_abs, K1, qb, limit, e0, ent, cnt, exit_);
-        else spec_strip<false, false>(tab_abs, K1, qb, limit, e0, ent, cnt, exit_);
+        if (last) spec_strip<true, false>(tab, K1, qrow, qlimit, e0, ent, cnt, exit_);
+        else spec_strip<false, false>(tab, K1, qrow, qlimit, e0, ent, cnt, exit_);
     }
     ex[tid] = (u8)exit_;
     __syncthreads();
     // strips whose guess differs from the exit in front of them walk again from that exit, until the walk meets the old one
     bool bad = false;
+    u32 *const wsum = (u32 *)(ex + DEC_THREADS), *const flags = wsum + 4;
+    u32 turn = 0;
     for (int round = 0; round < 4; ++round) {
         bad = tid > 0 && ent[0] != (u32)ex[tid - 1];
-        if (!__syncthreads_or(bad)) break;
+        if (!wg_any(bad, flags, turn)) break;
         if (bad) {
             const u32 e0 = ex[tid - 1];
-            if (last) spec_strip<true, true>(tab_abs, K1, qb, limit, e0, ent, cnt, exit_);
-            else spec_strip<false, true>(tab_abs, K1, qb, limit, e0, ent, cnt, exit_);
+            if (last) spec_strip<true, true>(tab, K1, qrow, qlimit, e0, ent, cnt, exit_);
+            else spec_strip<false, true>(tab, K1, qrow, qlimit, e0, ent, cnt, exit_);
         }
         __syncthreads();                                // every lane has read the exit in front of it
         ex[tid] = (u8)exit_;
         __syncthreads();
         bad = tid > 0 && ent[0] != (u32)ex[tid - 1];
     }
-    if (__syncthreads_or(bad)) {                        // did not settle: the block takes the exact kernels
+    if (wg_any(bad, flags, turn)) {                     // did not settle: the block takes the exact kernels
         if (tid == 0) __hip_atomic_store(blk.run_dp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // chunk tid * SPEC_STRIP + k of the region; a tile is 256 / SPEC_STRIP consecutive lanes
@@ -1356,7 +1369,6 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
 #pragma unroll
     for (int k = 0; k < SPEC_STRIP; ++k) mine += cnt[k];
     const u32 wtot = dpp_scan_add(mine);                // lane 63: the wave's codes
-    u32 *wsum = (u32 *)(ex + DEC_THREADS);
     if (lane == 63) wsum[wv] = wtot;
     __syncthreads();
     if (my_tile < ntl) {
@@ -1403,7 +1415,8 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_spec(const DecBlk *__restrict
     if (t_lo >= blk.n_tiles) return;
     const u32 t = t_lo + threadIdx.x;
     const bool mine = threadIdx.x < SPEC_FIX_REGIONS * SPEC_TILES && t < blk.n_tiles && tile_fix[(size_t)blk.tile_base + t] != 0;
-    if (!__syncthreads_or(mine)) return;
+    u32 turn = 0;
+    if (!wg_any(mine, (u32 *)(smem + SPEC_LDS_DATA + tab_bytes + DEC_THREADS + 16), turn)) return;
     for (u32 r = 0; r < SPEC_FIX_REGIONS; ++r) {
         const u32 tile0 = t_lo + r * SPEC_TILES;
         if (tile0 >= blk.n_tiles) break;
@@ -1548,7 +1561,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
     u32 *next = wsum + 4;
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 K1 = blk.K1, K3 = sym3_window(K1);
-    const u32 sh = 32 - K1, sh3 = 32 - K3;
+    const u32 sh = 32 - K1;
     fill_lds16(smem + tab_off, (const void *)blk.sym3, 4u << K3);
     if (LONG) {
         const u16 *src = LONG == 1 ? blk.longtab : blk.long32;
@@ -1557,9 +1570,12 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
     }
     for (u32 i = tid; i < cap / 16; i += DEC_THREADS) *(uint4 *)(smem + img_off + 16 * i) = make_uint4(0, 0, 0, 0);
     bool bad = false;
-    const u32 sbase = (u32)(size_t)smem;               // LDS offset of the dynamic segment (low half of its flat address)
-    const u32 qb_abs = 8u * (sbase + 16u + 4u * WS_ROW * tid) - 1u;
-    const u32 tab_abs = sbase + tab_off, dump_abs = sbase + img_off + cap + 4 * tid;
+    // LDS addresses as literals: the kernel has no static LDS, so its dynamic segment starts at 0 (checked), and a
+    // literal goes into the ds offset field where "smem + offset" leaves an add per look-up
+    if (lds_addr(smem) != 0) __builtin_trap();
+    const u32 q2row = 8u * (16u + 4u * WS_ROW * tid) - 2u;      // LDS bit address of the lane's row, minus 2 (see step)
+    const u32 mask4 = ((1u << K3) - 1u) << 2;
+    const u32 dump_abs = img_off + cap + 4 * tid;
     // 16 stream bytes at `off` (zeros past the end)
     auto fetch16 = [&](const u64 off) -> uint4 {
         if (off + 16 <= blk.in_n) return gload<uint4>(blk.in + off);
@@ -1587,13 +1603,13 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
     // tile word f -> LDS word f + f / 8; the first word of a row is also the look-ahead word of the row before
     auto put16 = [&](const u32 i, const uint4 v) {
         const u32 f = 4 * i, at = f + (f >> 3);
-        const u32 w0 = bswap32(v.x);
+        const u32 w0 = rev_bytes(v.x);
         if ((f & 7u) == 0 && f > 0) rows[at - 1] = w0;
         if (i < (u32)(DTILE / 16)) {
             rows[at] = w0;
-            rows[at + 1] = bswap32(v.y);
-            rows[at + 2] = bswap32(v.z);
-            rows[at + 3] = bswap32(v.w);
+            rows[at + 1] = rev_bytes(v.y);
+            rows[at + 2] = rev_bytes(v.z);
+            rows[at + 3] = rev_bytes(v.w);
         }
     };
     prefetch(first_tile);
@@ -1617,7 +1633,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
         const u64 room = blk.n_sym - toff;              // symbols of this tile that exist in the block
         const u32 tot_c = room < (u64)total ? (u32)room : total;
         u32 want = pre >= tot_c ? 0u : (tot_c - pre < cnt ? tot_c - pre : cnt);
-        int r = (int)entry;
+        u32 q2 = q2row + entry;
         for (u32 done = 0; done < tot_c;) {
             u8 *gout = blk.out + toff + done;
             const u32 mis = (u32)((uintptr_t)gout & 15u);
@@ -1635,13 +1651,17 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                 const u32 x = mis + (pre - done);
                 // LDS addresses are absolute from here on (the dynamic segment's base folded into the constants): an
                 // address that is "base + variable" costs an add per look-up that the ds instructions cannot absorb
-                u32 wp = sbase + img_off + (x & ~3u), nb8 = (x & 3u) * 8, acc = 0;
+                u32 wp = img_off + (x & ~3u), nb8 = (x & 3u) * 8, acc = 0;
                 auto step = [&](const bool tail) {
-                    const u32 q = qb_abs + (u32)r;
-                    const lds_u32 *pa = (const lds_u32 *)(size_t)((q >> 3) & ~3u);
-                    const u32 win = __builtin_amdgcn_alignbit(pa[0], pa[1], ~q);
-                    u32 e = *(const lds_u32 *)(size_t)(tab_abs + ((win >> sh3) << 2));
+                    // the rows hold the stream LSB first; the 64 bits around the position shifted down to two bits in
+                    // front of it are the window times four, the byte offset of its table entry: alignbit, and, read
+                    const lds_u32 *pa = (const lds_u32 *)(size_t)((q2 >> 3) & ~3u);
+                    const u32 w4 = __builtin_amdgcn_alignbit(pa[1], pa[0], q2);
+                    u32 e = *(const lds_u32 *)(size_t)(tab_off + (w4 & mask4));
                     if (ESC && __builtin_expect((e >> 30) == 0, 0)) {      // first code longer than the window: one code
+                        const u32 q = q2 + 2u;                             // its 32 bits, first bit at the top
+                        const lds_u32 *pb = (const lds_u32 *)(size_t)((q >> 3) & ~3u);
+                        const u32 win = __builtin_bitreverse32(__builtin_amdgcn_alignbit(pb[1], pb[0], q));
                         u32 e1 = LONG == 1 ? long_code(lt, win) : LONG == 2 ? long_code32(lt, win)
                                            : (u32)gload<u16>(blk.lut13 + (win >> sh));
                         if (e1 == 0) { bad = true; e1 = 1u << 8; }  // not a code (complete tables never get here)
@@ -1660,7 +1680,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                     acc = ov ? (u32)(t >> 32) : lo;
                     wp += ov ? 4u : 0u;
                     nb8 = nbn & 31u;
-                    r += (int)((e >> 24) & 63u);
+                    q2 += (e >> 24) & 63u;
                     want -= n;
                 };
                 while (want >= 3) step(false);
@@ -2197,7 +2217,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
             u32 k1_max = 1;
             for (int b = 0; b < nblocks; ++b) if (spec_blk[b] && spec_window(tabs[b].K1) > k1_max) k1_max = spec_window(tabs[b].K1);
             const u32 tabb = 2u << k1_max;
-            const size_t lds_spec = (size_t)SPEC_LDS_DATA + tabb + DEC_THREADS + 16;
+            const size_t lds_spec = (size_t)SPEC_LDS_DATA + tabb + DEC_THREADS + 16 + 32;
             const dim3 grid_s((u32)ceil_div_u64(max_tiles, SPEC_TILES), (u32)nblocks);
             const dim3 grid_sf((u32)ceil_div_u64(max_tiles, SPEC_TILES * SPEC_FIX_REGIONS), (u32)nblocks);
             hipLaunchKernelGGL(sfd_spec<false>, grid_s, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
