@@ -23,6 +23,7 @@
 //
 // Codes longer than the 11-bit LUT fall back to a bit-serial trie walk (any length up to 255).
 // Algorithmic HBM bytes per block: sf_n read + n_symbols written.
+#include <type_traits>
 #include "common.hpp"
 #include "internal.hpp"
 
@@ -1217,6 +1218,24 @@ __device__ __forceinline__ void spec_walk(const lds_u8 *tab, u32 K1, u32 &q, u32
     if (!LAST) {
         const u32 qk = qe - K1, q0 = q;                 // up to qk the window holds only codes that start before qe
         u32 acc = 0;                                    // sum of the entries = bits walked + 16 * codes: one add a step
+        // N look-ups per window fetch: the 32 bits fetched hold further windows behind the first one's codes
+        auto multi = [&](auto nlook) {
+            constexpr u32 N = decltype(nlook)::value;
+            const u32 qs = qe - N * K1;
+            while (q <= qs) {
+                const u32 w = sw.at(q);
+                u32 used = 0;
+#pragma unroll
+                for (u32 i = 0; i < N; ++i) {
+                    const u32 e = tab[(w >> used) & mask];
+                    used += e & 15u;
+                    acc += e;
+                }
+                q += used;
+            }
+        };
+        if (K1 <= 10) multi(std::integral_constant<u32, 3>{});
+        multi(std::integral_constant<u32, 2>{});          // K1 <= 13: 26 bits
         while (q <= qk) {
             const u32 e = tab[sw.at(q) & mask];
             q += e & 15u;
@@ -1652,12 +1671,26 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                 // LDS addresses are absolute from here on (the dynamic segment's base folded into the constants): an
                 // address that is "base + variable" costs an add per look-up that the ds instructions cannot absorb
                 u32 wp = img_off + (x & ~3u), nb8 = (x & 3u) * 8, acc = 0;
-                auto step = [&](const bool tail) {
-                    // the rows hold the stream LSB first; the 64 bits around the position shifted down to two bits in
-                    // front of it are the window times four, the byte offset of its table entry: alignbit, and, read
+                // n symbols (low bytes of syms) join the word being gathered; a finished word is ORed into the image,
+                // an unfinished one into the lane's dump word (no divergent flush)
+                auto emit = [&](const u32 n, const u32 syms) {
+                    const u64 t = (u64)syms << nb8;
+                    const u32 lo = acc | (u32)t;
+                    const u32 nbn = nb8 + 8 * n;
+                    const bool ov = nbn >= 32;
+                    __hip_atomic_fetch_or((lds_u32 *)(size_t)(ov ? wp : dump_abs), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    acc = ov ? (u32)(t >> 32) : lo;
+                    wp += ov ? 4u : 0u;
+                    nb8 = nbn & 31u;
+                };
+                // the rows hold the stream LSB first; the 64 bits around the position shifted down to two bits in
+                // front of it are the window times four, the byte offset of its table entry: alignbit, and, read
+                auto window4 = [&]() -> u32 {
                     const lds_u32 *pa = (const lds_u32 *)(size_t)((q2 >> 3) & ~3u);
-                    const u32 w4 = __builtin_amdgcn_alignbit(pa[1], pa[0], q2);
-                    u32 e = *(const lds_u32 *)(size_t)(tab_off + (w4 & mask4));
+                    return __builtin_amdgcn_alignbit(pa[1], pa[0], q2);
+                };
+                auto step = [&](const bool tail) {
+                    u32 e = *(const lds_u32 *)(size_t)(tab_off + (window4() & mask4));
                     if (ESC && __builtin_expect((e >> 30) == 0, 0)) {      // first code longer than the window: one code
                         const u32 q = q2 + 2u;                             // its 32 bits, first bit at the top
                         const lds_u32 *pb = (const lds_u32 *)(size_t)((q >> 3) & ~3u);
@@ -1672,17 +1705,31 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                         n = n < want ? n : want;
                         syms &= (1u << (8 * n)) - 1u;
                     }
-                    const u64 t = (u64)syms << nb8;
-                    const u32 lo = acc | (u32)t;
-                    const u32 nbn = nb8 + 8 * n;
-                    const bool ov = nbn >= 32;
-                    __hip_atomic_fetch_or((lds_u32 *)(size_t)(ov ? wp : dump_abs), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    acc = ov ? (u32)(t >> 32) : lo;
-                    wp += ov ? 4u : 0u;
-                    nb8 = nbn & 31u;
+                    emit(n, syms);
                     q2 += (e >> 24) & 63u;
                     want -= n;
                 };
+                // N look-ups per stream read: the 30 window bits fetched hold further windows behind the first one's
+                // codes as long as N windows fit (a look-up uses at most K3 bits)
+                auto multi = [&](auto nlook) {
+                    constexpr u32 N = decltype(nlook)::value;
+                    while (want >= 3 * N) {
+                        const u32 w4 = window4();
+                        u32 used = 0;
+#pragma unroll
+                        for (u32 i = 0; i < N; ++i) {
+                            const u32 e = *(const lds_u32 *)(size_t)(tab_off + ((w4 >> used) & mask4));
+                            emit(e >> 30, e & 0xFFFFFFu);
+                            used += (e >> 24) & 63u;
+                            want -= e >> 30;
+                        }
+                        q2 += used;
+                    }
+                };
+                if (!ESC) {
+                    if (K3 <= 10) multi(std::integral_constant<u32, 3>{});
+                    if (K3 <= 15) multi(std::integral_constant<u32, 2>{});
+                }
                 while (want >= 3) step(false);
                 while (want) step(true);
                 if (nb8) __hip_atomic_fetch_or((lds_u32 *)(size_t)wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
