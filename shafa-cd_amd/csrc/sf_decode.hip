@@ -1547,17 +1547,18 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *
 // A lane decodes one chunk from its entry, exactly the symbols counted for it.  The workgroup's symbols are one
 // contiguous run of the output, so they are collected in an LDS image of that run (aligned like the output address)
 // and leave as aligned 16-byte stores, fully coalesced.  A lane gathers symbols in a 32-bit word and ORs each finished
-// word into the image (ds_or_b32: the words at both ends of a lane's run are shared with its neighbours; unfinished
-// words go to a per-lane dump word so that the loop has no divergent flush).  The stream sits in LDS one row per
-// chunk (8 words + the next row's first: rows 9 words apart, conflict free); the window at bit p is
-// alignbit(W[(p-1)>>5], W[((p-1)>>5)+1], ~(p-1)), no bit buffer.
-// dynamic LDS: rows | sym3 (tab_bytes) | long table (LONG) | image (cap bytes) | dump[256] | wsum[4], next
+// word into the image (ds_or_b32: the words at both ends of a lane's run are shared with its neighbours; only lanes
+// with a finished word issue it — an LDS atomic costs bank cycles per active lane, and two steps in three finish none).
+// The stream sits in LDS one row per chunk (8 words + the next row's first: rows 9 words apart, conflict free), LSB
+// first (bytes bit-reversed): the window at LDS bit address q is alignbit(W[(q>>5)+1], W[q>>5], q), no bit buffer,
+// and the 30 bits it delivers serve two or three look-ups.
+// dynamic LDS: rows | sym3 (tab_bytes) | long table (LONG) | image (cap bytes) | wsum[4], next
 // The host sizes the image for the launch's average symbols per tile plus a margin (LDS is what limits the waves per
 // CU); a tile with more symbols than it holds goes in several rounds of consecutive lanes.
 // ------------------------------------------------------------------------------------------------
 constexpr int WS_ROW = CH_BYTES / 4 + 1;            // LDS words per chunk row
 constexpr int WS_ROWS_BYTES = 16 + DEC_THREADS * WS_ROW * 4;     // 16 in front: the window at a row's bit 0 reads the word before it
-constexpr int WS_MISC = DEC_THREADS * 4 + 32;
+constexpr int WS_MISC = 32;
 
 // ESC: some code of the launch may be longer than its block's sym3 window (then a look-up can return no symbol)
 template <int LONG, bool ESC>
@@ -1575,8 +1576,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
     const u32 tab_off = WS_ROWS_BYTES;
     const u16 *lt = (const u16 *)(smem + tab_off + tab_bytes);
     const u32 img_off = tab_off + tab_bytes + LONGB;
-    u32 *dump = (u32 *)(smem + img_off + cap);
-    u32 *wsum = dump + DEC_THREADS;
+    u32 *wsum = (u32 *)(smem + img_off + cap);
     u32 *next = wsum + 4;
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 K1 = blk.K1, K3 = sym3_window(K1);
@@ -1594,7 +1594,6 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
     if (lds_addr(smem) != 0) __builtin_trap();
     const u32 q2row = 8u * (16u + 4u * WS_ROW * tid) - 2u;      // LDS bit address of the lane's row, minus 2 (see step)
     const u32 mask4 = ((1u << K3) - 1u) << 2;
-    const u32 dump_abs = img_off + cap + 4 * tid;
     // 16 stream bytes at `off` (zeros past the end)
     auto fetch16 = [&](const u64 off) -> uint4 {
         if (off + 16 <= blk.in_n) return gload<uint4>(blk.in + off);
@@ -1671,14 +1670,13 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                 // LDS addresses are absolute from here on (the dynamic segment's base folded into the constants): an
                 // address that is "base + variable" costs an add per look-up that the ds instructions cannot absorb
                 u32 wp = img_off + (x & ~3u), nb8 = (x & 3u) * 8, acc = 0;
-                // n symbols (low bytes of syms) join the word being gathered; a finished word is ORed into the image,
-                // an unfinished one into the lane's dump word (no divergent flush)
+                // n symbols (low bytes of syms) join the word being gathered; a finished word is ORed into the image
                 auto emit = [&](const u32 n, const u32 syms) {
                     const u64 t = (u64)syms << nb8;
                     const u32 lo = acc | (u32)t;
                     const u32 nbn = nb8 + 8 * n;
                     const bool ov = nbn >= 32;
-                    __hip_atomic_fetch_or((lds_u32 *)(size_t)(ov ? wp : dump_abs), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (ov) __hip_atomic_fetch_or((lds_u32 *)(size_t)wp, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     acc = ov ? (u32)(t >> 32) : lo;
                     wp += ov ? 4u : 0u;
                     nb8 = nbn & 31u;
