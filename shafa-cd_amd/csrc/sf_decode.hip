@@ -1673,12 +1673,13 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                 // n symbols (low bytes of syms) join the word being gathered; a finished word is ORed into the image
                 auto emit = [&](const u32 n, const u32 syms) {
                     const u64 t = (u64)syms << nb8;
-                    const u32 lo = acc | (u32)t;
                     const u32 nbn = nb8 + 8 * n;
-                    const bool ov = nbn >= 32;
-                    if (ov) __hip_atomic_fetch_or((lds_u32 *)(size_t)wp, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    acc = ov ? (u32)(t >> 32) : lo;
-                    wp += ov ? 4u : 0u;
+                    acc |= (u32)t;
+                    if (nbn >= 32) {                    // only the lanes with a finished word touch the image
+                        __hip_atomic_fetch_or((lds_u32 *)(size_t)wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        wp += 4u;
+                        acc = (u32)(t >> 32);
+                    }
                     nb8 = nbn & 31u;
                 };
                 // the rows hold the stream LSB first; the 64 bits around the position shifted down to two bits in
