@@ -115,6 +115,37 @@ __device__ __forceinline__ T wave_reduce_add(T v)
 }
 
 __device__ __forceinline__ u32 bswap32(u32 x) { return __builtin_bswap32(x); }
+// SWAR zero-byte tests.  zero_bytes80: 0x80 in every byte of d that is zero (exact).  The flags are gathered into
+// mask bits by v_dot4_u32_u8 (flag bytes times the weights 1, 2, 4, 8 — or 16 .. 128 for the second word of a pair,
+// on top of the first word's sum): 128 * mask, no shift-and-or ladder.
+__device__ __forceinline__ u32 zero_bytes80(u32 d)
+{
+    const u32 s = (d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(s | d) & 0x80808080u;
+}
+// bit b = byte b of d is zero
+__device__ __forceinline__ u32 zmask4(u32 d) { return __builtin_amdgcn_udot4(zero_bytes80(d), 0x08040201u, 0u, false) >> 7; }
+// bit 4 i + b = byte b of d[i] is zero
+__device__ __forceinline__ u32 zmask32(const u32 *d)       // eight words, fully unrolled: d stays in registers
+{
+    u32 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        acc[k] = __builtin_amdgcn_udot4(zero_bytes80(d[2 * k + 1]), 0x80402010u,
+                                        __builtin_amdgcn_udot4(zero_bytes80(d[2 * k]), 0x08040201u, 0u, false), false);
+    return (acc[0] >> 7) | (acc[1] << 1) | (acc[2] << 9) | (acc[3] << 17);
+}
+// a + byte C of x in one instruction (SDWA source select); the compiler only finds this form for C = 3
+template <int C>
+__device__ __forceinline__ u32 add_byte(u32 a, u32 x)
+{
+    u32 r;
+    if (C == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(x));
+    if (C == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(x));
+    if (C == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(x));
+    if (C == 3) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(a), "v"(x));
+    return r;
+}
 // every byte of x bit-reversed, bytes in place: an MSB-first bit stream loaded little-endian becomes LSB first
 __device__ __forceinline__ u32 rev_bytes(u32 x) { return __builtin_bitreverse32(__builtin_bswap32(x)); }
 

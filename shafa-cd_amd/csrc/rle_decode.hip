@@ -188,14 +188,7 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
         *(u32 *)(sh.in + RLD_TILE) = la;
     }
     const u32 vm = nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
-    u32 z = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const u32 t = ((w[i] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w[i];
-        const u32 f = (~t >> 7) & 0x01010101u;                       // 0x01 in the zero bytes
-        z |= (((__umul24(f, 0x00204081u) >> 21) & 7u) | ((f >> 21) & 8u)) << (4 * i);
-    }
-    z &= vm;
+    const u32 z = zmask32(w) & vm;
 
     // ---- this lane's transition map and token starts for each entry state, ordered scan over lanes and waves --------
     u32 st3[3], ex3[3];

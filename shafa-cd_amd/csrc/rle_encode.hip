@@ -36,6 +36,7 @@ struct RleBlk {
     u32 n_tiles;
     u32 ticket;
     u32 pad;
+    uint2 *masks;          // per 32-byte granule of the block: {E, Z} masks of the first pass for the emit pass (pairs of tiles)
 };
 
 struct Seg { u32 f, v; };
@@ -244,11 +245,7 @@ __device__ __forceinline__ u32 nibf(u32 mask, int q) { return __umul24((mask >> 
 // 4-bit mask of the bytes of a that equal the bytes of b (exact SWAR zero-byte test of a ^ b)
 __device__ __forceinline__ u32 eqmask4(u32 a, u32 b)
 {
-    const u32 d = a ^ b;
-    u32 t = (d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
-    t = ~(t | d | 0x7F7F7F7Fu);                       // 0x80 in every byte of d that is zero
-    const u32 m = t >> 7;
-    return (m | (m >> 7) | (m >> 14) | (m >> 21)) & 0xFu;
+    return zmask4(a ^ b);
 }
 
 // ================================================================================================
@@ -422,22 +419,29 @@ __device__ __forceinline__ void rle3_first_tile(RleShared &sh, const RleBlk &blk
 }
 
 // R[t] = length of the run that ends at the last byte of tile t - 1
+constexpr u32 SCAN_EPT = 16;                           // tiles per thread and round of the two per-block scans
 __global__ __launch_bounds__(RLE_THREADS) void rle3_carry(const RleBlk *__restrict__ blks, const u32 *__restrict__ tsum,
                                                           u32 *__restrict__ R)
 {
+    // one workgroup per block; a thread takes SCAN_EPT consecutive tiles a round, all of its loads issued before the
+    // first is used (64 rounds of one tile per thread, a load and three barriers each, took 60 us for 16 K tiles)
     __shared__ Seg wtot[4];
     __shared__ Seg carry;
     const RleBlk blk = blks[blockIdx.x];
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
-    if (tid == 0) carry = Seg{0u, 0u};
+    if (tid == 0) carry = Seg{1u, 0u};
     lds_barrier();
-    u32 xn = (u32)tid < blk.n_tiles ? tsum[blk.desc_base + tid] : 0u;     // one iteration ahead
-    for (u32 t0 = 0; t0 < blk.n_tiles; t0 += RLE_THREADS) {
-        const u32 t = t0 + tid;
-        const u32 x = xn;
-        xn = t + RLE_THREADS < blk.n_tiles ? tsum[blk.desc_base + t + RLE_THREADS] : 0u;
-        Seg f = Seg{x >> 31, x & 0x7FFFFFFFu};
-        const Seg own = f;
+    for (u32 r0 = 0; r0 < blk.n_tiles; r0 += RLE_THREADS * SCAN_EPT) {
+        const u32 t0 = r0 + (u32)tid * SCAN_EPT;
+        u32 x[SCAN_EPT];
+#pragma unroll
+        for (u32 j = 0; j < SCAN_EPT; ++j) x[j] = t0 + j < blk.n_tiles ? tsum[blk.desc_base + t0 + j] : 0x80000000u;
+        Seg ex[SCAN_EPT], f = Seg{1u, 0u};              // ex[j]: the tiles of this thread in front of tile j
+#pragma unroll
+        for (u32 j = 0; j < SCAN_EPT; ++j) {
+            ex[j] = f;
+            f = comb_f(f, Seg{x[j] >> 31, x[j] & 0x7FFFFFFFu});
+        }
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             Seg y = Seg{(u32)__shfl_up(f.f, d, 64), (u32)__shfl_up(f.v, d, 64)};
@@ -447,12 +451,12 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_carry(const RleBlk *__restri
         lds_barrier();
         Seg pre = carry;                                // everything before this wave
         for (int ww = 0; ww < wv; ++ww) pre = comb_f(pre, wtot[ww]);
-        // exclusive value = run ending just before tile t
-        Seg ex = Seg{(u32)__shfl_up(f.f, 1, 64), (u32)__shfl_up(f.v, 1, 64)};
-        if (lane == 0) ex = Seg{1u, 0u};
-        const Seg before = comb_f(pre, ex);
-        (void)own;
-        if (t < blk.n_tiles) R[blk.desc_base + t] = before.v;
+        Seg lanes = Seg{(u32)__shfl_up(f.f, 1, 64), (u32)__shfl_up(f.v, 1, 64)};      // the lanes in front, this wave
+        if (lane == 0) lanes = Seg{1u, 0u};
+        pre = comb_f(pre, lanes);
+#pragma unroll
+        for (u32 j = 0; j < SCAN_EPT; ++j)              // the run that ends just before tile t0 + j
+            if (t0 + j < blk.n_tiles) R[blk.desc_base + t0 + j] = comb_f(pre, ex[j]).v;
         lds_barrier();
         if (tid == 0) {
             Seg c2 = carry;
@@ -472,17 +476,25 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_offsets(const RleBlk *__rest
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) carry = 0;
     lds_barrier();
-    u32 tn = tid < blk.n_tiles ? T[blk.desc_base + tid] : 0u;             // one iteration ahead
-    for (u32 t0 = 0; t0 < blk.n_tiles; t0 += RLE_THREADS) {
-        const u32 t = t0 + tid;
-        const u64 cnt = (u64)(tn & T_SIZE);             // flags of rle3_first masked off
-        tn = t + RLE_THREADS < blk.n_tiles ? T[blk.desc_base + t + RLE_THREADS] : 0u;
-        const u64 incl = wave_incl_scan_add<u64>(cnt);
+    for (u32 r0 = 0; r0 < blk.n_tiles; r0 += RLE_THREADS * SCAN_EPT) {      // as rle3_carry: SCAN_EPT tiles per thread
+        const u32 t0 = r0 + tid * SCAN_EPT;
+        u32 x[SCAN_EPT];
+#pragma unroll
+        for (u32 j = 0; j < SCAN_EPT; ++j) x[j] = t0 + j < blk.n_tiles ? T[blk.desc_base + t0 + j] & T_SIZE : 0u;   // flags of rle3_first masked off
+        u32 ex[SCAN_EPT], mine = 0;
+#pragma unroll
+        for (u32 j = 0; j < SCAN_EPT; ++j) {
+            ex[j] = mine;
+            mine += x[j];
+        }
+        const u64 incl = wave_incl_scan_add<u64>((u64)mine);
         if (lane == 63) wtot[wv] = incl;
         lds_barrier();
-        u64 base = carry;
+        u64 base = carry + incl - mine;
         for (u32 ww = 0; ww < wv; ++ww) base += wtot[ww];
-        if (t < blk.n_tiles) G[blk.desc_base + t] = base + incl - cnt;
+#pragma unroll
+        for (u32 j = 0; j < SCAN_EPT; ++j)
+            if (t0 + j < blk.n_tiles) G[blk.desc_base + t0 + j] = base + ex[j];
         lds_barrier();
         if (tid == 0) carry += wtot[0] + wtot[1] + wtot[2] + wtot[3];
         lds_barrier();
@@ -650,14 +662,6 @@ union R8Shared {
     R8Fast f;
 };
 
-// 4-bit mask of the zero bytes of d (exact)
-__device__ __forceinline__ u32 zmask4(u32 d)
-{
-    const u32 t = ((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d;
-    const u32 f = (~t >> 7) & 0x01010101u;
-    return ((__umul24(f, 0x00204081u) >> 21) & 7u) | ((f >> 21) & 8u);
-}
-
 __device__ __forceinline__ bool rle3_emit8k(R8Fast &sh, const RleBlk &blk, const int kp, const u32 Rin, const u64 G)
 {
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
@@ -671,6 +675,7 @@ __device__ __forceinline__ bool rle3_emit8k(R8Fast &sh, const RleBlk &blk, const
         const uint4 v0 = gload_nt<uint4>(blk.in + pos), v1 = gload_nt<uint4>(blk.in + pos + 16);
         w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
     }
+    const uint2 mz = gload_nt<uint2>(blk.masks + (size_t)kp * RLE_THREADS + tid);
     // everything else the pair needs from memory is requested now as well
     u32 hq[4] = {0x400u, 0x400u, 0x400u, 0x400u};      // wave 2: bytes tile_end + 4 lane + 0..3 (0x400 past the block)
     u32 qb = 0, qa = 0;
@@ -687,27 +692,15 @@ __device__ __forceinline__ bool rle3_emit8k(R8Fast &sh, const RleBlk &blk, const
     if (tid == 0 && kp > 0) qb = *(const u32 *)(blk.in + tile_start - 4);          // bytes -4 .. -1
     if (tid == RLE_THREADS - 1) qa = *(const u32 *)(blk.in + tile_end);            // the four bytes after the pair
     if (lane == 63) sh.wlast[wv] = w[7] >> 24;
-    u32 pb0 = 0x100u;                                  // lane 0: the byte before the pair (0x100: none)
     if (tid == 0) {
         u32 e0 = 0;
-        if (kp > 0) {
-            e0 = (zmask4(qb ^ (qb << 8)) >> 1) << 29;  // E of positions -3, -2, -1 in bits 29..31
-            pb0 = qb >> 24;
-        }
+        if (kp > 0) e0 = (zmask4(qb ^ (qb << 8)) >> 1) << 29;      // E of positions -3, -2, -1 in bits 29..31
         sh.E[0] = e0;
         sh.slow = 0;
     }
     if (tid == RLE_THREADS - 1) sh.E[RLE_THREADS + 1] = zmask4(qa ^ ((qa << 8) | (w[7] >> 24))) & 7u;
     lds_barrier();
-    u32 pb = (u32)__shfl_up((int)(w[7] >> 24), 1, 64);
-    if (lane == 0) pb = wv ? sh.wlast[wv - 1] : pb0;
-    u32 E = zmask4(w[0] ^ ((w[0] << 8) | (pb & 0xFFu))), Z = zmask4(w[0]);
-#pragma unroll
-    for (int i = 1; i < 8; ++i) {
-        E |= zmask4(w[i] ^ __builtin_amdgcn_alignbit(w[i], w[i - 1], 24)) << (4 * i);
-        Z |= zmask4(w[i]) << (4 * i);
-    }
-    if (pb > 0xFFu) E &= ~1u;
+    const u32 E = mz.x, Z = mz.y;                       // "equals the byte before" and "is zero" per byte: from the first pass
     sh.E[tid + 1] = E;
     const u32 H = ~E;                                   // run heads
     const u64 hm = __ballot(H != 0);
@@ -771,19 +764,21 @@ __device__ __forceinline__ bool rle3_emit8k(R8Fast &sh, const RleBlk &blk, const
     // ---- tokens into the image, which is aligned like the output address ---------------------------------------
     const u32 shift = (u32)((uintptr_t)(blk.out + G) & 15u);
     const u32 p0 = (u32)offsetof(R8Fast, img) + shift + off;
-    {   // every byte is written somewhere, no branches: a literal at the running position, the symbol of a triple in the
-        // triple's second place, a byte that emits nothing into the lane's dump word
+    {   // every byte is written somewhere, no branches: a literal at the running position p, the symbol of a triple in
+        // the triple's second place, and a byte that emits nothing ALSO at p — where the lane's next token will
+        // overwrite it (the symbol and, below, the 0 and the count of a triple are written later in program order) —
+        // unless no token follows in this lane (p has reached the lane's end): then into the lane's dump word
         u32 p = p0;
+        const u32 p_end = p0 + tot;
         const u32 dump = (u32)offsetof(R8Fast, dump) + 4u * (u32)tid;
 #pragma unroll
         for (int q = 0; q < R8_BPL / 4; ++q) {
             const u32 ft = nibf(T3, q), sz = nibf(Lit, q) | ft | (ft << 1);      // per byte: 1 at a literal, 3 at a triple head
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const u32 at = (Lit >> (4 * q + c)) & 1u ? p : ((T3 >> (4 * q + c)) & 1u ? p + 1 : dump);
-                smem[at] = (u8)(w[q] >> (8 * c));
-                p += (sz >> (8 * c)) & 0xFFu;
-            }
+            u32 a;
+            a = add_byte<0>(p, ft); smem[a < p_end ? a : dump] = (u8)w[q];         p = add_byte<0>(p, sz);
+            a = add_byte<1>(p, ft); smem[a < p_end ? a : dump] = (u8)(w[q] >> 8);  p = add_byte<1>(p, sz);
+            a = add_byte<2>(p, ft); smem[a < p_end ? a : dump] = (u8)(w[q] >> 16); p = add_byte<2>(p, sz);
+            a = add_byte<3>(p, ft); smem[a < p_end ? a : dump] = (u8)(w[q] >> 24); p = add_byte<3>(p, sz);
         }
     }
     for (u32 t = T3; t; t &= t - 1) {                   // triples: the lane's heads in order
@@ -887,14 +882,17 @@ __device__ __forceinline__ bool rle3_first8k(R8Fast &sh, const RleBlk &blk, cons
     lds_barrier();
     u32 pb = (u32)__shfl_up((int)(w[7] >> 24), 1, 64);
     if (lane == 0) pb = wv ? sh.wlast[wv - 1] : pb0;
-    u32 E = zmask4(w[0] ^ ((w[0] << 8) | (pb & 0xFFu))), Z = zmask4(w[0]);
+    u32 dif[8];                                         // every byte xor the byte before it
+    dif[0] = w[0] ^ ((w[0] << 8) | (pb & 0xFFu));
 #pragma unroll
-    for (int i = 1; i < 8; ++i) {
-        E |= zmask4(w[i] ^ __builtin_amdgcn_alignbit(w[i], w[i - 1], 24)) << (4 * i);
-        Z |= zmask4(w[i]) << (4 * i);
-    }
+    for (int i = 1; i < 8; ++i) dif[i] = w[i] ^ __builtin_amdgcn_alignbit(w[i], w[i - 1], 24);
+    u32 E = zmask32(dif);
+    const u32 Z = zmask32(in.w);
     if (pb > 0xFFu) E &= ~1u;
     sh.E[tid + 1] = E;
+    // the two masks are a third of this pass's arithmetic and the emit pass needs the same ones: 8 bytes per 32 of
+    // input through the workspace cost it less than computing them again
+    gstore<uint2>(blk.masks + (size_t)kp * RLE_THREADS + tid, make_uint2(E, Z));
     const u32 H = ~E;
     const u64 hm = __ballot(H != 0);
     const u32 transparent = (u32)__builtin_popcountll((unsigned long long)__ballot(E == 0xFFFFFFFFu));
@@ -999,13 +997,14 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
         ndesc += t;
         if (t > max_tiles) max_tiles = (u32)t;
     }
-    // workspace: [G: output offset per tile] [RleBlk] [tsum] [R] [T]
+    // workspace: [G: output offset per tile] [RleBlk] [tsum] [R] [T] [masks]
     size_t off = 0;
     const size_t o_sum = off; off += ndesc * 8; off = (off + 15) & ~(size_t)15;
     const size_t o_blk = off; off += (size_t)nblocks * sizeof(RleBlk); off = (off + 15) & ~(size_t)15;
     const size_t o_tsum = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;
     const size_t o_R = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;
     const size_t o_T = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;
+    const size_t o_M = off; off += ndesc * (RLE_TILE / 32) * sizeof(uint2);      // {E, Z} per 32 bytes: n / 4
     int rc = batch_reserve(bt, st, off);
     if (rc) return rc;
     u8 *ws = (u8 *)bt->d_ws;
@@ -1024,6 +1023,7 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
         e.n_tiles = (u32)ceil_div_u64(h_in_n[b], RLE_TILE);
         e.ticket = (u32)b;
         e.pad = 0;
+        e.masks = (uint2 *)(ws + o_M) + (size_t)dbase * (RLE_TILE / 32);
         dbase += e.n_tiles;
     }
     HIP_TRY(hipMemsetAsync(d_out_n, 0, (size_t)nblocks * 8, st));      // empty blocks: size 0
