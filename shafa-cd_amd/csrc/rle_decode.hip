@@ -317,13 +317,19 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
         }
         if (len && lbase >= done && lbase + len <= nxt) {
             const u32 p0 = img_off + (lbase - done);
-            {   // literals: running position, one byte write each; the other bytes go to a dump word (no branches)
+            {   // literals: one byte write each at the running position p, no branches.  The bytes of a triple are written
+                // at p as well: p is then the start of a run (filled below, later in program order) or the place of
+                // the lane's next literal, which overwrites them — unless nothing follows in this lane (p has reached
+                // the end of its output): those go to the lane's dump word
                 u32 p = p0;
+                const u32 p_end = p0 + len;
                 const u32 dump = (u32)offsetof(RldShared, dump) + 4u * (u32)tid;
 #pragma unroll
-                for (int j = 0; j < RLD_BPL; ++j) {
-                    smem[(Lm >> j) & 1u ? p : dump] = (u8)(w[j >> 2] >> (8 * (j & 3)));
-                    p += (lenw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                for (int i = 0; i < RLD_BPL / 4; ++i) {
+                    smem[p < p_end ? p : dump] = (u8)w[i];          p = add_byte<0>(p, lenw[i]);
+                    smem[p < p_end ? p : dump] = (u8)(w[i] >> 8);   p = add_byte<1>(p, lenw[i]);
+                    smem[p < p_end ? p : dump] = (u8)(w[i] >> 16);  p = add_byte<2>(p, lenw[i]);
+                    smem[p < p_end ? p : dump] = (u8)(w[i] >> 24);  p = add_byte<3>(p, lenw[i]);
                 }
             }
             u32 g = 0;                                  // bytes of the runs so far
