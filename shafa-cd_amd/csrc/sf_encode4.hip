@@ -31,10 +31,13 @@
 #include "common.hpp"
 #include "internal.hpp"
 
+int g_sfe4_wide = 1;                                   // 0: always the 256-lane form (A/B and tests)
+
 namespace {
 
-constexpr int E4_THREADS = 256;
-constexpr int E4_TILE = 8192;                          // symbols per tile
+// A workgroup has NT = 256 or 512 lanes and a tile is four rows of NT octs: 8 KiB or 16 KiB of symbols.  The wide form
+// (launches whose three windows fit 64 KiB of LDS: Lmax <= 10) halves what wave 0's chain work costs per byte and
+// spreads the window stores over seven waves instead of three.
 constexpr int E4_GUARD = 8;                            // dwords in front of the window: an oct writes up to 4 dwords before its last one
 constexpr u32 E4_NONE = 0xFFFFFFFFu;
 #ifndef E4_WPS
@@ -55,7 +58,7 @@ __device__ unsigned long long e4_stamp_buf[2048 * 4 * 8];
 
 struct E4Static {
     u64 lut[256];                // {code (low dword), len (high dword)}; a symbol without a code: len = 1 << 16
-    u32 wtot[16];                // [row][wave] bit totals, i.e. in stream order
+    u32 wtot[32];                // [row][wave] bit totals, i.e. in stream order (4 rows x up to 8 waves)
     u64 prefix;                  // bits before the pending tile
     u32 tick;                    // next ticket of the block (broadcast)
     u32 pad;
@@ -142,15 +145,16 @@ struct TileIn {
 // A FULL tile.  8 bytes per lane and row: in the instruction that places "the oct of row k" neighbouring lanes hold
 // neighbouring octs, so a 32-lane LDS group spans ~1.6 dwords per lane instead of ~3.3 with 16 bytes per lane.
 // Uniform base + 32-bit lane offset: the loads take the SGPR-base form, no 64-bit address registers.
+template <int NT>
 __device__ __forceinline__ void load_tile(const u8 *in, u32 tile, int tid, TileIn &t)
 {
-    const u8 *tb = in + (u64)tile * E4_TILE;
+    const u8 *tb = in + (u64)tile * (32u * NT);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) t.v[k] = gload_nt_off<uint2>(tb, (u32)k * 2048u + (u32)tid * 8u);
+    for (int k = 0; k < 4; ++k) t.v[k] = gload_nt_off<uint2>(tb, (u32)k * (8u * NT) + (u32)tid * 8u);
 }
 
 // one tile's look-ups, groups and lane scans; returns the packed inclusive lane prefixes of rows (0,1) and (2,3)
-template <bool SAFE, int NW, bool L16>
+template <bool SAFE, int NW, bool L16, int NT>
 __device__ __forceinline__ void tile_octs(const u64 *lut, const TileIn &in, u32 keep_base, int tid, Oct (&oct)[4], u32 (&incl)[2],
                                           u32 &absent)
 {
@@ -159,7 +163,7 @@ __device__ __forceinline__ void tile_octs(const u64 *lut, const TileIn &in, u32 
     for (int k = 0; k < 4; ++k) {
         u32 drop = 0;
         if (SAFE) {                                    // keep_base = symbols of the tile that exist
-            const u32 idx = (u32)k * 2048u + (u32)tid * 8u;
+            const u32 idx = (u32)k * (8u * NT) + (u32)tid * 8u;
             const u32 keep = idx >= keep_base ? 0u : (keep_base - idx >= 8u ? 8u : keep_base - idx);
             drop = (0xFFu << keep) & 0xFFu;
         }
@@ -174,19 +178,27 @@ __device__ __forceinline__ void tile_octs(const u64 *lut, const TileIn &in, u32 
     incl[1] = dpp_scan_add(oct[2].ll | (oct[3].ll << 16));
 }
 
-// the 16 (row, wave) totals in stream order -> this wave's four row offsets and the tile total: one 16-lane DPP scan
+// the (row, wave) totals in stream order -> this wave's four row offsets and the tile total: one DPP scan
+// (NWV = 4: 16 totals, a scan inside the 16-lane DPP rows; NWV = 8: 32 totals, the wave-wide scan)
+template <int NWV>
 __device__ __forceinline__ u32 tile_offsets(const u32 *wtot, int lane, int wv, u32 (&roff)[4])
 {
-    const u32 tot = wtot[lane & 15];
-    u32 sc = tot;
-    sc += (u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x111, 0xf, 0xf, false);   // row_shr:1
-    sc += (u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x112, 0xf, 0xf, false);   // row_shr:2
-    sc += (u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x114, 0xf, 0xf, false);   // row_shr:4
-    sc += (u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x118, 0xf, 0xf, false);   // row_shr:8
+    u32 tot, sc;
+    if (NWV == 4) {
+        tot = wtot[lane & 15];
+        sc = tot;
+        sc += (u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x111, 0xf, 0xf, false);   // row_shr:1
+        sc += (u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x112, 0xf, 0xf, false);   // row_shr:2
+        sc += (u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x114, 0xf, 0xf, false);   // row_shr:4
+        sc += (u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x118, 0xf, 0xf, false);   // row_shr:8
+    } else {
+        tot = lane < 4 * NWV ? wtot[lane] : 0u;
+        sc = dpp_scan_add(tot);
+    }
     const u32 ex = sc - tot;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) roff[k] = (u32)__builtin_amdgcn_readlane((int)ex, k * 4 + wv);
-    return (u32)__builtin_amdgcn_readlane((int)sc, 15);
+    for (int k = 0; k < 4; ++k) roff[k] = (u32)__builtin_amdgcn_readlane((int)ex, k * NWV + wv);
+    return (u32)__builtin_amdgcn_readlane((int)sc, 4 * NWV - 1);
 }
 
 // lead bits of a tile that starts at bit B of its block: the last r = B mod 32 bits before it, right-aligned, ORed into
@@ -261,25 +273,27 @@ __device__ __forceinline__ void store_window(const u32 *pwin, u8 *out, u64 out_c
 //     predecessors (earlier tickets) have published theirs unless they lag a whole tile time behind; after barrier A it
 //     publishes tile i's aggregate and requests the window of tile i-1.
 // Two barriers per tile.  A block's ragged remainder (< 8192 symbols) is left to sfe4_tail_kernel.
-template <int NW, bool L16>
-__global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *__restrict__ blks, int nblk, int nconc,
+template <int NW, bool L16, int NT>
+__global__ __launch_bounds__(NT, E4_WPS) void sfe4_kernel(const EncBlk *__restrict__ blks, int nblk, int nconc,
                                                              u64 *__restrict__ desc, u32 *__restrict__ tickets, u32 win_stride)
 {
     __shared__ E4Static sh;
     extern __shared__ __attribute__((aligned(16))) u32 dynwin[];     // three buffers of [E4_GUARD][window dwords]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NWV = NT / 64;                       // waves
+    constexpr u32 TILE = 32u * NT, TSHIFT = NT == 256 ? 13 : 14;        // symbols per tile
     E4_T0();
 
     for (int b = (int)(blockIdx.x % (u32)nconc); b < nblk; b += nconc) {
         const EncBlk *bp = blks + b;
         const u8 *in = bp->in;
-        const u32 nfull = (u32)(bp->n >> 13);          // full tiles; the tile count of the whole block is bp->n_tiles
-        const bool ragged = (bp->n & (E4_TILE - 1)) != 0;
+        const u32 nfull = (u32)(bp->n >> TSHIFT);      // full tiles of this kernel's size
+        const bool ragged = (bp->n & (TILE - 1)) != 0;
         u64 *bdesc = desc + bp->desc_base;
         u32 *tick = tickets + bp->ticket;
         __syncthreads();                               // the previous block's table and windows are no longer in use
-        sh.lut[tid] = gload<u64>((const u64 *)bp->lut + tid);
+        if (tid < 256) sh.lut[tid] = gload<u64>((const u64 *)bp->lut + tid);
         if (tid == 0) sh.tick = atomicAdd(tick, 3u);
         __syncthreads();
         // tickets are four deep so that no atomic's round trip is ever waited for: `cur` is processed, `nxt` is being
@@ -289,8 +303,8 @@ __global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *
         u32 req = E4_NONE;
         if (tid == 0) req = atomicAdd(tick, 1u);
         TileIn cin, nin, nin2;                         // inputs are requested two tiles ahead
-        load_tile(in, cur, tid, cin);
-        if (nxt < nfull) load_tile(in, nxt, tid, nin);
+        load_tile<NT>(in, cur, tid, cin);
+        if (nxt < nfull) load_tile<NT>(in, nxt, tid, nin);
         // wave 0: the descriptor window and the 32 symbols in front of the tile computed one iteration ago (q) are requested
         // after barrier A and used at the top of the next iteration, when that tile is p: one variable each, never copied
         // (a copy of a loaded register is a wait for the load)
@@ -339,7 +353,7 @@ __global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *
 
             // ---- this tile: zero its window, look up, group, scan ------------------------------------------------
             if (cur_ok) {
-                for (u32 i = (u32)tid; i < ((dirty[buf] + 3u) >> 2) + 1u; i += E4_THREADS)
+                for (u32 i = (u32)tid; i < ((dirty[buf] + 3u) >> 2) + 1u; i += NT)
                     ((uint4 *)win)[(int)i - 1] = make_uint4(0, 0, 0, 0);              // from dword -4: the lead word is win[-1]
             }
             // the input registers move up one place here, not at the end of the iteration: a wave that loads and stores
@@ -347,19 +361,19 @@ __global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *
             // order with respect to each other), and here the window stores of the previous iteration are oldest
             if (rotate_in) { cin = nin; nin = nin2; }
             rotate_in = true;
-            if (cur_ok && nn < nfull) load_tile(in, nn, tid, nin2);
+            if (cur_ok && nn < nfull) load_tile<NT>(in, nn, tid, nin2);
             // the next ticket: unconditional (a few tickets past the block's end are harmless), and issued only now, after
             // the wave's one drain of the iteration: the returned value is not touched before the next iteration's top
             if (tid == 0) req = atomicAdd(tick, 1u);
             if (cur_ok) {
                 u32 absent = 0;
-                tile_octs<false, NW, L16>(sh.lut, cin, 0u, tid, c_oct, incl, absent);
+                tile_octs<false, NW, L16, NT>(sh.lut, cin, 0u, tid, c_oct, incl, absent);
                 if (absent) set_error(bp->err, SHAFA_FILE_UNRECOGNIZABLE);   // data symbol without a code (output undefined, in bounds)
                 if (lane == 63) {
                     sh.wtot[wv] = incl[0] & 0xFFFFu;
-                    sh.wtot[4 + wv] = incl[0] >> 16;
-                    sh.wtot[8 + wv] = incl[1] & 0xFFFFu;
-                    sh.wtot[12 + wv] = incl[1] >> 16;
+                    sh.wtot[NWV + wv] = incl[0] >> 16;
+                    sh.wtot[2 * NWV + wv] = incl[1] & 0xFFFFu;
+                    sh.wtot[3 * NWV + wv] = incl[1] >> 16;
                 }
             }
             E4_T(1);
@@ -370,11 +384,11 @@ __global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *
             // the next iteration) has to wait for these stores, so they go out as early as the iteration allows
             if (wv != 0 && have_p)
                 store_window(pwin, bp->out, bp->out_cap, bp->err, sh.prefix, p_T, !ragged && p_tile == nfull - 1, tid - 64,
-                             E4_THREADS - 64);
+                             NT - 64);
             u32 c_T = 0;
             if (cur_ok) {
                 u32 roff[4];
-                c_T = tile_offsets(sh.wtot, lane, wv, roff);
+                c_T = tile_offsets<NWV>(sh.wtot, lane, wv, roff);
                 if (tid == 0) {
                     if (cur == 0) {
                         desc_store(bdesc, DESC_PREFIX, c_T);
@@ -391,7 +405,7 @@ __global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *
                 if (have_q && q_tile > 0) {            // descriptor window and leading symbols of the tile computed one iteration ago
                     const int idx = (int)q_tile - 1 - lane;
                     first_w = desc_load(bdesc + (idx > 0 ? idx : 0));
-                    if (lane < 32) pv_w = gload_off<u8>(in + (u64)q_tile * E4_TILE - 32, 31u - (u32)lane);
+                    if (lane < 32) pv_w = gload_off<u8>(in + (u64)q_tile * TILE - 32, 31u - (u32)lane);
                 }
             }
             E4_T(5);
@@ -410,10 +424,10 @@ __global__ __launch_bounds__(E4_THREADS, E4_WPS) void sfe4_kernel(const EncBlk *
     E4_TEND();
 }
 
-// The ragged remainder (< 8192 symbols) of every block whose size is not a multiple of the tile: one workgroup per block,
+// The ragged remainder (less than a tile) of every block whose size is not a multiple of the tile: one workgroup per block,
 // launched after sfe4_kernel, so the prefix of the last full tile is final.
-template <int NW, bool L16>
-__global__ __launch_bounds__(E4_THREADS) void sfe4_tail_kernel(const EncBlk *__restrict__ blks, const u64 *__restrict__ desc,
+template <int NW, bool L16, int NT>
+__global__ __launch_bounds__(NT) void sfe4_tail_kernel(const EncBlk *__restrict__ blks, const u64 *__restrict__ desc,
                                                                u32 win_stride)
 {
     __shared__ E4Static sh;
@@ -421,17 +435,19 @@ __global__ __launch_bounds__(E4_THREADS) void sfe4_tail_kernel(const EncBlk *__r
     u32 *win = dynwin + E4_GUARD;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NWV = NT / 64;
+    constexpr u32 TILE = 32u * NT, TSHIFT = NT == 256 ? 13 : 14;
     const EncBlk blk = blks[blockIdx.x];
-    const u32 rem = (u32)(blk.n & (E4_TILE - 1));
+    const u32 rem = (u32)(blk.n & (TILE - 1));
     if (!rem) return;
-    const u32 nfull = (u32)(blk.n >> 13);
-    const u8 *tb = blk.in + (u64)nfull * E4_TILE;
-    sh.lut[tid] = gload<u64>((const u64 *)blk.lut + tid);
-    for (u32 i = (u32)tid; i < win_stride / 4; i += E4_THREADS) ((uint4 *)dynwin)[i] = make_uint4(0, 0, 0, 0);
+    const u32 nfull = (u32)(blk.n >> TSHIFT);
+    const u8 *tb = blk.in + (u64)nfull * TILE;
+    if (tid < 256) sh.lut[tid] = gload<u64>((const u64 *)blk.lut + tid);
+    for (u32 i = (u32)tid; i < win_stride / 4; i += NT) ((uint4 *)dynwin)[i] = make_uint4(0, 0, 0, 0);
     TileIn in;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const u32 idx = (u32)k * 2048u + (u32)tid * 8u;
+        const u32 idx = (u32)k * (8u * NT) + (u32)tid * 8u;
         u32 w[2] = {0, 0};
         if (idx + 8 <= rem) {
             const uint2 x = gload<uint2>(tb + idx);
@@ -447,29 +463,29 @@ __global__ __launch_bounds__(E4_THREADS) void sfe4_tail_kernel(const EncBlk *__r
     __syncthreads();
     Oct oct[4];
     u32 incl[2], absent = 0, roff[4];
-    tile_octs<true, NW, L16>(sh.lut, in, rem, tid, oct, incl, absent);
+    tile_octs<true, NW, L16, NT>(sh.lut, in, rem, tid, oct, incl, absent);
     if (absent) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
     if (lane == 63) {
         sh.wtot[wv] = incl[0] & 0xFFFFu;
-        sh.wtot[4 + wv] = incl[0] >> 16;
-        sh.wtot[8 + wv] = incl[1] & 0xFFFFu;
-        sh.wtot[12 + wv] = incl[1] >> 16;
+        sh.wtot[NWV + wv] = incl[0] >> 16;
+        sh.wtot[2 * NWV + wv] = incl[1] & 0xFFFFu;
+        sh.wtot[3 * NWV + wv] = incl[1] >> 16;
     }
     if (wv == 0 && ((u32)B & 31u) && nfull > 0) lead_bits(sh.lut, win, pv, (u32)B & 31u, lane);
     __syncthreads();
-    const u32 T = tile_offsets(sh.wtot, lane, wv, roff);
+    const u32 T = tile_offsets<NWV>(sh.wtot, lane, wv, roff);
 #pragma unroll
     for (int k = 0; k < 4; ++k) place<NW>(win, oct[k], roff[k] + ((incl[k >> 1] >> (16 * (k & 1))) & 0xFFFFu));
     __syncthreads();
-    store_window(win, blk.out, blk.out_cap, blk.err, B, T, true, tid, E4_THREADS);
+    store_window(win, blk.out, blk.out_cap, blk.err, B, T, true, tid, NT);
     if (tid == 0) gstore<u64>(blk.out_n, (B + T + 7) >> 3);
 }
 
-template <int NW, bool L16>
-int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool any_ragged)
+template <int NW, bool L16, int NT>
+int e4_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool any_ragged)
 {
     static int wgs_by_lmax[17], cus = 0;
-    const u32 win_stride = ((u32)E4_GUARD + (u32)(((size_t)E4_TILE * lmax) >> 5) + 8u + 3u) & ~3u;     // dwords per buffer
+    const u32 win_stride = ((u32)E4_GUARD + (u32)(((size_t)(32 * NT) * lmax) >> 5) + 8u + 3u) & ~3u;   // dwords per buffer
     const size_t dyn = (size_t)win_stride * 3 * 4;
     if (!wgs_by_lmax[lmax]) {
         int dev = 0, occ = 0;
@@ -477,7 +493,7 @@ int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 
         HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         cus = prop.multiProcessorCount;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)sfe4_kernel<NW, L16>, E4_THREADS, dyn));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)sfe4_kernel<NW, L16, NT>, NT, dyn));
         wgs_by_lmax[lmax] = occ < 1 ? 1 : (occ > 6 ? 6 : occ);   // residency is a matter of speed only (tickets), 6 = what the registers allow
     }
     const int wgs_per_cu = wgs_by_lmax[lmax];
@@ -486,12 +502,21 @@ int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 
     int nconc = count < target ? count : target;
     int per = target / nconc;
     if (per < 1) per = 1;
-    hipLaunchKernelGGL((sfe4_kernel<NW, L16>), dim3((u32)(nconc * per)), dim3(E4_THREADS), dyn, st, dblk, count, nconc, d_desc, d_tickets,
+    hipLaunchKernelGGL((sfe4_kernel<NW, L16, NT>), dim3((u32)(nconc * per)), dim3(NT), dyn, st, dblk, count, nconc, d_desc, d_tickets,
                        win_stride);
     if (any_ragged)
-        hipLaunchKernelGGL((sfe4_tail_kernel<NW, L16>), dim3((u32)count), dim3(E4_THREADS), (size_t)win_stride * 4, st, dblk,
+        hipLaunchKernelGGL((sfe4_tail_kernel<NW, L16, NT>), dim3((u32)count), dim3(NT), (size_t)win_stride * 4, st, dblk,
                            (const u64 *)d_desc, win_stride);
     return SHAFA_SUCCESS;
+}
+
+// the wide form when its three windows (and the 2 KiB of static LDS) fit the 64 KiB a workgroup may use
+template <int NW, bool L16>
+int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool any_ragged)
+{
+    const size_t wide = (size_t)((((u32)E4_GUARD + (u32)(((size_t)16384 * lmax) >> 5) + 8u + 3u) & ~3u)) * 3 * 4 + sizeof(E4Static) + 64;
+    if (g_sfe4_wide && wide <= 65536) return e4_launch_nt<NW, L16, 512>(st, dblk, count, d_desc, d_tickets, lmax, any_ragged);
+    return e4_launch_nt<NW, L16, 256>(st, dblk, count, d_desc, d_tickets, lmax, any_ragged);
 }
 
 }  // namespace
