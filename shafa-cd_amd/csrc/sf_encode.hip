@@ -206,13 +206,13 @@ __global__ __launch_bounds__(ENC_THREADS) void sf_encode_generic(const EncBlk *_
 // host launcher
 // ------------------------------------------------------------------------------------------------
 void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 *d_tile_bits, u64 *d_tile_off, bool lut64);
-int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool any_ragged);
+int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool ragged8, bool ragged16);
 
 // A launch with at least this many class-1 blocks takes the one-pass encoder: every block is its own chain, and with this
 // many chains (<= ~10 workgroups per block) a tile's look-back stays inside one 64-entry descriptor window.  Measured
 // on 64 MiB Zipf blocks, GiB/s one-pass vs count/scan/pack: 16 blocks 588 / 1240, 32: 1112 / 1298, 64: 1407 / 1457,
 // 128: 1900 / 1632 (sf_encode4.hip).
-static int g_sfe4_min_blocks = 80;
+static int g_sfe4_min_blocks = 24;
 void sfenc_configure(int sfe4_min_blocks) { g_sfe4_min_blocks = sfe4_min_blocks; }
 
 static u32 code_value(const shafa_code_table &t, int s)
@@ -333,9 +333,12 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     u32 *dtick = (u32 *)(ws + o_tick);
     if (cls_count[1]) {
         if (one_pass) {
-            bool any_ragged = false;
-            for (int b = 0; b < nblocks; ++b) any_ragged = any_ragged || (cls[b] == 1 && (h_in_n[b] & 8191));
-            if ((rc = sfenc4_launch(st, dblk + cls_first[1], cls_count[1], ddesc, dtick, lmax1, any_ragged))) return rc;
+            bool ragged8 = false, ragged16 = false;    // a block has a remainder after its full 8 KiB / 16 KiB tiles
+            for (int b = 0; b < nblocks; ++b) {
+                ragged8 = ragged8 || (cls[b] == 1 && (h_in_n[b] & 8191));
+                ragged16 = ragged16 || (cls[b] == 1 && (h_in_n[b] & 16383));
+            }
+            if ((rc = sfenc4_launch(st, dblk + cls_first[1], cls_count[1], ddesc, dtick, lmax1, ragged8, ragged16))) return rc;
         } else sfenc3_launch(st, dblk + cls_first[1], cls_count[1], max_tiles[1], (u32 *)(ws + o_tbits), ddesc, false);
     }
     if (cls_count[2]) sfenc3_launch(st, dblk + cls_first[2], cls_count[2], max_tiles[2], (u32 *)(ws + o_tbits), ddesc, true);

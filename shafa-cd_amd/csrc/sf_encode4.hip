@@ -36,7 +36,7 @@ int g_sfe4_wide = 1;                                   // 0: always the 256-lane
 namespace {
 
 // A workgroup has NT = 256 or 512 lanes and a tile is four rows of NT octs: 8 KiB or 16 KiB of symbols.  The wide form
-// (launches whose three windows fit 64 KiB of LDS: Lmax <= 10) halves what wave 0's chain work costs per byte and
+// (launches where two such workgroups fit a CU's LDS: Lmax <= 12) halves what wave 0's chain work costs per byte and
 // spreads the window stores over seven waves instead of three.
 constexpr int E4_GUARD = 8;                            // dwords in front of the window: an oct writes up to 4 dwords before its last one
 constexpr u32 E4_NONE = 0xFFFFFFFFu;
@@ -493,6 +493,8 @@ int e4_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32
         HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         cus = prop.multiProcessorCount;
+        if (dyn > 65536)                               // more than the default 64 KiB of dynamic LDS per workgroup
+            HIP_TRY(hipFuncSetAttribute((const void *)sfe4_kernel<NW, L16, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)sfe4_kernel<NW, L16, NT>, NT, dyn));
         wgs_by_lmax[lmax] = occ < 1 ? 1 : (occ > 6 ? 6 : occ);   // residency is a matter of speed only (tickets), 6 = what the registers allow
     }
@@ -510,13 +512,13 @@ int e4_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32
     return SHAFA_SUCCESS;
 }
 
-// the wide form when its three windows (and the 2 KiB of static LDS) fit the 64 KiB a workgroup may use
+// the wide form when two workgroups of it (three windows + 2 KiB of static LDS each) fit the CU's 160 KiB: Lmax <= 12
 template <int NW, bool L16>
-int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool any_ragged)
+int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool ragged8, bool ragged16)
 {
     const size_t wide = (size_t)((((u32)E4_GUARD + (u32)(((size_t)16384 * lmax) >> 5) + 8u + 3u) & ~3u)) * 3 * 4 + sizeof(E4Static) + 64;
-    if (g_sfe4_wide && wide <= 65536) return e4_launch_nt<NW, L16, 512>(st, dblk, count, d_desc, d_tickets, lmax, any_ragged);
-    return e4_launch_nt<NW, L16, 256>(st, dblk, count, d_desc, d_tickets, lmax, any_ragged);
+    if (g_sfe4_wide && 2 * wide <= 160 * 1024) return e4_launch_nt<NW, L16, 512>(st, dblk, count, d_desc, d_tickets, lmax, ragged16);
+    return e4_launch_nt<NW, L16, 256>(st, dblk, count, d_desc, d_tickets, lmax, ragged8);
 }
 
 }  // namespace
@@ -531,10 +533,10 @@ extern "C" int shafa_e4_read_stamps(unsigned long long *dst, int n)
 // launched from sfenc_launch (sf_encode.hip) for blocks whose codes are <= 16 bits when the launch holds enough blocks
 // to keep every chain short; desc (one u64 per tile) and tickets (one u32 per block) are zeroed by the caller;
 // tables are 256 x u64 {code, len}
-int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool any_ragged)
+int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool ragged8, bool ragged16)
 {
-    if (lmax <= 8) return e4_launch_t<3, false>(st, dblk, count, d_desc, d_tickets, lmax, any_ragged);
-    if (lmax <= 12) return e4_launch_t<4, false>(st, dblk, count, d_desc, d_tickets, lmax, any_ragged);
-    if (lmax <= 15) return e4_launch_t<5, false>(st, dblk, count, d_desc, d_tickets, lmax, any_ragged);
-    return e4_launch_t<5, true>(st, dblk, count, d_desc, d_tickets, lmax, any_ragged);
+    if (lmax <= 8) return e4_launch_t<3, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged8, ragged16);
+    if (lmax <= 12) return e4_launch_t<4, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged8, ragged16);
+    if (lmax <= 15) return e4_launch_t<5, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged8, ragged16);
+    return e4_launch_t<5, true>(st, dblk, count, d_desc, d_tickets, lmax, ragged8, ragged16);
 }

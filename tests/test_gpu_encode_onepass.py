@@ -14,7 +14,7 @@ def one_pass(shafa):
     shafa.lib().shafa_hip_init(0)
     shafa.set_option("sf_encode_one_pass_min_blocks", 1)
     yield
-    shafa.set_option("sf_encode_one_pass_min_blocks", 80)
+    shafa.set_option("sf_encode_one_pass_min_blocks", 24)
 
 
 def run_batch(shafa, oracle, blocks, tables, caps=None, expect_err=None):
@@ -87,8 +87,16 @@ def test_one_pass_matches_oracle_ragged_sizes(shafa, oracle, one_pass):
     run_batch(shafa, oracle, blocks, tables)
 
 
+def test_one_pass_blocks_of_odd_multiples_of_8_kib(shafa, oracle, one_pass):
+    """Every block is an odd multiple of 8 KiB: no remainder for the 8 KiB tiles of the 256-lane kernel, half a tile of
+    remainder for the 16 KiB tiles of the 512-lane one (the tail kernel must be launched for exactly that form)."""
+    sizes = [8192 * (2 * i + 1) for i in range(12)] + [8192, 8192 * 127]
+    blocks, tables = zipf_blocks(shafa, oracle, sizes, seed0=4000)
+    run_batch(shafa, oracle, blocks, tables)
+
+
 def test_one_pass_and_three_kernel_agree_on_a_big_launch(shafa, oracle):
-    """128 blocks of 0.5 MiB + ragged tails through the default dispatch (one pass: >= 80 blocks)."""
+    """128 blocks of 0.5 MiB + ragged tails through the default dispatch (one pass: >= 24 blocks)."""
     sizes = [(1 << 19) + 13 * i for i in range(128)]
     blocks, tables = zipf_blocks(shafa, oracle, sizes, seed0=500)
     shafa.lib().shafa_hip_init(0)
@@ -97,7 +105,7 @@ def test_one_pass_and_three_kernel_agree_on_a_big_launch(shafa, oracle):
     try:
         run_batch(shafa, oracle, blocks, tables)
     finally:
-        shafa.set_option("sf_encode_one_pass_min_blocks", 80)
+        shafa.set_option("sf_encode_one_pass_min_blocks", 24)
 
 
 @pytest.mark.parametrize("kind", ["uniform", "two", "few", "lmax16", "lmax13", "single_long_chain"])
