@@ -8,7 +8,7 @@
 // here with a chained scan whose waiting never reaches the critical path:
 //
 //   * workgroups are persistent and stick to one block at a time (block = blockIdx % nconc, then + nconc): the
-//     block's look-up table is loaded once, and with >= 96 blocks per launch every block is a separate chain with
+//     block's look-up table is loaded once, and with many blocks per launch every block is a separate chain with
 //     only a handful of tiles in flight, so a look-back is one 64-entry window;
 //   * tiles of a block are handed out by a per-block ticket (atomicAdd), requested three iterations ahead: a tile's
 //     predecessors were always taken by workgroups that are running, so the chain cannot deadlock whatever part
@@ -46,10 +46,10 @@ constexpr u32 E4_NONE = 0xFFFFFFFFu;
 
 #ifdef E4_STAMPS
 // diagnostic build only (tools/dbg): per-wave cycle totals of the phases of an iteration
-__device__ unsigned long long e4_stamp_buf[2048 * 4 * 8];
+__device__ unsigned long long e4_stamp_buf[2048 * 8 * 8];
 #define E4_T0() unsigned long long _t_prev = __builtin_amdgcn_s_memtime(), _t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define E4_T(ph) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); _t_acc[ph] += _t - _t_prev; _t_prev = _t; } while (0)
-#define E4_TEND() do { if (lane == 0) for (int _q = 0; _q < 8; ++_q) e4_stamp_buf[((blockIdx.x & 2047) * 4 + wv) * 8 + _q] = _t_acc[_q]; } while (0)
+#define E4_TEND() do { if (lane == 0) for (int _q = 0; _q < 8; ++_q) e4_stamp_buf[((blockIdx.x & 2047) * 8 + wv) * 8 + _q] = _t_acc[_q]; } while (0)
 #else
 #define E4_T0()
 #define E4_T(ph)
