@@ -245,6 +245,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tiles(const DecBlk *__restric
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];   // 256 * R bytes of maps + 256 entries
     __shared__ u8 segmap[8 * 32], segent[8];
+    if (dp_skipped_early(blks + blockIdx.x)) return;    // the block's speculative entries verified
     const DecBlk blk = blks[blockIdx.x];
     u8 *maps = smem;
     u8 *ent = smem + (size_t)R * DEC_THREADS;
@@ -580,6 +581,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_sync32(const DecBlk *__restri
 {
     constexpr u32 R = 32;
     __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + R * DEC_THREADS + (1 << LEN_MAXK) + LONG32_BYTES + 4 * R + 64];
+    if (dp_skipped_early(blks + blockIdx.y)) return;    // the block's speculative entries verified
     const DecBlk blk = blks[blockIdx.y];
     if (blockIdx.x * tpw >= blk.n_tiles) return;
     u32 *data = (u32 *)smem;
@@ -671,6 +673,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_countfsm32(const DecBlk *__re
 {
     constexpr u32 R = 32;
     __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + R * DEC_THREADS + 16384 + 2048 + 4 * R + 16 + DEC_THREADS + 64];
+    if (dp_skipped_early(blks + blockIdx.y)) return;    // the block's speculative entries verified
     const DecBlk blk = blks[blockIdx.y];
     if (blockIdx.x * tpw >= blk.n_tiles) return;
     u32 *data = (u32 *)smem;
@@ -1211,10 +1214,20 @@ struct SpecWin {
 // started on the way.  tab: [total bits | codes << 4 of the whole codes in a K1-bit window] then [length of the window's
 // first code], 1 << K1 bytes each.
 // LAST: the stream ends at bit address `qlimit` (may lie in front of q); a code that does not end inside it is not a symbol.
-template <bool LAST>
-__device__ __forceinline__ void spec_walk(const lds_u8 *tab, u32 K1, u32 &q, u32 qe, int qlimit, u32 &cnt, SpecWin &sw)
+// LONG (1: codes of up to 16 bits, 2: up to 32): a window whose first code is longer than K1 bits has the entry 0; its
+// length comes from the table of long codes lt (long_code / long_code32) — rare by construction, a divergent branch.
+// entries / exits of a chunk are < 16 (< 32 for LONG == 2)
+template <int LONG> constexpr u32 spec_emask() { return LONG == 2 ? 31u : 15u; }
+
+template <bool LAST, int LONG>
+__device__ __forceinline__ void spec_walk(const lds_u8 *tab, const u16 *lt, u32 K1, u32 &q, u32 qe, int qlimit, u32 &cnt, SpecWin &sw)
 {
     const u32 mask = (1u << K1) - 1u;
+    auto long_len = [&](const u32 qq) -> u32 {          // the code of more than K1 bits at qq (at least 1: the walk must move)
+        const u32 win = __builtin_bitreverse32(sw.at(qq));
+        const u32 l = (LONG == 1 ? long_code(lt, win) : long_code32(lt, win)) >> 8;
+        return l ? l : 1u;
+    };
     if (!LAST) {
         const u32 qk = qe - K1, q0 = q;                 // up to qk the window holds only codes that start before qe
         u32 acc = 0;                                    // sum of the entries = bits walked + 16 * codes: one add a step
@@ -1224,14 +1237,19 @@ __device__ __forceinline__ void spec_walk(const lds_u8 *tab, u32 K1, u32 &q, u32
             const u32 qs = qe - N * K1;
             while (q <= qs) {
                 const u32 w = sw.at(q);
-                u32 used = 0;
+                u32 used = 0, e = 0;
 #pragma unroll
                 for (u32 i = 0; i < N; ++i) {
-                    const u32 e = tab[(w >> used) & mask];
+                    e = tab[(w >> used) & mask];
                     used += e & 15u;
                     acc += e;
                 }
                 q += used;
+                if (LONG && __builtin_expect((e & 15u) == 0u, 0)) {      // a long code stopped the look-ups: it starts at q
+                    const u32 l = long_len(q);
+                    q += l;
+                    acc += l + 16u;
+                }
             }
         };
         if (K1 <= 10) multi(std::integral_constant<u32, 3>{});
@@ -1240,13 +1258,19 @@ __device__ __forceinline__ void spec_walk(const lds_u8 *tab, u32 K1, u32 &q, u32
             const u32 e = tab[sw.at(q) & mask];
             q += e & 15u;
             acc += e;
+            if (LONG && __builtin_expect((e & 15u) == 0u, 0)) {
+                const u32 l = long_len(q);
+                q += l;
+                acc += l + 16u;
+            }
         }
         cnt += (acc - (q - q0)) >> 4;
     }
     const lds_u8 *len0 = tab + (1u << K1);
     while (q < qe) {
-        const u32 l0 = len0[sw.at(q) & mask];
-        if (LAST && (int)(q + l0) > qlimit) { q = qe + 15u; break; }     // cut by the end of the stream: nothing starts after it
+        u32 l0 = len0[sw.at(q) & mask];
+        if (LONG && __builtin_expect(l0 == 0u, 0)) l0 = long_len(q);
+        if (LAST && (int)(q + l0) > qlimit) { q = qe + spec_emask<LONG>(); break; }   // cut by the end of the stream: nothing starts after it
         q += l0;
         ++cnt;
     }
@@ -1255,8 +1279,8 @@ __device__ __forceinline__ void spec_walk(const lds_u8 *tab, u32 K1, u32 &q, u32
 // a strip (LDS bit address qrow) from entry `ent0` of its first chunk: entries and counts of its SPEC_STRIP chunks, exit
 // of the last one.  HAVE_OLD: ent[] holds the entries of an earlier walk of the same strip: once this walk meets it the
 // rest is unchanged.
-template <bool LAST, bool HAVE_OLD>
-__device__ __forceinline__ void spec_strip(const lds_u8 *tab, u32 K1, u32 qrow, int qlimit, u32 ent0,
+template <bool LAST, bool HAVE_OLD, int LONG>
+__device__ __forceinline__ void spec_strip(const lds_u8 *tab, const u16 *lt, u32 K1, u32 qrow, int qlimit, u32 ent0,
                                            u32 (&ent)[SPEC_STRIP], u32 (&cnt)[SPEC_STRIP], u32 &exit_)
 {
     u32 q = qrow + ent0;
@@ -1268,16 +1292,16 @@ __device__ __forceinline__ void spec_strip(const lds_u8 *tab, u32 K1, u32 qrow, 
         if (HAVE_OLD && k > 0 && r == ent[k]) return;   // back on the earlier walk's path
         ent[k] = r;
         u32 c = 0;
-        spec_walk<LAST>(tab, K1, q, qrow + 256u * (k + 1), qlimit, c, sw);
+        spec_walk<LAST, LONG>(tab, lt, K1, q, qrow + 256u * (k + 1), qlimit, c, sw);
         cnt[k] = c;
     }
-    exit_ = (q - (qrow + 256u * SPEC_STRIP)) & 15u;
+    exit_ = (q - (qrow + 256u * SPEC_STRIP)) & spec_emask<LONG>();
 }
 
-// dynamic LDS: stream frame | cnt3 (2 << K1max bytes) | exits[256] | wsum[4] | flags[8]
+// dynamic LDS: stream frame | cnt3 (2 << K1max bytes) | exits[256] | wsum[4] | flags[8] | long-code table (LONG)
 constexpr int SPEC_FIX_REGIONS = 32;               // regions a workgroup of a repair launch looks at (almost none needs work)
 
-template <bool FIX>
+template <bool FIX, int LONG>
 __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u32 tile0, u8 *__restrict__ chunk_entry,
                                             u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt,
                                             u8 *__restrict__ tile_guess, u8 *__restrict__ tile_exit,
@@ -1291,6 +1315,12 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 K1 = spec_window(blk.K1);                 // the counting table's window
     fill_lds16((void *)(smem + tab_off), (const void *)blk.cnt3, 2u << K1);
+    const u16 *lt = (const u16 *)(smem + SPEC_LDS_DATA + tab_bytes + DEC_THREADS + 16 + 32);
+    if (LONG) {
+        const u16 *src = LONG == 1 ? blk.longtab : blk.long32;
+        if (src) fill_lds16((void *)lt, src, LONG == 1 ? LONG_BYTES : LONG32_BYTES);
+        else if (threadIdx.x == 0) *(u16 *)lt = 0;
+    }
     {   // the region's stream from one strip before it, 16 bytes a lane; frame word f -> LDS word f + f / SPEC_SW.
         // All of a lane's pieces are requested before the first is used (five loads in flight, not five round trips).
         const long long base = (long long)tile0 * DTILE - 4 * SPEC_SW;
@@ -1353,12 +1383,12 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
             u32 q = qe - 256u, dummy = 0;
             SpecWin sw;
             sw.init();
-            if (last) spec_walk<true>(tab, K1, q, qe, qlimit, dummy, sw);
-            else spec_walk<false>(tab, K1, q, qe, 0, dummy, sw);
-            e0 = (q - qe) & 15u;
+            if (last) spec_walk<true, LONG>(tab, lt, K1, q, qe, qlimit, dummy, sw);
+            else spec_walk<false, LONG>(tab, lt, K1, q, qe, 0, dummy, sw);
+            e0 = (q - qe) & spec_emask<LONG>();
         }
-        if (last) spec_strip<true, false>(tab, K1, qrow, qlimit, e0, ent, cnt, exit_);
-        else spec_strip<false, false>(tab, K1, qrow, qlimit, e0, ent, cnt, exit_);
+        if (last) spec_strip<true, false, LONG>(tab, lt, K1, qrow, qlimit, e0, ent, cnt, exit_);
+        else spec_strip<false, false, LONG>(tab, lt, K1, qrow, qlimit, e0, ent, cnt, exit_);
     }
     ex[tid] = (u8)exit_;
     __syncthreads();
@@ -1371,8 +1401,8 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
         if (!wg_any(bad, flags, turn)) break;
         if (bad) {
             const u32 e0 = ex[tid - 1];
-            if (last) spec_strip<true, true>(tab, K1, qrow, qlimit, e0, ent, cnt, exit_);
-            else spec_strip<false, true>(tab, K1, qrow, qlimit, e0, ent, cnt, exit_);
+            if (last) spec_strip<true, true, LONG>(tab, lt, K1, qrow, qlimit, e0, ent, cnt, exit_);
+            else spec_strip<false, true, LONG>(tab, lt, K1, qrow, qlimit, e0, ent, cnt, exit_);
         }
         __syncthreads();                                // every lane has read the exit in front of it
         ex[tid] = (u8)exit_;
@@ -1415,7 +1445,7 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
     }
 }
 
-template <bool FIX>
+template <bool FIX, int LONG>
 __global__ __launch_bounds__(DEC_THREADS) void sfd_spec(const DecBlk *__restrict__ blks, u8 *__restrict__ chunk_entry,
                                                         u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt,
                                                         u8 *__restrict__ tile_guess, u8 *__restrict__ tile_exit,
@@ -1426,7 +1456,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_spec(const DecBlk *__restrict
     if (!blk.run_dp || __hip_atomic_load(blk.run_dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // exact path
     if (!FIX) {
         const u32 tile0 = blockIdx.x * SPEC_TILES;      // first tile of this workgroup's region
-        if (tile0 < blk.n_tiles) spec_region<false>(smem, blk, tile0, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tile_fix, tab_bytes);
+        if (tile0 < blk.n_tiles) spec_region<false, LONG>(smem, blk, tile0, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tile_fix, tab_bytes);
         return;
     }
     // repair launch: a workgroup looks at the flags of SPEC_FIX_REGIONS regions and redoes the few that are marked
@@ -1443,7 +1473,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_spec(const DecBlk *__restrict
         for (u32 q = 0; q < SPEC_TILES && tile0 + q < blk.n_tiles; ++q) any |= tile_fix[(size_t)blk.tile_base + tile0 + q] != 0;
         if (!any) continue;                             // uniform
         __syncthreads();                                // the region before is done with the LDS
-        spec_region<true>(smem, blk, tile0, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tile_fix, tab_bytes);
+        spec_region<true, LONG>(smem, blk, tile0, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tile_fix, tab_bytes);
     }
 }
 
@@ -1709,26 +1739,27 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                     want -= n;
                 };
                 // N look-ups per stream read: the 30 window bits fetched hold further windows behind the first one's
-                // codes as long as N windows fit (a look-up uses at most K3 bits)
+                // codes as long as N windows fit (a look-up uses at most K3 bits).  ESC: a window that starts with a code
+                // longer than K3 bits has the entry 0 — it emits nothing and uses no bits, so the look-ups behind it in
+                // the same round see the same window and do nothing either; the long code is then taken by one step
                 auto multi = [&](auto nlook) {
                     constexpr u32 N = decltype(nlook)::value;
                     while (want >= 3 * N) {
                         const u32 w4 = window4();
-                        u32 used = 0;
+                        u32 used = 0, e = 0;
 #pragma unroll
                         for (u32 i = 0; i < N; ++i) {
-                            const u32 e = *(const lds_u32 *)(size_t)(tab_off + ((w4 >> used) & mask4));
+                            e = *(const lds_u32 *)(size_t)(tab_off + ((w4 >> used) & mask4));
                             emit(e >> 30, e & 0xFFFFFFu);
                             used += (e >> 24) & 63u;
                             want -= e >> 30;
                         }
                         q2 += used;
+                        if (ESC && __builtin_expect((e >> 30) == 0, 0)) step(false);
                     }
                 };
-                if (!ESC) {
-                    if (K3 <= 10) multi(std::integral_constant<u32, 3>{});
-                    if (K3 <= 15) multi(std::integral_constant<u32, 2>{});
-                }
+                if (K3 <= 10) multi(std::integral_constant<u32, 3>{});
+                if (K3 <= 15) multi(std::integral_constant<u32, 2>{});
                 while (want >= 3) step(false);
                 while (want) step(true);
                 if (nb8) __hip_atomic_fetch_or((lds_u32 *)(size_t)wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2048,7 +2079,7 @@ void sfdec_configure(int speculate) { g_sfd_speculate = speculate; }
 // Verdicts are cached by a hash of the table (a launch usually repeats the previous launch's tables).
 static bool spec_worthwhile(const shafa_code_table &t, const HostTab &h, bool force)
 {
-    if (!h.ok || !h.complete || h.lmax > (u32)LEN_MAXK || h.lmax < 2) return false;
+    if (!h.ok || !(h.complete || h.complete16 || h.complete32) || h.lmax > 32 || h.lmax < 2) return false;
     if (force) return true;
     u64 key = 1469598103934665603ull;
     for (int s2 = 0; s2 < 256; ++s2) {
@@ -2073,12 +2104,14 @@ static bool spec_worthwhile(const shafa_code_table &t, const HostTab &h, bool fo
             return (u32)(v >> (64 - K1));
         };
         u64 starts[5] = {0, 0, 0, 0, 0};                // code starts of the true parse, bits 0..319
-        for (u32 pos = 0; pos < 300;) { starts[pos >> 6] |= 1ull << (pos & 63); pos += h.lenlut[window(pos)]; }
+        // (a window that starts a code of more than K1 bits — one random window in 2^K1 — counts as K1 + 1 bits)
+        auto len_at = [&](u32 pos) -> u32 { const u32 l = h.lenlut[window(pos)]; return l ? l : K1 + 1; };
+        for (u32 pos = 0; pos < 300;) { starts[pos >> 6] |= 1ull << (pos & 63); pos += len_at(pos); }
         u32 pos = 1 + (u32)(rnd() % 15);
         bool merged = false;
         while (pos <= 256) {
             if ((starts[pos >> 6] >> (pos & 63)) & 1ull) { merged = true; break; }
-            pos += h.lenlut[window(pos)];
+            pos += len_at(pos);
         }
         if (!merged) ++fails;
     }
@@ -2157,8 +2190,10 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const size_t o_fsm4 = off; off += need_tabs ? (size_t)nblocks * 16384 : 0;
     const size_t o_fsm1 = off; off += need_tabs ? (size_t)nblocks * 2048 : 0;
     const size_t o_cfn = off; off += packed ? (size_t)total_tiles * DEC_THREADS * 8 : (size_t)total_tiles * R * DEC_THREADS;
-    // speculative entries (complete codes, Lmax <= 13, tables that re-synchronise): per-tile guess / exit / redo flag
-    const bool spec_path = packed && fast13 && multi && !long_all && g_sfd_speculate != 0;
+    // speculative entries (complete codes, Lmax <= 32, tables that re-synchronise): per-tile guess / exit / redo flag
+    // (long_all and mid32 launches too: a code of more than 13 bits is an escape inside the walk)
+    const bool spec_path = ((packed && fast13 && multi) || mid32) && g_sfd_speculate != 0;
+    const int spec_long = mid32 ? 2 : long_all ? 1 : 0;
     std::vector<char> spec_blk(nblocks, 0);
     bool any_spec = false;
     for (int b = 0; spec_path && b < nblocks; ++b)
@@ -2255,32 +2290,45 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const dim3 grid_w((u32)ceil_div_u64(max_tiles, tpw * WSUBS), (u32)nblocks);
     constexpr int CSUBS = 4;                           // 256-lane groups per workgroup of sfd_countfsm
     const dim3 grid_c((u32)ceil_div_u64(max_tiles, tpw * CSUBS), (u32)nblocks);
+    // speculative entries: guesses, two rounds of tile repairs, final verdict per block
+    auto launch_spec = [&]() {
+        u8 *tg = ws + o_tguess, *tx = ws + o_texit, *tf = ws + o_tfix;
+        u32 k1_max = 1;
+        for (int b = 0; b < nblocks; ++b) if (spec_blk[b] && spec_window(tabs[b].K1) > k1_max) k1_max = spec_window(tabs[b].K1);
+        const u32 tabb = 2u << k1_max;
+        const size_t lds_spec = (size_t)SPEC_LDS_DATA + tabb + DEC_THREADS + 16 + 32 +
+                                (spec_long == 2 ? (size_t)((LONG32_BYTES + 15) & ~15) : spec_long == 1 ? (size_t)LONG_BYTES : 0);
+        const dim3 grid_s((u32)ceil_div_u64(max_tiles, SPEC_TILES), (u32)nblocks);
+        const dim3 grid_sf((u32)ceil_div_u64(max_tiles, SPEC_TILES * SPEC_FIX_REGIONS), (u32)nblocks);
+        auto spec = [&](auto fix, const dim3 grid) {
+            constexpr bool FIX = decltype(fix)::value;
+            if (spec_long == 2)
+                hipLaunchKernelGGL((sfd_spec<FIX, 2>), grid, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
+                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb);
+            else if (spec_long == 1)
+                hipLaunchKernelGGL((sfd_spec<FIX, 1>), grid, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
+                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb);
+            else
+                hipLaunchKernelGGL((sfd_spec<FIX, 0>), grid, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
+                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb);
+        };
+        spec(std::false_type{}, grid_s);
+        for (int round = 0; round < 2; ++round) {
+            hipLaunchKernelGGL(sfd_spec_check<false>, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
+            spec(std::true_type{}, grid_sf);
+        }
+        hipLaunchKernelGGL(sfd_spec_check<true>, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
+    };
+    // when every block of the launch speculates, the exact kernels are fall-backs that normally return at once:
+    // fat workgroups (256 tiles each) make that a launch of a few thousand workgroups instead of a few hundred thousand
+    bool all_spec = any_spec;
+    for (int b = 0; b < nblocks; ++b) if (ntiles[b] && !spec_blk[b]) all_spec = false;
+    const u32 tpw_dp = all_spec ? 256u : tpw;
+    const dim3 grid_fd((u32)ceil_div_u64(max_tiles, tpw_dp), (u32)nblocks);
     if (packed) {
         const size_t lds_count16 = lds_data + DEC_THREADS * 8 + lds_lut + 32 + DEC_THREADS + 64;
         if (need_tabs) hipLaunchKernelGGL(sfd_tables, grid_b, dim3(DEC_THREADS), 0, st, dblk);
-        if (any_spec) {                                // guesses, two rounds of tile repairs, final verdict per block
-            u8 *tg = ws + o_tguess, *tx = ws + o_texit, *tf = ws + o_tfix;
-            u32 k1_max = 1;
-            for (int b = 0; b < nblocks; ++b) if (spec_blk[b] && spec_window(tabs[b].K1) > k1_max) k1_max = spec_window(tabs[b].K1);
-            const u32 tabb = 2u << k1_max;
-            const size_t lds_spec = (size_t)SPEC_LDS_DATA + tabb + DEC_THREADS + 16 + 32;
-            const dim3 grid_s((u32)ceil_div_u64(max_tiles, SPEC_TILES), (u32)nblocks);
-            const dim3 grid_sf((u32)ceil_div_u64(max_tiles, SPEC_TILES * SPEC_FIX_REGIONS), (u32)nblocks);
-            hipLaunchKernelGGL(sfd_spec<false>, grid_s, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
-                               (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb);
-            for (int round = 0; round < 2; ++round) {
-                hipLaunchKernelGGL(sfd_spec_check<false>, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
-                hipLaunchKernelGGL(sfd_spec<true>, grid_sf, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
-                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb);
-            }
-            hipLaunchKernelGGL(sfd_spec_check<true>, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
-        }
-        // when every block of the launch speculates, the DP kernels below are fall-backs that normally return at once:
-        // fat workgroups (256 tiles each) make that a launch of a few thousand workgroups instead of a few hundred thousand
-        bool all_spec = any_spec;
-        for (int b = 0; b < nblocks; ++b) if (ntiles[b] && !spec_blk[b]) all_spec = false;
-        const u32 tpw_dp = all_spec ? 256u : tpw;
-        const dim3 grid_fd((u32)ceil_div_u64(max_tiles, tpw_dp), (u32)nblocks);
+        if (any_spec) launch_spec();
         const dim3 grid_cd((u32)ceil_div_u64(max_tiles, tpw_dp * CSUBS), (u32)nblocks);
         u32 k1_all = 0;                                // common K1 of the running blocks, 0 when they differ
         for (int b = 0; b < nblocks; ++b)
@@ -2318,11 +2366,12 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         }
     } else if (mid32) {
         hipLaunchKernelGGL(sfd_tables, grid_b, dim3(DEC_THREADS), 0, st, dblk);
-        hipLaunchKernelGGL(sfd_sync32, grid_f, dim3(DEC_THREADS), 0, st, dblk, ws + o_cfn, ws + o_tilefn, tpw);
+        if (any_spec) launch_spec();
+        hipLaunchKernelGGL(sfd_sync32, grid_fd, dim3(DEC_THREADS), 0, st, dblk, ws + o_cfn, ws + o_tilefn, tpw_dp);
         hipLaunchKernelGGL(sfd_tiles, grid_b, dim3(DEC_THREADS), lds_tiles, st, dblk, R, (const u8 *)(ws + o_tilefn),
                            ws + o_tent);
-        hipLaunchKernelGGL(sfd_countfsm32, grid_f, dim3(DEC_THREADS), 0, st, dblk, (const u8 *)(ws + o_cfn),
-                           (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt), (u32 *)(ws + o_tcnt), tpw);
+        hipLaunchKernelGGL(sfd_countfsm32, grid_fd, dim3(DEC_THREADS), 0, st, dblk, (const u8 *)(ws + o_cfn),
+                           (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt), (u32 *)(ws + o_tcnt), tpw_dp);
     } else {
         hipLaunchKernelGGL(sfd_sync, grid_t, dim3(DEC_THREADS), lds_sync, st, dblk, R, l2cap, ws + o_cfn, ws + o_tilefn);
         hipLaunchKernelGGL(sfd_tiles, grid_b, dim3(DEC_THREADS), lds_tiles, st, dblk, R, (const u8 *)(ws + o_tilefn),

@@ -136,3 +136,32 @@ def test_spec_many_blocks(oracle, shafa, modes):
     # a launch of many small blocks: tiles per workgroup shrink, regions end after one tile
     blocks = [zipfmod(oracle, 600 + i, 8192 * (1 + i % 5) + 13 * i) for i in range(40)]
     check(shafa, oracle, blocks, modes)
+
+
+def rare_tail(oracle, seed, n, ncommon, nrare, div):
+    """Zipf data over `ncommon` bytes plus `nrare` bytes that occur 1 + k^3 / div times: the long tail a real file has at
+    a large block size (the recipe of tools/longtail_time.py)."""
+    import golden.make_golden as mg
+    zt = mg.zipf_mod256_table(1.2)
+    t = np.where(zt >= ncommon, zt % ncommon, zt).astype(np.uint8)
+    a = oracle.gen_bytes(seed, n, t).copy()
+    rng = np.random.default_rng(seed)
+    for k, s in enumerate(range(ncommon, ncommon + nrare)):
+        a[rng.integers(0, n, size=1 + (k * k * k) // div)] = s
+    return a
+
+
+def test_spec_long_codes(oracle, shafa, modes):
+    # codes of 14-16 bits (one launch) and of 17-32 bits (another): the long code is an escape inside the walk; mode 2
+    # forces the speculation, mode 0 the exact kernels, both must agree with the oracle
+    mid = [rare_tail(oracle, 70, 100000, 150, 12, 60), rare_tail(oracle, 70, 200000, 150, 10, 60)]
+    for b in mid:
+        lm = oracle.sf_build(oracle.hist256(b)).lens().max()
+        assert 13 < lm <= 16, lm
+    check(shafa, oracle, mid, modes)
+    deep = [rare_tail(oracle, 70, 1048579, 200, 56, 600), rare_tail(oracle, 70, 3145728, 200, 56, 200),
+            rare_tail(oracle, 70, 300000, 200, 40, 2000)]
+    for b in deep:
+        lm = oracle.sf_build(oracle.hist256(b)).lens().max()
+        assert 16 < lm <= 32, lm
+    check(shafa, oracle, deep, modes, out_shift=32)
