@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) __attribute__((amdgpu_waves_per
 }
 
 // ================================================================================================
-// Speculative chunk entries for self-synchronising codes (complete codes, Lmax <= 13), verified exactly.
+// Speculative chunk entries for self-synchronising codes (complete codes, Lmax <= 32), verified exactly.
 //
 // The packed DP above prices every bit position (6.7 VALU per bit) to be exact for ANY code.  Shannon-Fano codes of
 // skewed data re-synchronise: a decoder started at an arbitrary bit agrees with the true parse after a few dozen bits
