@@ -781,12 +781,13 @@ __device__ __forceinline__ bool rle3_emit8k(R8Fast &sh, const RleBlk &blk, const
             a = add_byte<3>(p, ft); smem[a < p_end ? a : dump] = (u8)(w[q] >> 24); p = add_byte<3>(p, sz);
         }
     }
-    for (u32 t = T3; t; t &= t - 1) {                   // triples: the lane's heads in order
+    u32 p3 = p0;                                        // p0 + 3 * (triples of the lane so far): the same count in every lane
+    for (u32 t = T3; t; t &= t - 1, p3 += 3u) {         // triples: the lane's heads in order
         const u32 j = (u32)__builtin_ctz(t), below = (1u << j) - 1u;
         const u32 hn = j < 31 ? H >> (j + 1) : 0u;
         u32 L = hn ? (u32)__builtin_ctz(hn) + 1u : (32u - j) + after;   // to the next head: in this lane / beyond it
         L = L > 255u ? 255u : L;
-        const u32 at = p0 + (u32)__builtin_popcount(Lit & below) + 3u * (u32)__builtin_popcount(T3 & below);
+        const u32 at = p3 + (u32)__builtin_popcount(Lit & below);
         smem[at] = 0;
         smem[at + 2] = (u8)L;
     }
