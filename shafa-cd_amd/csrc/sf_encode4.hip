@@ -484,13 +484,15 @@ __global__ __launch_bounds__(NT) void sfe4_tail_kernel(const EncBlk *__restrict_
 template <int NW, bool L16, int NT>
 int e4_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool any_ragged)
 {
-    static int wgs_by_lmax[17], cus = 0;
+    static int wgs_by_dev_lmax[16][17], cus = 0;       // per device: the LDS attribute below belongs to the device's copy of the kernel
     const u32 win_stride = ((u32)E4_GUARD + (u32)(((size_t)(32 * NT) * lmax) >> 5) + 8u + 3u) & ~3u;   // dwords per buffer
     const size_t dyn = (size_t)win_stride * 3 * 4;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    int *wgs_by_lmax = wgs_by_dev_lmax[dev & 15];
     if (!wgs_by_lmax[lmax]) {
-        int dev = 0, occ = 0;
+        int occ = 0;
         hipDeviceProp_t prop;
-        HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         cus = prop.multiProcessorCount;
         if (dyn > 65536)                               // more than the default 64 KiB of dynamic LDS per workgroup
