@@ -108,7 +108,7 @@ def test_one_pass_and_three_kernel_agree_on_a_big_launch(shafa, oracle):
         shafa.set_option("sf_encode_one_pass_min_blocks", 24)
 
 
-@pytest.mark.parametrize("kind", ["uniform", "two", "few", "lmax16", "lmax13", "single_long_chain"])
+@pytest.mark.parametrize("kind", ["uniform", "two", "few", "lmax16", "lmax13", "lmax12", "single_long_chain"])
 def test_one_pass_code_length_classes(shafa, oracle, one_pass, kind):
     """NW = 3 (Lmax <= 8), 4 (<= 12), 5 (<= 15) and the Lmax == 16 variant; one block alone = the longest chain."""
     blocks, tables = [], []
@@ -134,6 +134,12 @@ def test_one_pass_code_length_classes(shafa, oracle, one_pass, kind):
         rare = np.nonzero(otab.lens() >= 12)[0].astype(np.uint8)
         blocks = [syms[oracle.gen_bytes(4, 200000) % syms.size], rare[oracle.gen_bytes(5, 70000) % rare.size],
                   np.full(30000, np.nonzero(otab.lens() == 16)[0][0], dtype=np.uint8)]      # only 16-bit codes: 64-bit groups
+        tables = [otab] * 3
+    elif kind == "lmax12":         # the widest codes of the 512-lane form: three 24 KiB windows, more than 64 KiB of LDS
+        otab, data = long_code_case(oracle, 400000, 13, 0.5, 8)
+        assert 10 < otab.lens().max() <= 12, otab.lens().max()
+        rare = np.nonzero(otab.lens() >= 10)[0].astype(np.uint8)
+        blocks = [data, data[:16385], rare[oracle.gen_bytes(6, 100000) % rare.size]]     # the last one: only long codes
         tables = [otab] * 3
     elif kind == "lmax13":
         otab, data = long_code_case(oracle, 400000, 14, 0.5, 6)
