@@ -1229,7 +1229,7 @@ __device__ __forceinline__ void spec_walk(const lds_u8 *tab, const u16 *lt, u32 
         return l ? l : 1u;
     };
     if (!LAST) {
-        const u32 qk = qe - K1, q0 = q;                 // up to qk the window holds only codes that start before qe
+        const u32 q0 = q;
         u32 acc = 0;                                    // sum of the entries = bits walked + 16 * codes: one add a step
         // N look-ups per window fetch: the 32 bits fetched hold further windows behind the first one's codes
         auto multi = [&](auto nlook) {
@@ -1253,17 +1253,7 @@ __device__ __forceinline__ void spec_walk(const lds_u8 *tab, const u16 *lt, u32 
             }
         };
         if (K1 <= 10) multi(std::integral_constant<u32, 3>{});
-        multi(std::integral_constant<u32, 2>{});          // K1 <= 13: 26 bits
-        while (q <= qk) {
-            const u32 e = tab[sw.at(q) & mask];
-            q += e & 15u;
-            acc += e;
-            if (LONG && __builtin_expect((e & 15u) == 0u, 0)) {
-                const u32 l = long_len(q);
-                q += l;
-                acc += l + 16u;
-            }
-        }
+        else multi(std::integral_constant<u32, 2>{});     // K1 <= 13: 26 bits
         cnt += (acc - (q - q0)) >> 4;
     }
     const lds_u8 *len0 = tab + (1u << K1);
@@ -1759,8 +1749,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                     }
                 };
                 if (K3 <= 10) multi(std::integral_constant<u32, 3>{});
-                if (K3 <= 15) multi(std::integral_constant<u32, 2>{});
-                while (want >= 3) step(false);
+                else if (K3 <= 15) multi(std::integral_constant<u32, 2>{});
                 while (want) step(true);
                 if (nb8) __hip_atomic_fetch_or((lds_u32 *)(size_t)wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -2402,20 +2391,25 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     }
     ws_cap &= ~15u;
     const size_t lds_ws = (size_t)WS_ROWS_BYTES + ws_tab + ws_cap + WS_MISC;
+    // the staged symbol pass takes 16 tiles per workgroup (table fill, image zeroing and the prefetch pipeline's start are
+    // paid once per workgroup: 7.8 -> 7.7 ms on the headline data against 4; 32: the same), the chip kept full as above
+    u32 tpw_ws = 16;
+    while (tpw_ws > 1 && (u64)ceil_div_u64(max_tiles, tpw_ws) * nblocks < 2048) tpw_ws >>= 1;
+    const dim3 grid_ws((u32)ceil_div_u64(max_tiles, tpw_ws), (u32)nblocks);
     if (mid32) {
-        hipLaunchKernelGGL((sfd_wstage<2, true>), grid_f, dim3(DEC_THREADS), lds_ws + LONG32_BYTES, st, dblk,
-                           (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, ws_tab, ws_cap);
+        hipLaunchKernelGGL((sfd_wstage<2, true>), grid_ws, dim3(DEC_THREADS), lds_ws + LONG32_BYTES, st, dblk,
+                           (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap);
     } else if (fast13) {
         if (multi && long_all)
-            hipLaunchKernelGGL((sfd_wstage<1, true>), grid_f, dim3(DEC_THREADS), lds_ws + LONG_BYTES, st, dblk,
-                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, ws_tab, ws_cap);
+            hipLaunchKernelGGL((sfd_wstage<1, true>), grid_ws, dim3(DEC_THREADS), lds_ws + LONG_BYTES, st, dblk,
+                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap);
         else if (multi)
             if (lmax_all > (u32)SYM3_MAXK)
-                hipLaunchKernelGGL((sfd_wstage<0, true>), grid_f, dim3(DEC_THREADS), lds_ws, st, dblk,
-                                   (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, ws_tab, ws_cap);
+                hipLaunchKernelGGL((sfd_wstage<0, true>), grid_ws, dim3(DEC_THREADS), lds_ws, st, dblk,
+                                   (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap);
             else
-                hipLaunchKernelGGL((sfd_wstage<0, false>), grid_f, dim3(DEC_THREADS), lds_ws, st, dblk,
-                                   (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw, ws_tab, ws_cap);
+                hipLaunchKernelGGL((sfd_wstage<0, false>), grid_ws, dim3(DEC_THREADS), lds_ws, st, dblk,
+                                   (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap);
         else
             hipLaunchKernelGGL((sfd_write13<WSUBS>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
                                (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw);
