@@ -1692,13 +1692,12 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                 u32 wp = img_off + (x & ~3u), nb8 = (x & 3u) * 8, acc = 0;
                 // n symbols (low bytes of syms) join the word being gathered; a finished word is ORed into the image
                 auto emit = [&](const u32 n, const u32 syms) {
-                    const u64 t = (u64)syms << nb8;
                     const u32 nbn = nb8 + 8 * n;
-                    acc |= (u32)t;
+                    acc |= syms << nb8;
                     if (nbn >= 32) {                    // only the lanes with a finished word touch the image
                         __hip_atomic_fetch_or((lds_u32 *)(size_t)wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         wp += 4u;
-                        acc = (u32)(t >> 32);
+                        acc = syms >> (32u - nb8);      // the bytes that did not fit (nb8 >= 8 here: n <= 3)
                     }
                     nb8 = nbn & 31u;
                 };
