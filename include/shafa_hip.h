@@ -70,7 +70,8 @@ const char *shafa_hip_last_error(void);      /* text of the last SHAFA_DEVICE_ER
 
 /* Tuning knobs (no reference counterpart).  Unknown names return SHAFA_OUTSIDE_MODULE.
  *   "sf_encode_one_pass_min_blocks": a shafa_hipd_sf_encode launch with at least this many blocks of <= 16-bit
- *       codes takes the one-pass encoder, smaller launches the count/scan/pack kernels (default 24).
+ *       codes takes the one-pass encoder, smaller launches the count/scan/pack kernels; 0 (default) = the measured crossovers: 6 blocks when every code
+ *       has <= 12 bits, 80 for codes of 13-16 bits.
  *   "sf_decode_speculate": 1 (default) lets blocks whose code re-synchronises take the speculative entry kernels of
  *       the Shannon-Fano decoder (verified exactly; falls back to the exact kernels per block), 0 = exact kernels only,
  *       2 = speculate for every block the kernels apply to, whatever its code (for tests of the fall-back).

@@ -112,7 +112,7 @@ const char *shafa_hip_last_error(void) { return g_last_error; }
 int shafa_hip_set_option(const char *name, long value)
 {
     if (name && !strcmp(name, "sf_encode_one_pass_min_blocks")) {
-        sfenc_configure(value < 1 ? 1 : (value > (1 << 30) ? (1 << 30) : (int)value));
+        sfenc_configure(value < 0 ? 0 : (value > (1 << 30) ? (1 << 30) : (int)value));      // 0: measured defaults
         return SHAFA_SUCCESS;
     }
     if (name && !strcmp(name, "sf_decode_speculate")) {

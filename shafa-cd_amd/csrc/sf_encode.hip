@@ -206,13 +206,15 @@ __global__ __launch_bounds__(ENC_THREADS) void sf_encode_generic(const EncBlk *_
 // host launcher
 // ------------------------------------------------------------------------------------------------
 void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 *d_tile_bits, u64 *d_tile_off, bool lut64);
-int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool ragged8, bool ragged16);
+int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool ragged8, bool ragged32);
 
 // A launch with at least this many class-1 blocks takes the one-pass encoder: every block is its own chain, and with this
 // many chains (<= ~10 workgroups per block) a tile's look-back stays inside one 64-entry descriptor window.  Measured
 // on 64 MiB Zipf blocks, GiB/s one-pass vs count/scan/pack: 16 blocks 588 / 1240, 32: 1112 / 1298, 64: 1407 / 1457,
 // 128: 1900 / 1632 (sf_encode4.hip).
-static int g_sfe4_min_blocks = 24;
+// launches with at least this many blocks of <= 16-bit codes take the one-pass encoder; 0 = the measured crossovers:
+// 6 blocks where the 1024-lane form runs (Lmax <= 12), 80 for the 256-lane form
+static int g_sfe4_min_blocks = 0;
 void sfenc_configure(int sfe4_min_blocks) { g_sfe4_min_blocks = sfe4_min_blocks; }
 
 static u32 code_value(const shafa_code_table &t, int s)
@@ -242,7 +244,7 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         cls_count[c]++;
         if (c == 1 && (u32)lmax > lmax1) lmax1 = (u32)lmax;
     }
-    const bool one_pass = cls_count[1] >= g_sfe4_min_blocks;
+    const bool one_pass = cls_count[1] >= (g_sfe4_min_blocks > 0 ? g_sfe4_min_blocks : (lmax1 <= 12 ? 6 : 80));
     const u64 tile_syms[4] = {1, 256 * 16 * 2, 256 * 16 * 2, GEN_TILE};
     u64 total_tiles[4] = {0, 0, 0, 0};
     u32 max_tiles[4] = {0, 0, 0, 0};
@@ -333,12 +335,12 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     u32 *dtick = (u32 *)(ws + o_tick);
     if (cls_count[1]) {
         if (one_pass) {
-            bool ragged8 = false, ragged16 = false;    // a block has a remainder after its full 8 KiB / 16 KiB tiles
+            bool ragged8 = false, ragged32 = false;    // a block has a remainder after its full 8 KiB / 32 KiB tiles
             for (int b = 0; b < nblocks; ++b) {
                 ragged8 = ragged8 || (cls[b] == 1 && (h_in_n[b] & 8191));
-                ragged16 = ragged16 || (cls[b] == 1 && (h_in_n[b] & 16383));
+                ragged32 = ragged32 || (cls[b] == 1 && (h_in_n[b] & 32767));
             }
-            if ((rc = sfenc4_launch(st, dblk + cls_first[1], cls_count[1], ddesc, dtick, lmax1, ragged8, ragged16))) return rc;
+            if ((rc = sfenc4_launch(st, dblk + cls_first[1], cls_count[1], ddesc, dtick, lmax1, ragged8, ragged32))) return rc;
         } else sfenc3_launch(st, dblk + cls_first[1], cls_count[1], max_tiles[1], (u32 *)(ws + o_tbits), ddesc, false);
     }
     if (cls_count[2]) sfenc3_launch(st, dblk + cls_first[2], cls_count[2], max_tiles[2], (u32 *)(ws + o_tbits), ddesc, true);

@@ -35,9 +35,9 @@ int g_sfe4_wide = 1;                                   // 0: always the 256-lane
 
 namespace {
 
-// A workgroup has NT = 256 or 512 lanes and a tile is four rows of NT octs: 8 KiB or 16 KiB of symbols.  The wide form
-// (launches where two such workgroups fit a CU's LDS: Lmax <= 12) halves what wave 0's chain work costs per byte and
-// spreads the window stores over seven waves instead of three.
+// A workgroup has NT = 256 or 1024 lanes and a tile is four rows of NT octs: 8 KiB or 32 KiB of symbols.  The wide form
+// (launches whose three 32 KiB-tile windows fit a CU's LDS: Lmax <= 12; one workgroup per CU) pays wave 0's chain work
+// once per 32 KiB instead of once per 8 KiB and spreads the window stores over fifteen waves instead of three.
 constexpr int E4_GUARD = 8;                            // dwords in front of the window: an oct writes up to 4 dwords before its last one
 constexpr u32 E4_NONE = 0xFFFFFFFFu;
 #ifndef E4_WPS
@@ -58,7 +58,7 @@ __device__ unsigned long long e4_stamp_buf[2048 * 8 * 8];
 
 struct E4Static {
     u64 lut[256];                // {code (low dword), len (high dword)}; a symbol without a code: len = 1 << 16
-    u32 wtot[32];                // [row][wave] bit totals, i.e. in stream order (4 rows x up to 8 waves)
+    u32 wtot[64];                // [row][wave] bit totals, i.e. in stream order (4 rows x up to 8 waves)
     u64 prefix;                  // bits before the pending tile
     u32 tick;                    // next ticket of the block (broadcast)
     u32 pad;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe4_kernel(const EncBlk *__restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NWV = NT / 64;                       // waves
-    constexpr u32 TILE = 32u * NT, TSHIFT = NT == 256 ? 13 : 14;        // symbols per tile
+    constexpr u32 TILE = 32u * NT, TSHIFT = NT == 256 ? 13 : NT == 512 ? 14 : 15;        // symbols per tile
     E4_T0();
 
     for (int b = (int)(blockIdx.x % (u32)nconc); b < nblk; b += nconc) {
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(NT) void sfe4_tail_kernel(const EncBlk *__restrict_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NWV = NT / 64;
-    constexpr u32 TILE = 32u * NT, TSHIFT = NT == 256 ? 13 : 14;
+    constexpr u32 TILE = 32u * NT, TSHIFT = NT == 256 ? 13 : NT == 512 ? 14 : 15;
     const EncBlk blk = blks[blockIdx.x];
     const u32 rem = (u32)(blk.n & (TILE - 1));
     if (!rem) return;
@@ -514,12 +514,13 @@ int e4_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32
     return SHAFA_SUCCESS;
 }
 
-// the wide form when two workgroups of it (three windows + 2 KiB of static LDS each) fit the CU's 160 KiB: Lmax <= 12
+// the wide form — ONE workgroup of 1024 lanes per CU, 32 KiB tiles — when its three windows (and the 2 KiB of static
+// LDS) fit the CU's 160 KiB: Lmax <= 12
 template <int NW, bool L16>
-int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool ragged8, bool ragged16)
+int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool ragged8, bool ragged32)
 {
-    const size_t wide = (size_t)((((u32)E4_GUARD + (u32)(((size_t)16384 * lmax) >> 5) + 8u + 3u) & ~3u)) * 3 * 4 + sizeof(E4Static) + 64;
-    if (g_sfe4_wide && 2 * wide <= 160 * 1024) return e4_launch_nt<NW, L16, 512>(st, dblk, count, d_desc, d_tickets, lmax, ragged16);
+    const size_t wide = (size_t)((((u32)E4_GUARD + (u32)(((size_t)32768 * lmax) >> 5) + 8u + 3u) & ~3u)) * 3 * 4 + sizeof(E4Static) + 64;
+    if (g_sfe4_wide && wide <= 160 * 1024) return e4_launch_nt<NW, L16, 1024>(st, dblk, count, d_desc, d_tickets, lmax, ragged32);
     return e4_launch_nt<NW, L16, 256>(st, dblk, count, d_desc, d_tickets, lmax, ragged8);
 }
 
@@ -535,10 +536,10 @@ extern "C" int shafa_e4_read_stamps(unsigned long long *dst, int n)
 // launched from sfenc_launch (sf_encode.hip) for blocks whose codes are <= 16 bits when the launch holds enough blocks
 // to keep every chain short; desc (one u64 per tile) and tickets (one u32 per block) are zeroed by the caller;
 // tables are 256 x u64 {code, len}
-int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool ragged8, bool ragged16)
+int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool ragged8, bool ragged32)
 {
-    if (lmax <= 8) return e4_launch_t<3, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged8, ragged16);
-    if (lmax <= 12) return e4_launch_t<4, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged8, ragged16);
-    if (lmax <= 15) return e4_launch_t<5, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged8, ragged16);
-    return e4_launch_t<5, true>(st, dblk, count, d_desc, d_tickets, lmax, ragged8, ragged16);
+    if (lmax <= 8) return e4_launch_t<3, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged8, ragged32);
+    if (lmax <= 12) return e4_launch_t<4, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged8, ragged32);
+    if (lmax <= 15) return e4_launch_t<5, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged8, ragged32);
+    return e4_launch_t<5, true>(st, dblk, count, d_desc, d_tickets, lmax, ragged8, ragged32);
 }

@@ -44,7 +44,7 @@ def test_library_exports_nothing_but_the_declared_symbols(shafa):
     extra = sorted(exported - declared)
     assert not extra, f"exported by libshafa_hip.so but not declared in include/shafa_hip.h: {extra}"
     assert shafa.lib().shafa_hip_set_option(b"no_such_option", 1) == shafa.OUTSIDE_MODULE
-    assert shafa.lib().shafa_hip_set_option(b"sf_encode_one_pass_min_blocks", 24) == shafa.SUCCESS
+    assert shafa.lib().shafa_hip_set_option(b"sf_encode_one_pass_min_blocks", 0) == shafa.SUCCESS
     for v in (0, 2, 1):
         assert shafa.lib().shafa_hip_set_option(b"sf_decode_speculate", v) == shafa.SUCCESS
 

@@ -14,7 +14,7 @@ def one_pass(shafa):
     shafa.lib().shafa_hip_init(0)
     shafa.set_option("sf_encode_one_pass_min_blocks", 1)
     yield
-    shafa.set_option("sf_encode_one_pass_min_blocks", 24)
+    shafa.set_option("sf_encode_one_pass_min_blocks", 0)
 
 
 def run_batch(shafa, oracle, blocks, tables, caps=None, expect_err=None):
@@ -87,16 +87,18 @@ def test_one_pass_matches_oracle_ragged_sizes(shafa, oracle, one_pass):
     run_batch(shafa, oracle, blocks, tables)
 
 
-def test_one_pass_blocks_of_odd_multiples_of_8_kib(shafa, oracle, one_pass):
-    """Every block is an odd multiple of 8 KiB: no remainder for the 8 KiB tiles of the 256-lane kernel, half a tile of
-    remainder for the 16 KiB tiles of the 512-lane one (the tail kernel must be launched for exactly that form)."""
-    sizes = [8192 * (2 * i + 1) for i in range(12)] + [8192, 8192 * 127]
+def test_one_pass_blocks_of_whole_8_kib_tiles(shafa, oracle, one_pass):
+    """Every block is a multiple of 8 KiB but not of 32 KiB: no remainder for the 8 KiB tiles of the 256-lane kernel,
+    a remainder of one to three quarters of a tile for the 32 KiB tiles of the 1024-lane one (the tail kernel must be
+    launched by the form that runs, not by the 8 KiB rule)."""
+    sizes = [8192 * (4 * i + 1 + i % 3) for i in range(12)] + [8192, 16384, 24576, 8192 * 127]
+    assert all(n % 8192 == 0 and n % 32768 for n in sizes)
     blocks, tables = zipf_blocks(shafa, oracle, sizes, seed0=4000)
     run_batch(shafa, oracle, blocks, tables)
 
 
 def test_one_pass_and_three_kernel_agree_on_a_big_launch(shafa, oracle):
-    """128 blocks of 0.5 MiB + ragged tails through the default dispatch (one pass: >= 24 blocks)."""
+    """128 blocks of 0.5 MiB + ragged tails through the default dispatch (one pass: the default threshold is 6 blocks for codes of <= 12 bits)."""
     sizes = [(1 << 19) + 13 * i for i in range(128)]
     blocks, tables = zipf_blocks(shafa, oracle, sizes, seed0=500)
     shafa.lib().shafa_hip_init(0)
@@ -105,7 +107,7 @@ def test_one_pass_and_three_kernel_agree_on_a_big_launch(shafa, oracle):
     try:
         run_batch(shafa, oracle, blocks, tables)
     finally:
-        shafa.set_option("sf_encode_one_pass_min_blocks", 24)
+        shafa.set_option("sf_encode_one_pass_min_blocks", 0)
 
 
 @pytest.mark.parametrize("kind", ["uniform", "two", "few", "lmax16", "lmax13", "lmax12", "single_long_chain"])
@@ -135,7 +137,7 @@ def test_one_pass_code_length_classes(shafa, oracle, one_pass, kind):
         blocks = [syms[oracle.gen_bytes(4, 200000) % syms.size], rare[oracle.gen_bytes(5, 70000) % rare.size],
                   np.full(30000, np.nonzero(otab.lens() == 16)[0][0], dtype=np.uint8)]      # only 16-bit codes: 64-bit groups
         tables = [otab] * 3
-    elif kind == "lmax12":         # the widest codes of the 512-lane form: three 24 KiB windows, more than 64 KiB of LDS
+    elif kind == "lmax12":         # the widest codes of the 1024-lane form: three 48 KiB windows in one CU's LDS
         otab, data = long_code_case(oracle, 400000, 13, 0.5, 8)
         assert 10 < otab.lens().max() <= 12, otab.lens().max()
         rare = np.nonzero(otab.lens() >= 10)[0].astype(np.uint8)
