@@ -46,10 +46,10 @@ constexpr u32 E4_NONE = 0xFFFFFFFFu;
 
 #ifdef E4_STAMPS
 // diagnostic build only (tools/dbg): per-wave cycle totals of the phases of an iteration
-__device__ unsigned long long e4_stamp_buf[2048 * 8 * 8];
+__device__ unsigned long long e4_stamp_buf[2048 * 16 * 8];
 #define E4_T0() unsigned long long _t_prev = __builtin_amdgcn_s_memtime(), _t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define E4_T(ph) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); _t_acc[ph] += _t - _t_prev; _t_prev = _t; } while (0)
-#define E4_TEND() do { if (lane == 0) for (int _q = 0; _q < 8; ++_q) e4_stamp_buf[((blockIdx.x & 2047) * 8 + wv) * 8 + _q] = _t_acc[_q]; } while (0)
+#define E4_TEND() do { if (lane == 0) for (int _q = 0; _q < 8; ++_q) e4_stamp_buf[((blockIdx.x & 2047) * 16 + wv) * 8 + _q] = _t_acc[_q]; } while (0)
 #else
 #define E4_T0()
 #define E4_T(ph)

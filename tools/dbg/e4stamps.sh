@@ -17,15 +17,15 @@ try:
 except SystemExit:
     pass
 L = pkg.lib()
-n = 2048 * 8 * 8
+n = 2048 * 16 * 8
 buf = (C.c_ulonglong * n)()
 rc = L.shafa_e4_read_stamps(buf, n)
-a = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 8, 8).astype(np.float64)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 16, 8).astype(np.float64)
 a = a[a.sum(axis=(1, 2)) > 0]
 names = ["w0 lookback", "prefetch+octs", "w0 ticket", "wait A", "offsets+place", "store|request", "wait B", "rotate+w0 publish/lead"]
 tot = a.sum(axis=2)
 print("workgroups with stamps:", a.shape[0], " mean cycles per wave:", tot.mean())
-for w in range(8):
+for w in range(16):
     sh = a[:, w, :].mean(axis=0)
     if sh.sum() == 0: continue
     print(f"wave {w}: " + "  ".join(f"{names[i]}={sh[i] / sh.sum() * 100:.1f}%" for i in range(8)))
