@@ -117,7 +117,10 @@ int shafa_hip_rle_decode(const uint8_t *in, size_t in_n, uint8_t *out, size_t ou
 typedef struct shafa_hipd_batch shafa_hipd_batch;
 
 /* Allocate a reusable batch context (device workspace, pinned staging) for up to max_blocks blocks
- * of up to max_block_bytes input bytes each (for RLE/SF decode: of the LARGER of input and output). */
+ * of up to max_block_bytes input bytes each (for RLE/SF decode: of the LARGER of input and output).
+ * The device workspace grows on demand and is kept: the largest users are RLE encode (about 0.26 bytes per input
+ * byte of a launch) and SF decode (about 0.1 bytes per byte of stream; 0.35 on the exact path of codes that do not
+ * re-synchronise). */
 int shafa_hipd_batch_create(int max_blocks, size_t max_block_bytes, shafa_hipd_batch **out);
 void shafa_hipd_batch_destroy(shafa_hipd_batch *b);
 
