@@ -57,6 +57,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-scatter-gather", action="store_true", help="skip the X1/X2 leg at N>1")
     ap.add_argument("--pipeline", action="store_true",
                     help="extra object: F (RLE + histogram) -> T -> C and D (SF + RLE decode) at this block size on run-heavy data")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="shafa_hip_set_option(NAME, VALUE) before anything runs (A/B of kernel variants)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="test aid: allow more ranks than GPUs (ranks share devices, collectives over gloo); never a valid scaling number")
     return ap.parse_args(argv)
@@ -295,6 +297,10 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(dev)
     pkg.lib().shafa_hip_init(comm.device_index)
+    for o in args.opt:
+        k, v = o.split("=", 1)
+        if pkg.lib().shafa_hip_set_option(k.encode(), int(v)) != 0:
+            raise SystemExit(f"bench.py: unknown option {o}")
 
     bs = args.block_mib << 20
     nb = args.blocks

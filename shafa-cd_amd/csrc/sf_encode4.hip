@@ -32,6 +32,7 @@
 #include "internal.hpp"
 
 int g_sfe4_wide = 1;                                   // 0: always the 256-lane form (A/B and tests)
+int g_sfe_variant = 5;                                 // 5: plain-store windows (sfe5_kernel); 4: atomic-OR windows (sfe4_kernel)
 
 namespace {
 
@@ -58,7 +59,13 @@ __device__ unsigned long long e4_stamp_buf[2048 * 16 * 8];
 
 struct E4Static {
     u64 lut[256];                // {code (low dword), len (high dword)}; a symbol without a code: len = 1 << 16
-    u32 wtot[64];                // [row][wave] bit totals, i.e. in stream order (4 rows x up to 8 waves)
+    u32 wtot[64];                // sfe4: [row][wave] bit totals, i.e. in stream order (4 rows x up to 8 waves); sfe5: [wave]
+    u32 dump[64];                // sfe5: where the stores of lanes that have nothing to store go (one word per lane)
+    // sfe5 has ONE barrier per iteration, so what the waves hand each other across it exists twice (iteration parity):
+    u32 wtot5[2][16];            //   bit total of every wave's string
+    u32 tail5[2][16];            //   the last 32 bits of every wave's string
+    u64 prefix5[2];              //   bits before the tile that is stored in this iteration
+    u32 tick5[2];                //   next ticket of the block
     u64 prefix;                  // bits before the pending tile
     u32 tick;                    // next ticket of the block (broadcast)
     u32 pad;
@@ -424,6 +431,250 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe4_kernel(const EncBlk *__restri
     E4_TEND();
 }
 
+// =====================================================================================================================
+// sfe5: the same three-stage pipeline with a window that is filled by PLAIN LDS stores (no atomics, no zeroing).
+//
+// A lane owns 32 CONSECUTIVE symbols of the tile (four octs), so its bit string is ~6 dwords long and all but its two
+// end dwords belong to it alone.  An oct that covers window bits [s, e) stores every dword it has bits in EXCEPT the one
+// it ends in: that partial dword (x0) travels on as a carry and is ORed into the first dword of whatever comes next — the
+// lane's next oct, the next lane's first oct (DPP wave_shr:1 of the lane's final partial dword, which is known before any
+// oct is placed: it is the last e mod 32 bits of the lane's string), or the next wave's first oct (the waves publish
+// their last 32 bits next to their totals).  Every window dword in [0, T >> 5) is stored exactly once, the tile's last
+// lane adds the final partial dword and a zero behind it (the padding of a block's last byte).  Model with the algebra
+// checked against a direct concatenation: tools/model/sfe5_model.py.
+//
+// Per lane and tile: 32 table look-ups and <= 12 exec-masked ds_write_b32 instead of 32 look-ups, 16 ds_or_b32 and the
+// window zeroing (sfe4: LDS pipe busy 60 % of the time, half of it bank conflicts of the atomics and look-ups).
+// =====================================================================================================================
+struct TileIn5 {
+    uint4 v[2];                  // lane t holds bytes [32 t, 32 t + 32) of the tile
+};
+
+template <int NT>
+__device__ __forceinline__ void load_tile5(const u8 *in, u32 tile, int tid, TileIn5 &t)
+{
+    const u8 *tb = in + (u64)tile * (32u * NT);
+#ifdef E5_LOADTEST                                     // timing experiment only (wrong symbol order): fully coalesced loads
+    t.v[0] = gload_nt_off<uint4>(tb, (u32)tid * 16u);
+    t.v[1] = gload_nt_off<uint4>(tb, (u32)tid * 16u + 16u * NT);
+#elif defined(E5_NTLOAD)
+    t.v[0] = gload_nt_off<uint4>(tb, (u32)tid * 32u);
+    t.v[1] = gload_nt_off<uint4>(tb, (u32)tid * 32u + 16u);
+#else
+    // 32 bytes per lane = two 16-byte loads at a 32-byte lane stride: each instruction uses half of every cache line it
+    // touches, the other half is the second instruction's.  Default (L1-allocating) policy: with `nt` the second
+    // instruction fetches the lines again (measured: 4.05 ms per 8 GiB with nt, 3.72 plain, 3.66 with a fully coalesced
+    // but wrong symbol order).
+    t.v[0] = gload_off<uint4>(tb, (u32)tid * 32u);
+    t.v[1] = gload_off<uint4>(tb, (u32)tid * 32u + 16u);
+#endif
+}
+
+// the lane's four octs, its inclusive bit prefix inside the wave and the last 32 bits of its string
+template <int NW, bool L16>
+__device__ __forceinline__ void tile_octs5(const u64 *lut, const TileIn5 &in, Oct (&oct)[4], u32 &tot, u32 &incl, u32 &tail,
+                                           u32 &absent)
+{
+    constexpr bool R3 = NW >= 5;
+    oct[0] = make_oct<false, L16, R3>(lut, in.v[0].x, in.v[0].y, 0u);
+    oct[1] = make_oct<false, L16, R3>(lut, in.v[0].z, in.v[0].w, 0u);
+    oct[2] = make_oct<false, L16, R3>(lut, in.v[1].x, in.v[1].y, 0u);
+    oct[3] = make_oct<false, L16, R3>(lut, in.v[1].z, in.v[1].w, 0u);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        absent |= oct[k].ll >> 16;
+        oct[k].ll &= 0xFFFFu;
+    }
+    tot = oct[0].ll + oct[1].ll + oct[2].ll + oct[3].ll;           // <= 512
+    incl = dpp_scan_add(tot);                                      // a wave's total <= 32768
+    tail = oct[3].r0;                                              // the last oct has >= 32 bits: its low dword
+    if (__any(oct[3].ll < 32u)) {                                  // rare: short codes only (wave-uniform branch)
+        u32 v = oct[0].r0;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) v = oct[k].ll >= 32u ? oct[k].r0 : ((v << (oct[k].ll & 31u)) | oct[k].r0);
+        tail = v;
+    }
+}
+
+// exclusive offset of this wave and the tile total from the NWV (4 or 16) wave totals: a scan inside one 16-lane DPP row
+template <int NWV>
+__device__ __forceinline__ u32 tile_offsets5(const u32 *wtot, int lane, int wv, u32 &woff)
+{
+    const u32 tot = wtot[lane & (NWV - 1)];
+    u32 sc = tot;
+    sc += (u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x111, 0xf, 0xf, false);   // row_shr:1
+    sc += (u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x112, 0xf, 0xf, false);   // row_shr:2
+    if (NWV > 4) {
+        sc += (u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x114, 0xf, 0xf, false);   // row_shr:4
+        sc += (u32)__builtin_amdgcn_update_dpp(0, (int)sc, 0x118, 0xf, 0xf, false);   // row_shr:8
+    }
+    woff = (u32)__builtin_amdgcn_readlane((int)(sc - tot), wv);
+    return (u32)__builtin_amdgcn_readlane((int)sc, NWV - 1);
+}
+
+// One oct that ends at window bit e (exclusive), with the partial dword c in front of it (the bits of the dword that
+// holds the oct's first bit which belong to earlier octs; 0 when the oct starts on a dword boundary).  Stores the dwords
+// [s >> 5, e >> 5) and returns the new partial dword.  NW = dwords an oct of this launch can touch (x0 .. x[NW-1]).
+template <int NW>
+__device__ __forceinline__ u32 emit_oct(u32 *win, u32 *dump, const Oct &o, u32 e, u32 c)
+{
+    const u32 p = e >> 5, ps = (e - o.ll) >> 5;
+    const u32 j = p - ps;                              // dword boundaries inside (s, e]: 0 .. NW - 1
+    const u32 x0 = __builtin_amdgcn_alignbit(o.r0, 0u, e);             // e mod 32 == 0: nothing in dword p
+    const u32 x1 = __builtin_amdgcn_alignbit(o.r1, o.r0, e);
+    const u32 x2 = __builtin_amdgcn_alignbit(NW >= 4 ? o.r2 : 0u, o.r1, e);
+    const u32 x3 = NW >= 4 ? __builtin_amdgcn_alignbit(NW >= 5 ? o.r3 : 0u, o.r2, e) : 0u;
+    const u32 x4 = NW >= 5 ? (o.r3 >> (e & 31u)) : 0u;
+    u32 v = j >= 1u ? x1 : x0;                         // the dword the oct starts in
+    v = j >= 2u ? x2 : v;
+    if (NW >= 4) v = j >= 3u ? x3 : v;
+    if (NW >= 5) v = j >= 4u ? x4 : v;
+    v |= c;
+    // Branch-free: a store that is not due goes to the lane's dump word.  (As `if (j >= k) win[..] = ..` the compiler
+    // moved every store out of line behind s_cbranch_execnz: two taken branches per store, 24 per lane and tile.)
+    u32 *w = win + p;
+    *(j >= 1u ? win + ps : dump) = v;
+    *(j >= 2u ? w - 1 : dump) = x1;
+    if (NW >= 4) *(j >= 3u ? w - 2 : dump) = x2;
+    if (NW >= 5) *(j >= 4u ? w - 3 : dump) = x3;
+    return j >= 1u ? x0 : v;
+}
+
+template <int NW, bool L16, int NT>
+__global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restrict__ blks, int nblk, int nconc,
+                                                             u64 *__restrict__ desc, u32 *__restrict__ tickets, u32 win_stride)
+{
+    __shared__ E4Static sh;
+    extern __shared__ __attribute__((aligned(16))) u32 dynwin[];     // three buffers of [E4_GUARD][window dwords]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NWV = NT / 64;                       // waves
+    constexpr u32 TILE = 32u * NT, TSHIFT = NT == 256 ? 13 : NT == 512 ? 14 : 15;        // symbols per tile
+
+    for (int b = (int)(blockIdx.x % (u32)nconc); b < nblk; b += nconc) {
+        const EncBlk *bp = blks + b;
+        const u8 *in = bp->in;
+        const u32 nfull = (u32)(bp->n >> TSHIFT);      // full tiles of this kernel's size
+        const bool ragged = (bp->n & (TILE - 1)) != 0;
+        u64 *bdesc = desc + bp->desc_base;
+        u32 *tick = tickets + bp->ticket;
+        __syncthreads();                               // the previous block's table and windows are no longer in use
+        if (tid < 256) sh.lut[tid] = gload<u64>((const u64 *)bp->lut + tid);
+        if (tid == 0) sh.tick = atomicAdd(tick, 3u);
+        __syncthreads();
+        u32 cur = sh.tick, nxt = cur + 1, nn = cur + 2;        // tickets four deep, as in sfe4_kernel
+        if (cur >= nfull) continue;
+        u32 req = E4_NONE;
+        if (tid == 0) req = atomicAdd(tick, 1u);
+        TileIn5 cin, nin, nin2;                        // inputs are requested two tiles ahead
+        load_tile5<NT>(in, cur, tid, cin);
+        if (nxt < nfull) load_tile5<NT>(in, nxt, tid, nin);
+        u64 first_w = 0;
+        u32 pv_w = 0;
+
+        u32 q_tile = E4_NONE, q_T = 0;                 // computed in the previous iteration: aggregate out, window requested now
+        u32 p_tile = E4_NONE, p_T = 0;                 // computed two iterations ago: resolved and stored now
+        u32 buf = 0;                                   // window buffer of `cur`; q: buf - 1, p: buf - 2 (mod 3)
+        u32 par = 0;                                   // iteration parity: which copy of the hand-over words is this iteration's
+        bool rotate_in = false;
+
+        for (;;) {
+            const bool cur_ok = cur < nfull;
+            const bool have_q = q_tile != E4_NONE, have_p = p_tile != E4_NONE;
+            if (!cur_ok && !have_q && !have_p) break;
+            const u32 pbuf = buf >= 2 ? buf - 2 : buf + 1;
+            u32 *win = dynwin + buf * win_stride + E4_GUARD;               // this tile's window
+            u32 *pwin = dynwin + pbuf * win_stride + E4_GUARD;             // the window that is stored in this iteration
+            Oct c_oct[4];
+            u32 tot = 0, incl = 0, tail = 0;
+
+            // ---- wave 0, before it issues anything new (see sfe4_kernel) -----------------------------------------------
+            if (wv == 0) {
+                if (lane == 0) sh.tick5[par] = req;    // last iteration's ticket request
+                if (have_p) {                          // prefix and lead bits of the tile that is stored in this iteration
+                    u64 B = 0;
+                    if (p_tile > 0) {
+                        B = lookback_sum_dpp(bdesc, (int)p_tile, bp->err, first_w);
+                        if (lane == 0) {
+                            desc_store(bdesc + p_tile, DESC_PREFIX, B + p_T);
+                            if (!ragged && p_tile == nfull - 1) gstore<u64>(bp->out_n, (B + p_T + 7) >> 3);
+                        }
+                        const u32 r = (u32)B & 31u;
+                        if (r) lead_bits(sh.lut, pwin, pv_w, r, lane);
+                    }
+                    if (lane == 0) sh.prefix5[par] = B;
+                }
+            }
+
+            // ---- this tile: look up, group, scan -----------------------------------------------------------------------
+            if (rotate_in) { cin = nin; nin = nin2; }
+            rotate_in = true;
+            if (cur_ok && nn < nfull) load_tile5<NT>(in, nn, tid, nin2);
+            if (tid == 0) req = atomicAdd(tick, 1u);
+            if (cur_ok) {
+                u32 absent = 0;
+                tile_octs5<NW, L16>(sh.lut, cin, c_oct, tot, incl, tail, absent);
+                if (absent) set_error(bp->err, SHAFA_FILE_UNRECOGNIZABLE);   // data symbol without a code (output undefined, in bounds)
+                if (lane == 63) {
+                    sh.wtot5[par][wv] = incl;
+                    sh.tail5[par][wv] = tail;
+                }
+            }
+            // The only barrier of the iteration.  Behind it: this tile's window (buffer buf) was last READ by the stores
+            // of the previous iteration, the window that is stored now (pbuf) was filled two iterations ago, and the
+            // hand-over words of this parity were last read two iterations ago.
+            lds_barrier();
+            const u32 n3 = sh.tick5[par];
+            if (wv != 0 && have_p)
+                store_window(pwin, bp->out, bp->out_cap, bp->err, sh.prefix5[par], p_T, !ragged && p_tile == nfull - 1, tid - 64,
+                             NT - 64);
+            u32 c_T = 0;
+            if (cur_ok) {
+                u32 woff;
+                c_T = tile_offsets5<NWV>(sh.wtot5[par], lane, wv, woff);
+                if (tid == 0) {
+                    if (cur == 0) {
+                        desc_store(bdesc, DESC_PREFIX, c_T);
+                        if (!ragged && nfull == 1) gstore<u64>(bp->out_n, ((u64)c_T + 7) >> 3);
+                    } else desc_store(bdesc + cur, DESC_AGG, c_T);
+                }
+                const u32 E = woff + incl;             // the lane's string is window bits [E - tot, E)
+                u32 e = E - tot;
+                // partial dword in front of the lane: the previous lane's last E mod 32 bits (wave_shr:1; lane 0: nothing
+                // arrives, the old value 0 stays), lane 0: the previous wave's (a tile starts at bit 0: alignbit by 0 of
+                // {x, 0} is 0, whatever tail[] holds)
+                const u32 fin = __builtin_amdgcn_alignbit(tail, 0u, E);
+                u32 c = (u32)__builtin_amdgcn_update_dpp(0, (int)fin, 0x138, 0xf, 0xf, false);
+                if (lane == 0) c = __builtin_amdgcn_alignbit(sh.tail5[par][wv ? wv - 1 : 0], 0u, e);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    e += c_oct[k].ll;
+                    c = emit_oct<NW>(win, sh.dump + lane, c_oct[k], e, c);
+                }
+                if (tid == NT - 1) {                   // the tile's final partial dword and the zero behind it; the lead word
+                    win[e >> 5] = c;                   //   (lead_bits ORs into it two iterations from now)
+                    win[(e >> 5) + 1] = 0u;
+                    win[-1] = 0u;
+                }
+            }
+            if (wv == 0) {
+                if (have_q && q_tile > 0) {            // descriptor window and leading symbols of the tile computed one iteration ago
+                    const int idx = (int)q_tile - 1 - lane;
+                    first_w = desc_load(bdesc + (idx > 0 ? idx : 0));
+                    if (lane < 32) pv_w = gload_off<u8>(in + (u64)q_tile * TILE - 32, 31u - (u32)lane);
+                }
+            }
+            par ^= 1u;
+            p_tile = q_tile; p_T = q_T;
+            q_tile = cur_ok ? cur : E4_NONE; q_T = c_T;
+            buf = buf == 2 ? 0 : buf + 1;
+            cur = nxt;
+            nxt = nn;
+            nn = n3;
+        }
+    }
+}
+
 // The ragged remainder (less than a tile) of every block whose size is not a multiple of the tile: one workgroup per block,
 // launched after sfe4_kernel, so the prefix of the last full tile is final.
 template <int NW, bool L16, int NT>
@@ -495,8 +746,10 @@ int e4_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         cus = prop.multiProcessorCount;
-        if (dyn > 65536)                               // more than the default 64 KiB of dynamic LDS per workgroup
+        if (dyn > 65536) {                             // more than the default 64 KiB of dynamic LDS per workgroup
             HIP_TRY(hipFuncSetAttribute((const void *)sfe4_kernel<NW, L16, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            HIP_TRY(hipFuncSetAttribute((const void *)sfe5_kernel<NW, L16, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        }
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)sfe4_kernel<NW, L16, NT>, NT, dyn));
         wgs_by_lmax[lmax] = occ < 1 ? 1 : (occ > 6 ? 6 : occ);   // residency is a matter of speed only (tickets), 6 = what the registers allow
     }
@@ -506,8 +759,12 @@ int e4_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32
     int nconc = count < target ? count : target;
     int per = target / nconc;
     if (per < 1) per = 1;
-    hipLaunchKernelGGL((sfe4_kernel<NW, L16, NT>), dim3((u32)(nconc * per)), dim3(NT), dyn, st, dblk, count, nconc, d_desc, d_tickets,
-                       win_stride);
+    if (g_sfe_variant == 5)
+        hipLaunchKernelGGL((sfe5_kernel<NW, L16, NT>), dim3((u32)(nconc * per)), dim3(NT), dyn, st, dblk, count, nconc, d_desc, d_tickets,
+                           win_stride);
+    else
+        hipLaunchKernelGGL((sfe4_kernel<NW, L16, NT>), dim3((u32)(nconc * per)), dim3(NT), dyn, st, dblk, count, nconc, d_desc, d_tickets,
+                           win_stride);
     if (any_ragged)
         hipLaunchKernelGGL((sfe4_tail_kernel<NW, L16, NT>), dim3((u32)count), dim3(NT), (size_t)win_stride * 4, st, dblk,
                            (const u64 *)d_desc, win_stride);
