@@ -31,7 +31,27 @@ import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+PKG_DIR = os.path.join(ROOT, "shafa-cd_amd")
+
+
+def load_pkg(sub=None):
+    """The product package by path (its directory name has a hyphen); `sub`: one of its submodules."""
+    import importlib
+    import importlib.util
+    if "shafa_cd_amd" not in sys.modules:
+        spec = importlib.util.spec_from_file_location("shafa_cd_amd", os.path.join(PKG_DIR, "__init__.py"),
+                                                      submodule_search_locations=[PKG_DIR])
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["shafa_cd_amd"] = mod
+        spec.loader.exec_module(mod)
+    return importlib.import_module("shafa_cd_amd." + sub) if sub else sys.modules["shafa_cd_amd"]
+
+
+def load_oracle():
+    """tests/oracle_lib.py: the CPU oracle, for the pre-timing spot check and the cpu_baseline leg ONLY."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    return oracle_lib
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (8.0 TB/s)
 GIB = float(1 << 30)
@@ -56,7 +76,11 @@ def parse_args(argv=None):
                     help="time X1 (root scatters whole blocks) + encode + X2 (root gathers the payloads) also at N=1")
     ap.add_argument("--no-scatter-gather", action="store_true", help="skip the X1/X2 leg at N>1")
     ap.add_argument("--pipeline", action="store_true",
-                    help="extra object: F (RLE + histogram) -> T -> C and D (SF + RLE decode) at this block size on run-heavy data")
+                    help="the F (RLE + histogram) -> T -> C and D (SF + RLE decode) leg on 32 blocks instead of the default 8")
+    ap.add_argument("--pipeline-blocks", type=int, default=8,
+                    help="blocks of the pipeline leg (`pipeline` object: per-family times and roofline fractions of K1, K2, K5 "
+                         "on run-heavy data at this block size; bounded, a fraction of a second of GPU time)")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the pipeline leg")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="shafa_hip_set_option(NAME, VALUE) before anything runs (A/B of kernel variants)")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -112,11 +136,11 @@ def measured_traffic(workload_key):
 
 
 def dist_table(pkg, args):
-    import golden.make_golden as mg
+    synth = load_pkg("synth")
     if args.dist == "zipfmod":
-        return mg.zipf_mod256_table(args.zipf_s)
+        return synth.zipf_mod256_table(args.zipf_s)
     if args.dist == "zipf":
-        return pkg.zipf_table(args.zipf_s)
+        return synth.zipf_table(args.zipf_s)
     return None
 
 
@@ -124,7 +148,7 @@ def cpu_baseline(args, pkg, zt):
     """Reference CPU path timed on the host cores: Module C then Module D (SF only) of the reference
     binary on a bounded sample of the same stream (its own wall clock incl. file I/O on tmpfs, as the
     reference's timer does, c.c:321,463).  Falls back to the oracle port (1 thread) without it."""
-    import oracle_lib
+    oracle_lib = load_oracle()
     orc = oracle_lib.load()
     nblk = args.cpu_sample_blocks
     bs = args.block_mib << 20
@@ -211,15 +235,35 @@ class Comm:
             self.dist.destroy_process_group()
 
 
-def pipeline_leg(args, pkg, torch, dev, st, steps):
+def pipeline_key(args, nb):
+    return f"pipeline:{args.block_mib}:{nb}"
+
+
+def measured_pipeline_traffic(pkey):
+    """per-kernel HBM bytes per launch of the pipeline leg from the newest profiles/*_traffic.json with this csrc hash
+    and pipeline key (tools/gpu_prof.sh); None otherwise."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    for fn in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if fn.endswith("_traffic.json"):
+            try:
+                with open(os.path.join(pdir, fn)) as f:
+                    j = json.load(f)
+            except Exception:
+                continue
+            if j.get("csrc_sha256") == csrc_hash() and j.get("pipeline_key") == pkey:
+                best = (fn, j)
+    return best
+
+
+def pipeline_leg(args, pkg, torch, dev, st, steps, nb):
     """F (RLE + histogram of the RLE bytes) -> T (host) -> C (SF encode of the RLE bytes), then D (SF decode + RLE
     decode) on run-heavy data (Zipf symbols in geometric runs, cfg-2 shape); per-family HIP-event times and
     algorithmic-byte rooflines."""
     import numpy as np
-    import golden.make_golden as mg
-    nb = min(args.blocks, 32)
+    synth = load_pkg("synth")
     bs = args.block_mib << 20
-    blk = torch.from_numpy(mg.runs_stream(11, bs, pkg.zipf_table(1.2))).to(dev)
+    blk = torch.from_numpy(synth.runs_stream(11, bs, synth.zipf_table(1.2))).to(dev)
     d_in = blk.repeat(nb)
     bt = pkg.Batch(nb, 2 * bs + 64)
     off, n = [b * bs for b in range(nb)], [bs] * nb
@@ -267,14 +311,30 @@ def pipeline_leg(args, pkg, torch, dev, st, steps):
     assert [int(x) for x in d_dec_n.cpu().numpy()] == n and torch.equal(d_dec[:bs], blk), "pipeline round trip differs"
     tot, rle_tot, enc_tot = float(nb * bs), float(sum(rle_n)), float(sum(enc_bytes))
 
-    def fam(alg, t):
-        return {"ms": t * 1e3, "algorithmic_bytes": alg, "achieved_GBs": alg / t / 1e9, "frac": alg / t / 1e9 / HBM_PEAK_GBS,
-                "GiBs_of_original": tot / GIB / t}
+    def fam(alg, t, name=None):
+        d = {"ms": t * 1e3, "algorithmic_bytes": alg, "achieved_GBs": alg / t / 1e9, "frac": alg / t / 1e9 / HBM_PEAK_GBS,
+             "GiBs_of_original": tot / GIB / t}
+        if name in traffic:
+            d["traffic"] = traffic[name]
+        return d
 
-    out.update({"rle_ratio": rle_tot / tot, "sf_ratio_of_rle": enc_tot / rle_tot,
-                "K1_hist256": fam(tot, t_h), "K2_rle_encode_hist": fam(tot + rle_tot, t_f),
+    # HBM traffic of the RLE kernels from the PMC passes of a profile of THIS code and leg (else null)
+    traffic = {"K1_hist256": None, "K2_rle_encode_hist": None, "K5_rle_decode": None}
+    tsrc = None
+    m = measured_pipeline_traffic(pipeline_key(args, nb))
+    if m:
+        pk = m[1]["per_kernel_bytes"]
+        tot_of = lambda pred: sum(v["read"] + v["written"] for k, v in pk.items() if pred(k))      # noqa: E731
+        rle3 = tot_of(lambda k: k.startswith("rle3_"))
+        if rle3:
+            traffic["K2_rle_encode_hist"] = rle3 + rle_tot     # + the fused histogram's one read of the RLE bytes
+        traffic["K5_rle_decode"] = tot_of(lambda k: k.startswith("rle_decode")) or None
+        traffic["K1_hist256"] = tot                             # hist256 reads its input once (PMC: 1.00 B/B)
+        tsrc = f"profiles/{m[0]}"
+    out.update({"rle_ratio": rle_tot / tot, "sf_ratio_of_rle": enc_tot / rle_tot, "traffic_source": tsrc,
+                "K1_hist256": fam(tot, t_h, "K1_hist256"), "K2_rle_encode_hist": fam(tot + rle_tot, t_f, "K2_rle_encode_hist"),
                 "T_host_ms": t_t * 1e3, "K3_sf_encode": fam(rle_tot + enc_tot, t_c),
-                "K4_sf_decode": fam(enc_tot + rle_tot, t_ds), "K5_rle_decode": fam(rle_tot + tot, t_dr),
+                "K4_sf_decode": fam(enc_tot + rle_tot, t_ds), "K5_rle_decode": fam(rle_tot + tot, t_dr, "K5_rle_decode"),
                 "F_T_C_GiBs": tot / GIB / (t_f + t_t + t_c), "D_GiBs": tot / GIB / (t_ds + t_dr)})
     bt.close()
     return out
@@ -288,8 +348,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    import pkgload
-    pkg = pkgload.load()
+    pkg = load_pkg()
 
     comm = Comm(args, torch, dist)
     world, rank, dev = comm.world, comm.rank, comm.dev
@@ -352,8 +411,7 @@ def main():
         assert torch.equal(d_dec, d_in), "decode(encode(x)) != x"
     if rank == 0 and os.environ.get("SHAFA_BENCH_ORACLE_CHECK", "1") == "1":
         import ctypes as C
-        import oracle_lib
-        orc = oracle_lib.load()
+        orc = load_oracle().load()
         blk = d_in[:min(bs, 4 << 20)].cpu().numpy()           # bounded oracle spot check of block 0's head
         otab = orc.sf_build(orc.hist256(blk))
         rc, want = orc.sf_encode(blk, otab)
@@ -393,6 +451,18 @@ def main():
     dec_ms = [ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(args.steps)]
     enc_t = float(np.mean(enc_ms)) * 1e-3
     dec_t = float(np.mean(dec_ms)) * 1e-3 if have_decode else 0.0
+    # every rank's own kernel-sequence times (HIP events on its stream): a straggler shows here
+    per_rank = None
+    if world > 1:
+        t_ = torch.tensor([enc_t * 1e3, dec_t * 1e3], dtype=torch.float64, device=dev if comm.backend == "nccl" else "cpu")
+        all_ = [torch.zeros_like(t_) for _ in range(world)]
+        dist.all_gather(all_, t_)
+        e_ = [float(x[0]) for x in all_]
+        d_ = [float(x[1]) for x in all_]
+    else:
+        e_, d_ = [enc_t * 1e3], [dec_t * 1e3]
+    per_rank = {"encode_ms": e_, "decode_ms": d_, "encode_ms_min": min(e_), "encode_ms_max": max(e_),
+                "decode_ms_min": min(d_), "decode_ms_max": max(d_)}
     total_in = float(shard)
     total_enc = float(enc_bytes.sum())
     # algorithmic bytes per launch: encode n + enc ; decode enc + n
@@ -419,7 +489,7 @@ def main():
     sg = None
     if ((world > 1 and not args.no_scatter_gather) or args.scatter_gather) and not comm.oversubscribed:
         def scatter_gather_leg():
-            shd = pkgload.load_submodule("sharding")
+            shd = load_pkg("sharding")
             sg_nb = min(nb, 16)                               # bounded: the root holds world * sg_nb blocks
             sg_shard = sg_nb * bs
             total_all = world * sg_shard
@@ -458,8 +528,14 @@ def main():
         bt.finish(st, nb)
 
     pipe = None
-    if args.pipeline and rank == 0:
-        pipe = pipeline_leg(args, pkg, torch, dev, st, max(2, min(args.steps, 5)))
+    if not args.no_pipeline and rank == 0:
+        try:
+            pipe = pipeline_leg(args, pkg, torch, dev, st, 3 if args.pipeline else 2,
+                                max(1, min(args.blocks, 32 if args.pipeline else args.pipeline_blocks)))
+        except AssertionError:
+            raise                                      # a parity failure is never swallowed
+        except Exception as e:                         # (memory on a small device: the headline line must still come out)
+            pipe = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     dist_name = {"zipfmod": f"Zipf({args.zipf_s:g}) mod 256", "zipf": f"Zipf({args.zipf_s:g}) truncated to 256 ranks",
                  "uniform": "uniform"}[args.dist]
@@ -486,6 +562,7 @@ def main():
                                  "frac": dec_gbs / HBM_PEAK_GBS, "traffic": traffic["sf_decode"],
                                  "algorithmic_bytes_per_launch": alg} if have_decode else None),
         }
+        out["per_rank"] = per_rank
         if comm.oversubscribed:
             out["invalid"] = "oversubscribed: ranks share GPUs (plumbing test only)"
         if sg:

@@ -15,8 +15,18 @@
  *      — used by the streaming drivers, bench.py and the multi-GPU sharding; every pointer named
  *      d_* is a DEVICE pointer, every h_* a HOST pointer.
  *
- * Threading: entry points may be called from one thread at a time per process (the reference's
- * drivers call from the main thread only, multithread.c:55-60).  No entry point throws or exits.
+ * Threading.  The reference calls the functions layer 1 replaces from one pthread per block at the same time
+ * (utils/multithread.c:70-87 starts `process` per block; c.c:411 compress_to_buffer, d.c:735 process_shafa_decomp), so
+ * LAYER 1 IS THREAD-SAFE: every shafa_hip_* entry point may be called from any number of host threads concurrently.
+ * Layer 1 keeps one stream and one pair of staging buffers per process and serialises the calls on an internal lock
+ * (one block's kernels fill the GPU; overlap of copies, kernels and I/O is what layer 3 is for).
+ * Layers 2 and 3: a batch / a pipe is used by one thread at a time; different batches and pipes may be used from different
+ * threads concurrently.  A batch serves one stream at a time: a launch on another stream first waits for the batch's
+ * previous stream.  The calling thread's current HIP device must be the batch's device (the one current at
+ * shafa_hipd_batch_create) for layer-2 calls; layer 1 and layer 3 select their devices themselves and NO entry point
+ * leaves the calling thread's current device changed.  shafa_hip_set_option() and shafa_hip_init*() are configuration:
+ * call them while no other call is in flight.  shafa_hip_last_error() is per calling thread.
+ * No entry point throws or exits.
  */
 #ifndef SHAFA_HIP_H
 #define SHAFA_HIP_H
@@ -28,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SHAFA_HIP_ABI_VERSION 3
+#define SHAFA_HIP_ABI_VERSION 4
 
 /* utils/errors.h:5-16 (_modules_error), same numbers */
 enum shafa_error {
@@ -75,8 +85,16 @@ const char *shafa_hip_last_error(void);      /* text of the last SHAFA_DEVICE_ER
  *   "sf_decode_speculate": 1 (default) lets blocks whose code re-synchronises take the speculative entry kernels of
  *       the Shannon-Fano decoder (verified exactly; falls back to the exact kernels per block), 0 = exact kernels only,
  *       2 = speculate for every block the kernels apply to, whatever its code (for tests of the fall-back).
+ *   "sf_encode_variant": 5 (default) = one-pass encoder with plain-store LDS windows and one barrier per tile
+ *       (sfe5_kernel), 4 = the form with atomic-OR windows (sfe4_kernel).
+ *   "sf_encode_lanes": 0 (default) = the widest workgroup whose windows fit the CU's LDS (1024 lanes, 32 KiB tiles, for
+ *       codes of <= 12 bits; 256 lanes otherwise), 256 / 512 = that width.
+ * Test knobs that force the fall-back kernels the library otherwise takes by itself (tests/test_gpu_codec.py):
+ *   "sf_decode_path": 0 (default) = the fastest kernels the tables allow, 1 = one code per look-up as for incomplete
+ *       codes, 2 = the generic byte-map kernels of codes longer than 32 bits.
+ *   "rle_encode_general": 1 = every tile takes the per-element general RLE code (long runs, ragged tiles), 0 = by data.
  * shafa_hip_init() reads the environment variables SHAFA_SF_ENCODE_ONE_PASS_MIN_BLOCKS and SHAFA_SF_DECODE_SPECULATE
- * once for the same knobs. */
+ * once for the first two knobs. */
 int shafa_hip_set_option(const char *name, long value);
 
 /* ------------------------------------------------------------------ layer 1: host buffers, one block */

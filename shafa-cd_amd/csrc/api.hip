@@ -7,10 +7,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 // ------------------------------------------------------------------------------------------------
-// error text
+// error text (per calling thread: the reference's drivers call the per-block functions from one thread per block)
 // ------------------------------------------------------------------------------------------------
-static char g_last_error[512] = "";
+static thread_local char g_last_error[512] = "";
 
 int shafa_set_hip_error(hipError_t e, const char *what)
 {
@@ -21,6 +23,21 @@ int shafa_set_hip_error(hipError_t e, const char *what)
 // ------------------------------------------------------------------------------------------------
 // batch context
 // ------------------------------------------------------------------------------------------------
+int batch_enter(Batch *b, hipStream_t st)
+{
+    if (!b) return SHAFA_OUTSIDE_MODULE;
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != b->device) {
+        snprintf(g_last_error, sizeof(g_last_error), "batch of device %d used while device %d is current", b->device, dev);
+        return SHAFA_DEVICE_ERROR;
+    }
+    if (b->has_last && b->last_st != st) HIP_TRY(hipStreamSynchronize(b->last_st));
+    b->last_st = st;
+    b->has_last = true;
+    return SHAFA_SUCCESS;
+}
+
 int batch_reserve(Batch *b, hipStream_t st, size_t bytes)
 {
     if (bytes <= b->ws_bytes) return SHAFA_SUCCESS;
@@ -121,6 +138,21 @@ int shafa_hip_set_option(const char *name, long value)
         g_sfe_variant = (int)value;
         return SHAFA_SUCCESS;
     }
+    if (name && !strcmp(name, "sf_encode_lanes")) {
+        extern int g_sfe_lanes;
+        if (value != 0 && value != 256 && value != 512) return SHAFA_OUTSIDE_MODULE;
+        g_sfe_lanes = (int)value;
+        return SHAFA_SUCCESS;
+    }
+    if (name && !strcmp(name, "sf_decode_path")) {
+        if (value < 0 || value > 2) return SHAFA_OUTSIDE_MODULE;
+        sfdec_configure_path((int)value);
+        return SHAFA_SUCCESS;
+    }
+    if (name && !strcmp(name, "rle_encode_general")) {
+        rleenc_configure(value != 0);
+        return SHAFA_SUCCESS;
+    }
     if (name && !strcmp(name, "sf_decode_speculate")) {
         sfdec_configure(value <= 0 ? 0 : value >= 2 ? 2 : 1);
         return SHAFA_SUCCESS;
@@ -135,6 +167,7 @@ int shafa_hipd_batch_create(int max_blocks, size_t max_block_bytes, shafa_hipd_b
     if (!b) return SHAFA_LACK_OF_MEMORY;
     b->max_blocks = max_blocks;
     b->max_block_bytes = max_block_bytes;
+    if (hipGetDevice(&b->device) != hipSuccess) { free(b); return SHAFA_DEVICE_ERROR; }
     b->h_hosterr = (int *)calloc((size_t)max_blocks, sizeof(int));
     if (!b->h_hosterr) { free(b); return SHAFA_LACK_OF_MEMORY; }
     hipError_t e = hipMalloc((void **)&b->d_err, (size_t)max_blocks * sizeof(int));
@@ -154,6 +187,8 @@ void shafa_hipd_batch_destroy(shafa_hipd_batch *hb)
 {
     Batch *b = (Batch *)hb;
     if (!b) return;
+    DeviceGuard dg(b->device);                     // the batch's device, whatever the caller's current device is
+    if (b->has_last) (void)hipStreamSynchronize(b->last_st);
     hipDeviceSynchronize();
     if (b->d_ws) hipFree(b->d_ws);
     if (b->segs) {
@@ -171,6 +206,7 @@ void shafa_hipd_batch_destroy(shafa_hipd_batch *hb)
 int shafa_hipd_hist256(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
                        const uint64_t *h_in_off, const uint64_t *h_in_n, uint64_t *d_freq)
 {
+    if (int rc = batch_enter((Batch *)b, (hipStream_t)stream)) return rc;
     return hist_launch((Batch *)b, (hipStream_t)stream, nblocks, d_in, h_in_off, h_in_n, d_freq);
 }
 
@@ -179,6 +215,7 @@ int shafa_hipd_rle_encode(shafa_hipd_batch *b, void *stream, int nblocks, const 
                           const uint64_t *h_out_off, const uint64_t *h_out_cap,
                           uint64_t *d_out_n, uint64_t *d_freq)
 {
+    if (int rc = batch_enter((Batch *)b, (hipStream_t)stream)) return rc;
     return rleenc_launch((Batch *)b, (hipStream_t)stream, nblocks, d_in, h_in_off, h_in_n, d_out, h_out_off,
                          h_out_cap, d_out_n, d_freq);
 }
@@ -188,6 +225,7 @@ int shafa_hipd_sf_encode(shafa_hipd_batch *b, void *stream, int nblocks, const u
                          const shafa_code_table *h_tables, uint8_t *d_out, const uint64_t *h_out_off,
                          const uint64_t *h_out_cap, uint64_t *d_out_n)
 {
+    if (int rc = batch_enter((Batch *)b, (hipStream_t)stream)) return rc;
     return sfenc_launch((Batch *)b, (hipStream_t)stream, nblocks, d_in, h_in_off, h_in_n, h_tables, d_out,
                         h_out_off, h_out_cap, d_out_n);
 }
@@ -197,6 +235,7 @@ int shafa_hipd_sf_decode(shafa_hipd_batch *b, void *stream, int nblocks, const u
                          const shafa_code_table *h_tables, const uint64_t *h_n_symbols,
                          uint8_t *d_out, const uint64_t *h_out_off)
 {
+    if (int rc = batch_enter((Batch *)b, (hipStream_t)stream)) return rc;
     return sfdec_launch((Batch *)b, (hipStream_t)stream, nblocks, d_in, h_in_off, h_in_n, h_tables,
                         h_n_symbols, d_out, h_out_off);
 }
@@ -205,6 +244,7 @@ int shafa_hipd_rle_decode(shafa_hipd_batch *b, void *stream, int nblocks, const 
                           const uint64_t *h_in_off, const uint64_t *h_in_n, uint8_t *d_out,
                           const uint64_t *h_out_off, const uint64_t *h_out_cap, uint64_t *d_out_n)
 {
+    if (int rc = batch_enter((Batch *)b, (hipStream_t)stream)) return rc;
     return rledec_launch((Batch *)b, (hipStream_t)stream, nblocks, d_in, h_in_off, h_in_n, d_out, h_out_off,
                          h_out_cap, d_out_n);
 }
@@ -213,6 +253,7 @@ int shafa_hipd_finish(shafa_hipd_batch *hb, void *stream, int nblocks, int *h_bl
 {
     Batch *b = (Batch *)hb;
     hipStream_t st = (hipStream_t)stream;
+    if (int rc = batch_enter(b, st)) return rc;
     if (nblocks > b->max_blocks) nblocks = b->max_blocks;
     if (nblocks < 0) nblocks = 0;
     if (nblocks) {
@@ -255,6 +296,17 @@ static struct {
 static int g_devs[64];
 static int g_ndevs = 0;                     // 0: layer 3 uses the layer-1 device only
 
+// Layer 1 keeps ONE stream, batch context and pair of staging buffers per process.  The reference calls the functions
+// layer 1 replaces from one thread per block at the same time (multithread.c:70-87 with c.c:411, d.c:735), so every
+// layer-1 entry point takes this lock for its whole duration: calls from several threads are safe and run one after the
+// other on the GPU (a block's kernels fill the device anyway; overlap of copies and kernels is what layer 3 is for).
+static std::recursive_mutex g_l1_mu;
+#define L1_ENTER()                                   \
+    std::lock_guard<std::recursive_mutex> l1_lock(g_l1_mu); \
+    int rc = lazy_init();                            \
+    if (rc) return rc;                               \
+    DeviceGuard l1_dev(g.device)
+
 static int ensure_dev(u8 **p, size_t *cap, size_t bytes)
 {
     if (bytes <= *cap) return SHAFA_SUCCESS;
@@ -267,6 +319,7 @@ static int ensure_dev(u8 **p, size_t *cap, size_t bytes)
 
 int shafa_hip_init(int device)
 {
+    std::lock_guard<std::recursive_mutex> l1_lock(g_l1_mu);
     if (g.ready && g.device == device) return SHAFA_SUCCESS;
     if (g.ready) shafa_hip_shutdown();
     int n = 0;
@@ -276,7 +329,7 @@ int shafa_hip_init(int device)
         return SHAFA_DEVICE_ERROR;
     }
     if (device < 0 || device >= n) return SHAFA_OUTSIDE_MODULE;
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard dg(device);                      // the caller's current device is left as it was
     if (const char *e = getenv("SHAFA_SF_ENCODE_ONE_PASS_MIN_BLOCKS")) shafa_hip_set_option("sf_encode_one_pass_min_blocks", atol(e));
     if (const char *e = getenv("SHAFA_SF_DECODE_SPECULATE")) shafa_hip_set_option("sf_decode_speculate", atol(e));
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
@@ -292,7 +345,9 @@ int shafa_hip_init(int device)
 
 void shafa_hip_shutdown(void)
 {
+    std::lock_guard<std::recursive_mutex> l1_lock(g_l1_mu);
     if (!g.ready) return;
+    DeviceGuard dg(g.device);
     hipDeviceSynchronize();
     shafa_hipd_batch_destroy((shafa_hipd_batch *)g.batch);
     if (g.d_a) hipFree(g.d_a);
@@ -306,6 +361,7 @@ void shafa_hip_shutdown(void)
 
 int shafa_hip_init_devices(const int *devices, int n_devices)
 {
+    std::lock_guard<std::recursive_mutex> l1_lock(g_l1_mu);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         snprintf(g_last_error, sizeof(g_last_error), "no HIP device visible");
@@ -324,7 +380,11 @@ int shafa_hip_init_devices(const int *devices, int n_devices)
 
 int shafa_hip_devices(void) { return g_ndevs ? g_ndevs : 1; }
 
-static int lazy_init(void) { return g.ready ? SHAFA_SUCCESS : shafa_hip_init(0); }
+static int lazy_init(void)
+{
+    std::lock_guard<std::recursive_mutex> l1_lock(g_l1_mu);
+    return g.ready ? SHAFA_SUCCESS : shafa_hip_init(0);
+}
 
 static int upload(const uint8_t *in, size_t n)
 {
@@ -336,8 +396,7 @@ static int upload(const uint8_t *in, size_t n)
 
 int shafa_hip_hist256(const uint8_t *in, size_t n, uint64_t freq[256])
 {
-    int rc = lazy_init();
-    if (rc) return rc;
+    L1_ENTER();
     if ((rc = upload(in, n))) return rc;
     const u64 off[1] = {0}, len[1] = {n};
     if ((rc = hist_launch(g.batch, g.stream, 1, g.d_a, off, len, g.d_small))) return rc;
@@ -348,8 +407,7 @@ int shafa_hip_hist256(const uint8_t *in, size_t n, uint64_t freq[256])
 int shafa_hip_rle_encode(const uint8_t *in, size_t n, uint8_t *out, size_t out_cap, size_t *out_n,
                          uint64_t *freq_out)
 {
-    int rc = lazy_init();
-    if (rc) return rc;
+    L1_ENTER();
     if (out_cap < 2 * n + 3) return SHAFA_LACK_OF_MEMORY;      // f.c:244 worst case
     if ((rc = upload(in, n))) return rc;
     const size_t cap = (2 * n + 3 + 15) & ~(size_t)15;
@@ -371,8 +429,7 @@ int shafa_hip_rle_encode(const uint8_t *in, size_t n, uint8_t *out, size_t out_c
 int shafa_hip_sf_encode(const uint8_t *in, size_t n, const shafa_code_table *table,
                         uint8_t *out, size_t out_cap, size_t *out_n)
 {
-    int rc = lazy_init();
-    if (rc) return rc;
+    L1_ENTER();
     if ((rc = upload(in, n))) return rc;
     const size_t cap = (out_cap + 15) & ~(size_t)15;
     if ((rc = ensure_dev(&g.d_b, &g.b_bytes, cap + 16))) return rc;
@@ -392,8 +449,7 @@ int shafa_hip_sf_encode(const uint8_t *in, size_t n, const shafa_code_table *tab
 int shafa_hip_sf_decode(const uint8_t *in, size_t in_n, const shafa_code_table *table,
                         uint8_t *out, size_t n_symbols)
 {
-    int rc = lazy_init();
-    if (rc) return rc;
+    L1_ENTER();
     if ((rc = upload(in, in_n))) return rc;
     if ((rc = ensure_dev(&g.d_b, &g.b_bytes, n_symbols + 64))) return rc;
     const u64 ioff[1] = {0}, ilen[1] = {in_n}, ooff[1] = {0}, ns[1] = {n_symbols};
@@ -406,8 +462,7 @@ int shafa_hip_sf_decode(const uint8_t *in, size_t in_n, const shafa_code_table *
 
 int shafa_hip_rle_decode(const uint8_t *in, size_t in_n, uint8_t *out, size_t out_cap, size_t *out_n)
 {
-    int rc = lazy_init();
-    if (rc) return rc;
+    L1_ENTER();
     if ((rc = upload(in, in_n))) return rc;
     size_t cap = out_cap < SHAFA_RLE_DECODE_MAX ? out_cap : SHAFA_RLE_DECODE_MAX;
     if ((rc = ensure_dev(&g.d_b, &g.b_bytes, cap + 64))) return rc;
@@ -425,4 +480,8 @@ int shafa_hip_rle_decode(const uint8_t *in, size_t in_n, uint8_t *out, size_t ou
 }  // extern "C"
 
 int api_lazy_init() { return lazy_init(); }     // layer 3 (pipe.hip)
-int api_pipe_device(int slot) { return g_ndevs ? g_devs[slot % g_ndevs] : g.device; }
+int api_pipe_device(int slot)
+{
+    std::lock_guard<std::recursive_mutex> l1_lock(g_l1_mu);
+    return g_ndevs ? g_devs[slot % g_ndevs] : g.device;
+}

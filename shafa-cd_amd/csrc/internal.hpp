@@ -17,6 +17,9 @@ struct StageSeg {
 
 // Reusable per-batch context behind the opaque shafa_hipd_batch handle.
 struct Batch {
+    int device;            // the device the batch was created on: its workspace, error words and kernels live there
+    hipStream_t last_st;   // the stream of the batch's last launch (a batch serves ONE stream at a time: a launch on a
+    bool has_last;         //   different stream first waits for the previous one, see batch_enter)
     int max_blocks;
     size_t max_block_bytes;
     void *d_ws;            // device workspace (grow-only; grown outside timed regions by warm-up calls)
@@ -30,6 +33,26 @@ struct Batch {
     int *d_err;            // one error code per block (first error wins)
     int *h_err;            // pinned mirror
     int *h_hosterr;        // errors found on the host while preparing a launch (malformed tables)
+};
+
+// Every layer-2 entry point starts with this: checks that the calling thread's current device is the batch's, and
+// serialises a change of stream (the workspace, the error words and the staging ring are shared by all launches of
+// a batch, so work enqueued on another stream must have finished before the new stream's launch reuses them).
+int batch_enter(Batch *b, hipStream_t st);
+
+// RAII: make `device` current for the calling thread, restore the caller's device on exit (a torch caller, or layer 1
+// next to a multi-device pipe, must not see its current device change under it)
+struct DeviceGuard {
+    int prev;
+    bool changed;
+    explicit DeviceGuard(int device) : prev(-1), changed(false)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) changed = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
 
 // make sure the device workspace holds `bytes` (growing waits for `st`, the only stream that uses this batch's workspace)
@@ -72,4 +95,6 @@ int rledec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
                   const u64 *h_in_n, u8 *d_out, const u64 *h_out_off, const u64 *h_out_cap, u64 *d_out_n);
 void sfenc_configure(int sfe4_min_blocks);
 void sfdec_configure(int speculate);
+void sfdec_configure_path(int path);
+void rleenc_configure(int force_general);
 int gen_launch(hipStream_t st, u64 seed, u64 first, const u8 *d_map, u8 *d_out, size_t n);

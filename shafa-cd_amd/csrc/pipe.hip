@@ -66,7 +66,8 @@ int grow_dev(u8 **p, size_t *cap, size_t need)
 int slot_submit(Slot &s, const shafa_code_table *table)
 {
     int rc;
-    HIP_TRY(hipSetDevice(s.device));
+    DeviceGuard dg(s.device);                      // the caller's current device is restored on return
+    if ((rc = batch_enter(s.batch, s.st))) return rc;
     const u64 off0[1] = {0}, in_n[1] = {s.in_n};
     if ((rc = grow_dev(&s.d_in, &s.d_in_cap, s.in_n))) return rc;
     if (s.in_n) HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, s.in_n, hipMemcpyHostToDevice, s.st));
@@ -148,15 +149,14 @@ int shafa_pipe_create(int n_slots, shafa_pipe **out)
         Slot &s = p->slots[i];
         shafa_hipd_batch *bh = nullptr;
         s.device = api_pipe_device(i);
-        hipError_t e = hipSetDevice(s.device);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking);
+        DeviceGuard dg(s.device);
+        hipError_t e = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc((void **)&s.d_small, 514 * sizeof(u64));
         if (e == hipSuccess) e = hipHostMalloc((void **)&s.h_small, 514 * sizeof(u64), hipHostMallocPortable);
         if (e != hipSuccess) { shafa_pipe_destroy(p); return shafa_set_hip_error(e, "shafa_pipe_create"); }
         if ((rc = shafa_hipd_batch_create(1, (size_t)1 << 27, &bh))) { shafa_pipe_destroy(p); return rc; }
         s.batch = (Batch *)bh;
     }
-    (void)hipSetDevice(api_pipe_device(0));
     *out = p;
     return SHAFA_SUCCESS;
 }
@@ -166,7 +166,7 @@ void shafa_pipe_destroy(shafa_pipe *p)
     if (!p) return;
     for (int i = 0; i < p->n_slots; ++i) {
         Slot &s = p->slots[i];
-        (void)hipSetDevice(s.device);
+        DeviceGuard dg(s.device);
         if (s.st) (void)hipStreamSynchronize(s.st);
         if (s.batch) shafa_hipd_batch_destroy((shafa_hipd_batch *)s.batch);
         if (s.h_in) hipHostFree(s.h_in);
@@ -178,7 +178,6 @@ void shafa_pipe_destroy(shafa_pipe *p)
         if (s.h_small) hipHostFree(s.h_small);
         if (s.st) hipStreamDestroy(s.st);
     }
-    (void)hipSetDevice(api_pipe_device(0));
     free(p->slots);
     free(p);
 }
@@ -217,7 +216,7 @@ int shafa_pipe_wait(shafa_pipe *p, int slot, shafa_pipe_result *res)
     if (!s.busy) return SHAFA_OUTSIDE_MODULE;
     s.busy = false;
     memset(res, 0, sizeof(*res));
-    HIP_TRY(hipSetDevice(s.device));
+    DeviceGuard dg(s.device);
     int rc = shafa_hipd_finish((shafa_hipd_batch *)s.batch, s.st, 1, nullptr);   // synchronises the slot's stream
     if (s.rc) return s.rc;
     if (rc) return rc;

@@ -35,7 +35,7 @@ struct RleBlk {
     u32 desc_base;
     u32 n_tiles;
     u32 ticket;
-    u32 pad;
+    u32 force_general;     // test knob ("rle_encode_general"): every tile takes the per-element general code
     uint2 *masks;          // per 32-byte granule of the block: {E, Z} masks of the first pass for the emit pass (pairs of tiles)
 };
 
@@ -303,7 +303,8 @@ __device__ __forceinline__ Rle3Pre rle3_preload(const RleBlk &blk, const int k, 
     return p;
 }
 
-__device__ __forceinline__ bool rle3_masks(RleShared &sh, const int k, Rle3Ctx &c, const bool lookahead, const Rle3Pre &pre)
+__device__ __forceinline__ bool rle3_masks(RleShared &sh, const int k, Rle3Ctx &c, const bool lookahead, const Rle3Pre &pre,
+                                           const u32 force_general = 0)
 {
     const int tid = threadIdx.x;
     if (!pre.full) return false;                                         // uniform
@@ -318,7 +319,7 @@ __device__ __forceinline__ bool rle3_masks(RleShared &sh, const int k, Rle3Ctx &
         }
         sh.E[0] = (u16)e0;
         sh.lastb[0] = (u16)lb;
-        sh.slow = 0;
+        sh.slow = force_general;
     }
     if (tid == RLE_THREADS - 1) {
         u32 e = 0;
@@ -377,7 +378,7 @@ __device__ __forceinline__ void rle3_first_tile(RleShared &sh, const RleBlk &blk
 {
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     Rle3Ctx c;
-    if (!rle3_masks(sh, k, c, true, pre)) {             // ragged tile, or the last full one: summary alone, size by rle3_fix
+    if (!rle3_masks(sh, k, c, true, pre, blk.force_general)) {   // ragged tile, or the last full one: summary alone, size by rle3_fix
         const Rle3Pre q = rle3_preload(blk, k, false);
         rle3_summary_tile(sh, blk, k, q, tsum);
         if (tid == 0) Tarr[blk.desc_base + k] = T_GENERAL;
@@ -508,7 +509,7 @@ __device__ __forceinline__ void rle3_pass_tile(RleShared &sh, const RleBlk &blk,
 {
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     Rle3Ctx c;
-    bool fast = rle3_masks(sh, k, c, true, pre);
+    bool fast = rle3_masks(sh, k, c, true, pre, blk.force_general);
     if (fast) {
         // mask code only when no run around the tile can reach 255 bytes inside it: at most 5 threads per wave lie
         // wholly inside a run (<= 10 across a wave edge: 192 bytes with both ends) and the entering run is < 60 bytes
@@ -696,7 +697,7 @@ __device__ __forceinline__ bool rle3_emit8k(R8Fast &sh, const RleBlk &blk, const
         u32 e0 = 0;
         if (kp > 0) e0 = (zmask4(qb ^ (qb << 8)) >> 1) << 29;      // E of positions -3, -2, -1 in bits 29..31
         sh.E[0] = e0;
-        sh.slow = 0;
+        sh.slow = blk.force_general;
     }
     if (tid == RLE_THREADS - 1) sh.E[RLE_THREADS + 1] = zmask4(qa ^ ((qa << 8) | (w[7] >> 24))) & 7u;
     lds_barrier();
@@ -877,7 +878,7 @@ __device__ __forceinline__ bool rle3_first8k(R8Fast &sh, const RleBlk &blk, cons
             pb0 = in.qb >> 24;
         }
         sh.E[0] = e0;
-        sh.slow = 0;
+        sh.slow = blk.force_general;
     }
     if (tid == RLE_THREADS - 1) sh.E[RLE_THREADS + 1] = zmask4(in.qa ^ ((in.qa << 8) | (w[7] >> 24))) & 7u;
     lds_barrier();
@@ -984,6 +985,9 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_fix(const RleBlk *__restrict
 
 }  // namespace
 
+static int g_rle_force_general = 0;
+void rleenc_configure(int force_general) { g_rle_force_general = force_general; }
+
 int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                   const u64 *h_in_n, u8 *d_out, const u64 *h_out_off, const u64 *h_out_cap, u64 *d_out_n,
                   u64 *d_freq)
@@ -1023,7 +1027,7 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
         e.desc_base = dbase;
         e.n_tiles = (u32)ceil_div_u64(h_in_n[b], RLE_TILE);
         e.ticket = (u32)b;
-        e.pad = 0;
+        e.force_general = g_rle_force_general ? 1u : 0u;
         e.masks = (uint2 *)(ws + o_M) + (size_t)dbase * (RLE_TILE / 32);
         dbase += e.n_tiles;
     }

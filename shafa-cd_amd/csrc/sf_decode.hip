@@ -27,6 +27,8 @@
 #include "common.hpp"
 #include "internal.hpp"
 
+#include <mutex>
+
 #include <algorithm>
 
 #include <stdlib.h>
@@ -2056,6 +2058,12 @@ void build_host_tab(const shafa_code_table &t, HostTab &h)
 
 static int g_sfd_speculate = 1;                    // 0 never, 1 where spec_worthwhile() says so, 2 wherever the kernels apply
 void sfdec_configure(int speculate) { g_sfd_speculate = speculate; }
+// test knob ("sf_decode_path"): 0 = the fastest kernels the launch's tables allow; 1 = treat every table as if it were not
+// a complete code: one code per look-up (sfd_sync16<false> + sfd_count13 + sfd_write13 for Lmax <= 13, the two-level
+// LUT passes sfd_count / sfd_write for 14..16 bits); 2 = the generic byte-map kernels (sfd_sync / sfd_tiles / sfd_count /
+// sfd_write) that otherwise serve codes of more than 32 bits
+static int g_sfd_path = 0;
+void sfdec_configure_path(int path) { g_sfd_path = path; }
 
 // Does a decoder that starts 256 bits early agree with the true parse when it reaches the chunk?  Answered per table by
 // simulation on random bits (any bit string is a concatenation of code words of a complete code, distributed as the
@@ -2076,8 +2084,12 @@ static bool spec_worthwhile(const shafa_code_table &t, const HostTab &h, bool fo
     }
     static u64 ckey[1024];
     static signed char cval[1024];                      // 0 = empty, 1 = no, 2 = yes
+    static std::mutex cmu;                              // decodes run on several host threads (pipes, layer 1 callers)
     const u32 slot = (u32)(key >> 17) & 1023u;
-    if (cval[slot] && ckey[slot] == key) return cval[slot] == 2;
+    {
+        std::lock_guard<std::mutex> lk(cmu);
+        if (cval[slot] && ckey[slot] == key) return cval[slot] == 2;
+    }
     const u32 K1 = h.K1;
     u64 rs = key | 1ull;
     auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; };
@@ -2104,6 +2116,7 @@ static bool spec_worthwhile(const shafa_code_table &t, const HostTab &h, bool fo
         if (!merged) ++fails;
     }
     const bool yes = fails <= 6;
+    std::lock_guard<std::mutex> lk(cmu);
     ckey[slot] = key;
     cval[slot] = yes ? 2 : 1;
     return yes;
@@ -2151,6 +2164,8 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     if (!total_tiles) return SHAFA_SUCCESS;
     u32 R = 16;
     while (R < lmax_all) R <<= 1;
+    if (g_sfd_path >= 1) pair_all = c16_all = c32_all = false;
+    if (g_sfd_path >= 2 && R < 32) R = 32;
 
     // workspace layout
     size_t off = 0;

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(ENC_THREADS) void sf_encode_generic(const EncBlk *_
 // host launcher
 // ------------------------------------------------------------------------------------------------
 void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 *d_tile_bits, u64 *d_tile_off, bool lut64);
-int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool ragged8, bool ragged32);
+int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, u32 ragged);
 
 // A launch with at least this many class-1 blocks takes the one-pass encoder: every block is its own chain, and with this
 // many chains (<= ~10 workgroups per block) a tile's look-back stays inside one 64-entry descriptor window.  Measured
@@ -335,12 +335,10 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     u32 *dtick = (u32 *)(ws + o_tick);
     if (cls_count[1]) {
         if (one_pass) {
-            bool ragged8 = false, ragged32 = false;    // a block has a remainder after its full 8 KiB / 32 KiB tiles
-            for (int b = 0; b < nblocks; ++b) {
-                ragged8 = ragged8 || (cls[b] == 1 && (h_in_n[b] & 8191));
-                ragged32 = ragged32 || (cls[b] == 1 && (h_in_n[b] & 32767));
-            }
-            if ((rc = sfenc4_launch(st, dblk + cls_first[1], cls_count[1], ddesc, dtick, lmax1, ragged8, ragged32))) return rc;
+            u32 ragged = 0;                            // bit 0 / 1 / 2: a block has a remainder after its full 8 / 16 / 32 KiB tiles
+            for (int b = 0; b < nblocks; ++b)
+                if (cls[b] == 1) ragged |= ((h_in_n[b] & 8191) ? 1u : 0u) | ((h_in_n[b] & 16383) ? 2u : 0u) | ((h_in_n[b] & 32767) ? 4u : 0u);
+            if ((rc = sfenc4_launch(st, dblk + cls_first[1], cls_count[1], ddesc, dtick, lmax1, ragged))) return rc;
         } else sfenc3_launch(st, dblk + cls_first[1], cls_count[1], max_tiles[1], (u32 *)(ws + o_tbits), ddesc, false);
     }
     if (cls_count[2]) sfenc3_launch(st, dblk + cls_first[2], cls_count[2], max_tiles[2], (u32 *)(ws + o_tbits), ddesc, true);

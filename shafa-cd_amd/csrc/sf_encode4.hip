@@ -31,7 +31,10 @@
 #include "common.hpp"
 #include "internal.hpp"
 
+#include <mutex>
+
 int g_sfe4_wide = 1;                                   // 0: always the 256-lane form (A/B and tests)
+int g_sfe_lanes = 0;                                   // 0: widest form that fits; 256 / 512: that workgroup width (A/B and tests)
 int g_sfe_variant = 5;                                 // 5: plain-store windows (sfe5_kernel); 4: atomic-OR windows (sfe4_kernel)
 
 namespace {
@@ -822,25 +825,36 @@ __global__ __launch_bounds__(NT) void sfe4_tail_kernel(const EncBlk *__restrict_
 template <int NW, bool L16, int NT>
 int e4_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool any_ragged)
 {
-    static int wgs_by_dev_lmax[16][17], cus = 0;       // per device: the LDS attribute below belongs to the device's copy of the kernel
+    // per device: the LDS attribute below belongs to the device's copy of the kernel, and devices may differ in CUs.
+    // (Statics of a template: one set per instantiation.  Guarded: pipes on several host threads launch concurrently.)
+    constexpr int MAXDEV = 64;
+    static int wgs_by_dev_lmax[MAXDEV][17], cus_by_dev[MAXDEV];
+    static std::mutex mu;
     const u32 win_stride = ((u32)E4_GUARD + (u32)(((size_t)(32 * NT) * lmax) >> 5) + 8u + 3u) & ~3u;   // dwords per buffer
     const size_t dyn = (size_t)win_stride * 3 * 4;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    int *wgs_by_lmax = wgs_by_dev_lmax[dev & 15];
-    if (!wgs_by_lmax[lmax]) {
-        int occ = 0;
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, dev));
-        cus = prop.multiProcessorCount;
-        if (dyn > 65536) {                             // more than the default 64 KiB of dynamic LDS per workgroup
-            HIP_TRY(hipFuncSetAttribute((const void *)sfe4_kernel<NW, L16, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-            HIP_TRY(hipFuncSetAttribute((const void *)sfe5_kernel<NW, L16, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    if (dev < 0 || dev >= MAXDEV) return SHAFA_OUTSIDE_MODULE;
+    int wgs_per_cu_v = 0, cus = 0;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        int *wgs_by_lmax = wgs_by_dev_lmax[dev];
+        if (!wgs_by_lmax[lmax]) {
+            int occ = 0;
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, dev));
+            cus_by_dev[dev] = prop.multiProcessorCount;
+            if (dyn > 65536) {                         // more than the default 64 KiB of dynamic LDS per workgroup
+                HIP_TRY(hipFuncSetAttribute((const void *)sfe4_kernel<NW, L16, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+                HIP_TRY(hipFuncSetAttribute((const void *)sfe5_kernel<NW, L16, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            }
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)sfe4_kernel<NW, L16, NT>, NT, dyn));
+            wgs_by_lmax[lmax] = occ < 1 ? 1 : (occ > 6 ? 6 : occ);   // residency is a matter of speed only (tickets), 6 = what the registers allow
         }
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)sfe4_kernel<NW, L16, NT>, NT, dyn));
-        wgs_by_lmax[lmax] = occ < 1 ? 1 : (occ > 6 ? 6 : occ);   // residency is a matter of speed only (tickets), 6 = what the registers allow
+        wgs_per_cu_v = wgs_by_lmax[lmax];
+        cus = cus_by_dev[dev];
     }
-    const int wgs_per_cu = wgs_by_lmax[lmax];
+    const int wgs_per_cu = wgs_per_cu_v;
     // the grid is a multiple of the number of concurrently served blocks, so a workgroup stays with one block
     int target = cus * wgs_per_cu;
     int nconc = count < target ? count : target;
@@ -861,8 +875,11 @@ int e4_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32
 // the wide form — ONE workgroup of 1024 lanes per CU, 32 KiB tiles — when its three windows (and the 2 KiB of static
 // LDS) fit the CU's 160 KiB: Lmax <= 12
 template <int NW, bool L16>
-int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool ragged8, bool ragged32)
+int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, u32 ragged)
 {
+    const bool ragged8 = ragged & 1u, ragged16 = ragged & 2u, ragged32 = ragged & 4u;
+    if (g_sfe_lanes == 512 && g_sfe_variant == 5) return e4_launch_nt<NW, L16, 512>(st, dblk, count, d_desc, d_tickets, lmax, ragged16);
+    if (g_sfe_lanes == 256) return e4_launch_nt<NW, L16, 256>(st, dblk, count, d_desc, d_tickets, lmax, ragged8);
     const size_t wide = (size_t)((((u32)E4_GUARD + (u32)(((size_t)32768 * lmax) >> 5) + 8u + 3u) & ~3u)) * 3 * 4 + sizeof(E4Static) + 64;
     if (g_sfe4_wide && wide <= 160 * 1024) return e4_launch_nt<NW, L16, 1024>(st, dblk, count, d_desc, d_tickets, lmax, ragged32);
     return e4_launch_nt<NW, L16, 256>(st, dblk, count, d_desc, d_tickets, lmax, ragged8);
@@ -880,10 +897,10 @@ extern "C" int shafa_e4_read_stamps(unsigned long long *dst, int n)
 // launched from sfenc_launch (sf_encode.hip) for blocks whose codes are <= 16 bits when the launch holds enough blocks
 // to keep every chain short; desc (one u64 per tile) and tickets (one u32 per block) are zeroed by the caller;
 // tables are 256 x u64 {code, len}
-int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool ragged8, bool ragged32)
+int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, u32 ragged)
 {
-    if (lmax <= 8) return e4_launch_t<3, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged8, ragged32);
-    if (lmax <= 12) return e4_launch_t<4, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged8, ragged32);
-    if (lmax <= 15) return e4_launch_t<5, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged8, ragged32);
-    return e4_launch_t<5, true>(st, dblk, count, d_desc, d_tickets, lmax, ragged8, ragged32);
+    if (lmax <= 8) return e4_launch_t<3, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged);
+    if (lmax <= 12) return e4_launch_t<4, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged);
+    if (lmax <= 15) return e4_launch_t<5, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged);
+    return e4_launch_t<5, true>(st, dblk, count, d_desc, d_tickets, lmax, ragged);
 }

@@ -22,6 +22,7 @@
 #include "shafa_host.h"
 
 #include <pthread.h>
+#include <sys/stat.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -190,16 +191,19 @@ static bool read_u64(text_t *t, uint64_t *v)
     return true;
 }
 
-/* bytes between the read position and the end of a regular file: a block size announced by a header can never
- * exceed it (checked before a pinned buffer of that size is requested) */
-static uint64_t bytes_left(FILE *f)
+/* Bytes of a regular file that have not been consumed yet: a block size announced by a header can never exceed them
+ * (checked before a pinned buffer of that size is requested).  The size is taken ONCE with fstat after fopen and the
+ * drivers count what they read: an ftell / fseek pair per block would drop the stdio read buffer on the path that feeds
+ * the GPU pipeline.  A stream that is not a regular file (a pipe) has no bound: the fread that follows decides. */
+typedef struct { uint64_t size, used; bool bounded; } in_budget;
+static in_budget budget_of(FILE *f)
 {
-    const long here = ftell(f);
-    if (here < 0 || fseek(f, 0, SEEK_END) != 0) return 0;
-    const long end = ftell(f);
-    if (fseek(f, here, SEEK_SET) != 0 || end < here) return 0;
-    return (uint64_t)(end - here);
+    in_budget b = {0, 0, false};
+    struct stat sb;
+    if (f && fstat(fileno(f), &sb) == 0 && S_ISREG(sb.st_mode)) { b.size = (uint64_t)sb.st_size; b.bounded = true; }
+    return b;
 }
+static bool budget_has(const in_budget *b, uint64_t want) { return !b->bounded || want <= b->size - (b->used < b->size ? b->used : b->size); }
 
 /* "@<R|N>@<n>" (f.c:289,294; t.c:302) */
 static bool read_header(text_t *t, char *mode, uint64_t *n)
@@ -428,6 +432,7 @@ _modules_error shafa_compress(char **path)
 
     FILE *in = fopen(*path, "rb");
     if (!in) { free(t.buf); return SHAFA_FILE_INACCESSIBLE; }
+    in_budget left = budget_of(in);
     char *p_shaf = shafa_add_ext(*path, SHAFA_SHAFA_EXT);
     FILE *out = p_shaf ? fopen(p_shaf, "wb") : NULL;
     uint64_t *in_sizes = malloc((n_blocks ? n_blocks : 1) * 2 * sizeof(uint64_t));
@@ -457,10 +462,11 @@ _modules_error shafa_compress(char **path)
             const int perr = shafa_cod_parse(codes, &tab);                       /* c.c:115-177 */
             t.buf[t.pos] = keep;
             const int slot = (int)(sub % depth);
-            if (size > bytes_left(in)) { err = SHAFA_FILE_STREAM_FAILED; break; }                     /* fread would come up short */
+            if (!budget_has(&left, size)) { err = SHAFA_FILE_STREAM_FAILED; break; }                  /* fread would come up short */
             uint8_t *buf = shafa_pipe_in(pipe, slot, size);
             if (!buf) { err = SHAFA_LACK_OF_MEMORY; break; }
             if (fread(buf, 1, size, in) != size) { err = SHAFA_FILE_STREAM_FAILED; break; }          /* c.c:392 */
+            left.used += size;
             unsigned lmax = 0;
             for (int q = 0; q < 256; ++q) lmax = tab.len[q] > lmax ? tab.len[q] : lmax;
             const size_t need = (size_t)((size * (uint64_t)lmax + 7) / 8) + 16;  /* exact upper bound, not 1.05 n (c.c:58) */
@@ -533,6 +539,7 @@ _modules_error rle_decompress(char **path)
     if (!in) return SHAFA_FILE_INACCESSIBLE;
     char *p_out = shafa_rm_ext(*path);
     FILE *out = p_out ? fopen(p_out, "wb") : NULL;                               /* d.c:256 */
+    in_budget left = budget_of(in);
     char *p_freq = shafa_add_ext(*path, SHAFA_FREQ_EXT);
     int err = (!p_out || !p_freq) ? SHAFA_LACK_OF_MEMORY : (!out ? SHAFA_FILE_INACCESSIBLE : SHAFA_SUCCESS);
     text_t t = {0};
@@ -559,10 +566,11 @@ _modules_error rle_decompress(char **path)
     while (!err && ret < n_blocks) {
         if (sub < n_blocks && sub - ret < depth) {
             const int slot = (int)(sub % depth);
-            if (sizes[sub] > bytes_left(in)) { err = SHAFA_FILE_STREAM_FAILED; break; }
+            if (!budget_has(&left, sizes[sub])) { err = SHAFA_FILE_STREAM_FAILED; break; }
             uint8_t *buf = shafa_pipe_in(pipe, slot, sizes[sub]);
             if (!buf) { err = SHAFA_LACK_OF_MEMORY; break; }
             if (fread(buf, 1, sizes[sub], in) != sizes[sub]) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* d.c:84 */
+            left.used += sizes[sub];
             if ((err = writer_wait(&wr, ticket[slot]))) break;
             err = shafa_pipe_submit(pipe, slot, SHAFA_OP_RLE_DECODE, sizes[sub], NULL, 0, 0, 0);   /* rle_block_decompressor */
             ++sub;
@@ -612,6 +620,7 @@ _modules_error shafa_decompress(char **path, bool decompress_rle)
     FILE *in = fopen(*path, "rb");
     if (!in) return SHAFA_FILE_INACCESSIBLE;
     int err = SHAFA_SUCCESS;
+    in_budget left = budget_of(in);
     char *p_tmp = shafa_rm_ext(*path);                                                /* X[.rle] */
     char *p_out = p_tmp ? (decompress_rle ? shafa_rm_ext(p_tmp) : shafa_add_ext(p_tmp, "")) : NULL;
     char *p_cod = p_tmp ? shafa_add_ext(p_tmp, SHAFA_CODES_EXT) : NULL;
@@ -642,10 +651,11 @@ _modules_error shafa_decompress(char **path, bool decompress_rle)
             uint64_t sf_n = 0, n_sym = 0;
             if (!shaf_read_u64(in, '@', &sf_n, true)) { err = SHAFA_FILE_STREAM_FAILED; break; }     /* d.c:697 */
             const int slot = (int)(sub % depth);
-            if (sf_n > bytes_left(in)) { err = SHAFA_FILE_STREAM_FAILED; break; }
+            if (!budget_has(&left, sf_n)) { err = SHAFA_FILE_STREAM_FAILED; break; }
             uint8_t *payload = shafa_pipe_in(pipe, slot, sf_n);
             if (!payload) { err = SHAFA_LACK_OF_MEMORY; break; }
             if (fread(payload, 1, sf_n, in) != sf_n) { err = SHAFA_FILE_STREAM_FAILED; break; }       /* d.c:706 */
+            left.used += sf_n;
             char *codes = NULL;
             if (!read_block(&t, &n_sym, &codes, SHAFA_COD_BLOCK_MAX)) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* d.c:709,716 */
             const char keep = t.buf[t.pos];

@@ -144,18 +144,27 @@ int main(int argc, char *const argv[])
     if (!o.block_size) o.block_size = SHAFA_64KiB;  /* shafa.c:304-305 */
 
     /* The reference's -m f/c/d start one thread per block on the host's cores; here the blocks of a file go to every
-     * GPU of the node (three in flight per GPU, retired in order).  SHAFA_DEVICES="0,2,3" restricts the set. */
-    {
+     * GPU of the node (three in flight per GPU, retired in order).  SHAFA_DEVICES="0,2,3" restricts the set; a list that
+     * names a GPU the node does not have is an error, not a silent fall-back to device 0.  Module T alone runs on the host
+     * and touches no GPU. */
+    if (o.f || o.c || o.d) {
         int devs[64], nd = 0;
         const char *e = getenv("SHAFA_DEVICES");
+        bool bad = false;
         for (const char *q = e; q && *q && nd < 64;) {
             char *end = NULL;
             const long v = strtol(q, &end, 10);
-            if (end == q) break;
+            if (end == q || v < 0 || v > 1023) { bad = true; break; }
             devs[nd++] = (int)v;
+            if (*end && *end != ',') { bad = true; break; }
             q = (*end == ',') ? end + 1 : end;
         }
-        if (nd > 0 || shafa_hip_device_count() > 1) (void)shafa_hip_init_devices(devs, nd);    /* errors surface in the modules */
+        if (e && *e && (bad || nd == 0 || shafa_hip_init_devices(devs, nd) != SHAFA_SUCCESS)) {
+            fprintf(stderr, "SHAFA_DEVICES=%s does not name GPUs of this node (%d visible)\n", e, shafa_hip_device_count());
+            free(file);
+            return 1;
+        }
+        if (!(e && *e) && shafa_hip_device_count() > 1) (void)shafa_hip_init_devices(NULL, 0);   /* every visible GPU */
     }
     const int err = run_modules(&o, &file);
     free(file);

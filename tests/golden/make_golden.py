@@ -29,66 +29,14 @@ STORE_LIMIT = 400 * 1024  # files above this are recorded by hash only
 
 
 # ---------------------------------------------------------------- deterministic inputs
-def splitmix64(x):
-    x = (x + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
-    x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)).astype(np.uint64)
-    x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)).astype(np.uint64)
-    return x ^ (x >> np.uint64(31))
+# the generators live in the product package (shafa-cd_amd/synth.py: bench.py uses them too); tests may depend on the
+# product, not the other way round
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import pkgload  # noqa: E402
 
-
-def gen_bytes(seed, n, table=None, first=0):
-    """Same stream as oracle/shafa_oracle.c orc_gen_bytes and the HIP generator."""
-    with np.errstate(over="ignore"):
-        i = np.arange(first, first + n, dtype=np.uint64)
-        w = splitmix64(np.uint64(seed) + (i >> np.uint64(2)))
-        r16 = ((w >> (np.uint64(16) * (i & np.uint64(3)))) & np.uint64(0xFFFF)).astype(np.int64)
-    if table is None:
-        return (r16 >> 8).astype(np.uint8)
-    return table[r16]
-
-
-def zipf_table(s=1.2, nsym=256):
-    """2^16-entry inverse CDF: table[r] = smallest k with cdf(k) * 65536 > r."""
-    w = np.arange(1, nsym + 1, dtype=np.float64) ** (-s)
-    cdf = np.cumsum(w) / np.sum(w)
-    edges = np.minimum(np.floor(cdf * 65536.0 + 0.5).astype(np.int64), 65536)
-    edges[-1] = 65536
-    table = np.zeros(65536, dtype=np.uint8)
-    lo = 0
-    for k in range(nsym):
-        table[lo:edges[k]] = k
-        lo = max(lo, edges[k])
-    return table
-
-
-def zipf_mod256_table(s=1.2):
-    """2^16-entry inverse CDF of "Zipf(s) over the positive integers, taken mod 256" (SURVEY.md §8(d) config 4):
-    P(byte b) = sum_j (b + 256 j)^-s / zeta(s).  Shannon-Fano output of such a 64 MiB block is 0.812 n."""
-    p = np.zeros(256, dtype=np.float64)
-    j = np.arange(0, 200000, dtype=np.float64)
-    for b in range(256):
-        k = (b if b else 256) + 256.0 * j
-        # tail of the series beyond the summed terms: integral of x^-s from the last term + 128
-        p[b] = np.sum(k ** (-s)) + (k[-1] + 128.0) ** (1.0 - s) / ((s - 1.0) * 256.0)
-    cdf = np.cumsum(p) / np.sum(p)
-    edges = np.minimum(np.floor(cdf * 65536.0 + 0.5).astype(np.int64), 65536)
-    edges[-1] = 65536
-    table = np.zeros(65536, dtype=np.uint8)
-    lo = 0
-    for k in range(256):
-        table[lo:edges[k]] = k
-        lo = max(lo, edges[k])
-    return table
-
-
-def runs_stream(seed, n, table, p=0.35):
-    """Zipf symbol repeated for a geometric run length (gives RLE something to do)."""
-    syms = gen_bytes(seed, n, table)
-    u = gen_bytes(seed ^ 0x5DEECE66D, n).astype(np.float64) / 256.0 + 1.0 / 512.0
-    runlen = (np.floor(np.log(u) / np.log(1.0 - p)) + 1).astype(np.int64)
-    out = np.repeat(syms, runlen)[:n]
-    assert out.size == n
-    return out.astype(np.uint8)
+_synth = pkgload.load_submodule("synth")
+splitmix64, gen_bytes, zipf_table = _synth.splitmix64, _synth.gen_bytes, _synth.zipf_table
+zipf_mod256_table, runs_stream = _synth.zipf_mod256_table, _synth.runs_stream
 
 
 def edge_stream():

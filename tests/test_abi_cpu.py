@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(shafa):
     L = ctypes.CDLL(shafa.LIB_PATH)
     missing = [s for s in syms if not hasattr(L, s)]
     assert not missing, f"declared in include/shafa_hip.h but not exported: {missing}"
-    assert L.shafa_hip_abi_version() == 3
+    assert L.shafa_hip_abi_version() == 4
     assert ctypes.sizeof(shafa.CodeTable) == 256 + 256 * 32
 
 
@@ -47,6 +47,12 @@ def test_library_exports_nothing_but_the_declared_symbols(shafa):
     assert shafa.lib().shafa_hip_set_option(b"sf_encode_one_pass_min_blocks", 0) == shafa.SUCCESS
     for v in (0, 2, 1):
         assert shafa.lib().shafa_hip_set_option(b"sf_decode_speculate", v) == shafa.SUCCESS
+    for name, good, bad in ((b"sf_encode_variant", (4, 5), 6), (b"sf_encode_lanes", (256, 512, 0), 100),
+                            (b"sf_decode_path", (1, 2, 0), 3), (b"rle_encode_general", (1, 0), None)):
+        for v in good:
+            assert shafa.lib().shafa_hip_set_option(name, v) == shafa.SUCCESS, (name, v)
+        if bad is not None:
+            assert shafa.lib().shafa_hip_set_option(name, bad) == shafa.OUTSIDE_MODULE, (name, bad)
 
 
 def test_no_gpu_is_reported_not_faked(shafa):

@@ -360,32 +360,46 @@ def test_sf_decode_codes_of_17_to_32_bits_fast_path(oracle, shafa):
         assert rc == shafa.FILE_UNRECOGNIZABLE
 
 
-@pytest.mark.parametrize("env", [{"SHAFA_RLE_V": "1"}, {"SHAFA_RLE_V": "1", "SHAFA_RLE_GENERAL": "1"},
-                                 {"SHAFA_ENC_V": "1"}, {"SHAFA_ENC_V": "2"}, {"SHAFA_ENC_V": "4"},
-                                 {"SHAFA_DEC_NOPAIR": "1"}, {"SHAFA_DEC_NOMULTI": "1"}, {"SHAFA_DEC_NOFSM": "1"},
-                                 {"SHAFA_DEC_NOLONG": "1"}, {"SHAFA_DEC_GENERIC": "1"}])
-def test_alternative_kernel_paths_stay_bit_exact(oracle, shafa, env):
-    """The selectable variants (chained RLE encoder, single-pass / persistent SF encoders, the decoder's fallbacks) are
-    kept for comparison and as fallbacks: each must still produce the oracle's bytes."""
+DEFAULT_OPTIONS = {"sf_encode_one_pass_min_blocks": 0, "sf_encode_variant": 5, "sf_encode_lanes": 0,
+                   "sf_decode_speculate": 1, "sf_decode_path": 0, "rle_encode_general": 0}
+
+
+@pytest.mark.parametrize("options", [
+    {"sf_encode_one_pass_min_blocks": 1 << 30},                            # count / scan / pack kernels (sfe3_*) for every launch
+    {"sf_encode_one_pass_min_blocks": 1},                                  # the one-pass kernel even for one block
+    {"sf_encode_one_pass_min_blocks": 1, "sf_encode_variant": 4},          # ... with atomic-OR windows (sfe4_kernel)
+    {"sf_encode_one_pass_min_blocks": 1, "sf_encode_lanes": 256},          # ... 256-lane workgroups, 8 KiB tiles
+    {"sf_encode_one_pass_min_blocks": 1, "sf_encode_lanes": 512},          # ... 512-lane workgroups, 16 KiB tiles
+    {"sf_decode_speculate": 0},                                            # exact DP kernels (sfd_sync16 / sfd_countfsm)
+    {"sf_decode_speculate": 2},                                            # speculative entries whatever the code
+    {"sf_decode_path": 1},                                                 # one code per look-up (sfd_count13 / sfd_write13, sfd_count / sfd_write)
+    {"sf_decode_path": 2},                                                 # generic byte-map kernels (sfd_sync / sfd_tiles)
+    {"rle_encode_general": 1},                                             # per-element general RLE tile code for every tile
+], ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
+def test_alternative_kernel_paths_stay_bit_exact(oracle, shafa, options):
+    """Every fall-back / alternative kernel path that the library can be told to take (shafa_hip_set_option) must produce
+    the oracle's bytes on the same inputs as the default path."""
     import golden.make_golden as mg
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
+    shafa.lib().shafa_hip_init(0)
+    for k, v in options.items():
+        shafa.set_option(k, v)
     try:
         zt = shafa.zipf_table(1.2)
         for n in (5000, 300001):
             data = mg.runs_stream(900 + n, n, zt)
             want = oracle.rle_encode(data)
             got, freq = shafa.rle_encode(data, want_freq=True)
-            assert got.tobytes() == want.tobytes(), f"{env} rle n={n}: {first_diff(got, want)}"
+            assert got.tobytes() == want.tobytes(), f"{options} rle n={n}: {first_diff(got, want)}"
+            assert (freq == oracle.hist256(want)).all(), f"{options} rle histogram n={n}"
+            assert shafa.rle_decode(want).tobytes() == data.tobytes(), f"{options} rle_decode n={n}"
             for src in (want, oracle.gen_bytes(n, n, shafa.zipf_table(2.0))):        # Lmax <= 13 and 14..16
                 otab = oracle.sf_build(oracle.hist256(src))
                 rc, enc = oracle.sf_encode(src, otab)
                 t = to_shafa_table(shafa, otab)
-                assert shafa.sf_encode(src, t).tobytes() == enc.tobytes(), f"{env} sf_encode n={n}"
-                assert shafa.sf_decode(enc, t, len(src)).tobytes() == src.tobytes(), f"{env} sf_decode n={n}"
+                got_enc = shafa.sf_encode(src, t)
+                assert got_enc.tobytes() == enc.tobytes(), f"{options} sf_encode n={n}: {first_diff(got_enc, enc)}"
+                back = shafa.sf_decode(enc, t, len(src))
+                assert back.tobytes() == src.tobytes(), f"{options} sf_decode n={n}: {first_diff(back, src)}"
     finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        for k, v in DEFAULT_OPTIONS.items():
+            shafa.set_option(k, v)

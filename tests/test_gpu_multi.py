@@ -78,7 +78,7 @@ def _gpu_count():
 @pytest.mark.parametrize("total,bs", [(5 * (1 << 20) + 4096 + 16, 1 << 20), (3 * (8 << 20), 8 << 20)])
 def test_scatter_hip_encode_gather_over_rccl(total, bs):
     import torch.multiprocessing as mp
-    world = max(1, min(_gpu_count(), 4))
+    world = max(1, _gpu_count())                   # one rank per visible GPU (8 on a full node)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29600 + (os.getpid() + total) % 1500
@@ -116,6 +116,23 @@ def test_bench_self_launches_ranks():
     assert ("invalid" in j) == (n < 2)
     if n >= 2:
         assert "scatter_gather" in j and j["scatter_gather"]["backend"] == "nccl"
+
+
+def test_bench_on_every_visible_gpu_over_rccl():
+    """`bench.py --gpus <all visible>` (not oversubscribed): one rank per GPU over RCCL, the X1/X2 leg present with
+    backend nccl, and per-rank encode/decode times in the line so that a straggler is visible.  On a one-GPU box this is
+    the N=1 line with --scatter-gather (the collectives still run through RCCL)."""
+    n = max(1, _gpu_count())
+    argv = ["--gpus", str(n), "--steps", "2", "--warmup", "1", "--blocks", "8", "--block-mib", "8", "--no-cpu"]
+    if n == 1:
+        argv.append("--scatter-gather")
+    j = _bench(argv, timeout=600)
+    assert j["n_gpus"] == n and "invalid" not in j
+    assert "scatter_gather" in j and "error" not in j["scatter_gather"] and j["scatter_gather"]["backend"] == "nccl"
+    pr = j["per_rank"]
+    assert len(pr["encode_ms"]) == n and len(pr["decode_ms"]) == n
+    assert pr["encode_ms_min"] <= pr["encode_ms_max"] and pr["decode_ms_min"] <= pr["decode_ms_max"]
+    assert all(x > 0 for x in pr["encode_ms"] + pr["decode_ms"])
 
 
 def test_bench_single_gpu_line_has_the_contract_fields():

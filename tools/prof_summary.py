@@ -107,7 +107,10 @@ if total_in:
             a[x] = args[i + 1]
     j = {"what": "HBM traffic from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, tools/gpu_prof.sh); "
                  "FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes",
-         "workload_key": f"{a['--dist']}:{float(a['--zipf-s']):g}:{a['--block-mib']}:{a['--blocks']}" + (":pipeline" if "--pipeline" in args else ""),
+         "workload_key": f"{a['--dist']}:{float(a['--zipf-s']):g}:{a['--block-mib']}:{a['--blocks']}",
+         "pipeline_key": (None if "--no-pipeline" in args else
+                          "pipeline:%s:%s" % (a["--block-mib"], min(int(a["--blocks"]), 32 if "--pipeline" in args else
+                                                                    int(next((args[i + 1] for i, x in enumerate(args) if x == "--pipeline-blocks"), 8))))),
          "bench_args": args, "csrc_sha256": csrc_hash(),
          "bytes_per_input_byte": {"sf_encode": enc / total_in if enc else None, "sf_decode": dec / total_in if dec else None},
          "algorithmic_bytes_per_input_byte": 1 + ratio,
