@@ -76,8 +76,8 @@ def parse_args(argv=None):
                     help="time X1 (root scatters whole blocks) + encode + X2 (root gathers the payloads) also at N=1")
     ap.add_argument("--no-scatter-gather", action="store_true", help="skip the X1/X2 leg at N>1")
     ap.add_argument("--pipeline", action="store_true",
-                    help="the F (RLE + histogram) -> T -> C and D (SF + RLE decode) leg on 32 blocks instead of the default 8")
-    ap.add_argument("--pipeline-blocks", type=int, default=8,
+                    help="(kept for old command lines: the pipeline leg runs by default)")
+    ap.add_argument("--pipeline-blocks", type=int, default=32,
                     help="blocks of the pipeline leg (`pipeline` object: per-family times and roofline fractions of K1, K2, K5 "
                          "on run-heavy data at this block size; bounded, a fraction of a second of GPU time)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the pipeline leg")
@@ -530,8 +530,8 @@ def main():
     pipe = None
     if not args.no_pipeline and rank == 0:
         try:
-            pipe = pipeline_leg(args, pkg, torch, dev, st, 3 if args.pipeline else 2,
-                                max(1, min(args.blocks, 32 if args.pipeline else args.pipeline_blocks)))
+            pipe = pipeline_leg(args, pkg, torch, dev, st, 3,
+                                max(1, min(args.blocks, args.pipeline_blocks)))
         except AssertionError:
             raise                                      # a parity failure is never swallowed
         except Exception as e:                         # (memory on a small device: the headline line must still come out)

@@ -659,8 +659,10 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restri
         u32 par = 0;                                   // iteration parity: which copy of the hand-over words is this iteration's
         bool rotate_in = false;
 
-        // (Unrolling this loop three times so that the three input register sets take turns without the sixteen v_mov of
-        // the rotation was measured: 3.40 ms against 3.34 - the code no longer fits the instruction cache as well.)
+        // (Measured and dropped, ms per 8 GiB against 3.34: this loop unrolled three times so that the three input register
+        // sets take turns without the sixteen v_mov of the rotation 3.40 - the code no longer fits the instruction cache
+        // as well; s_setprio 3 around wave 0's chain work 3.34; odd waves storing the resolved window AFTER they place
+        // the new tile 3.51; only waves 8..15 / 12..15 storing 3.37 / 3.47; 512-lane workgroups, two per CU, 3.48.)
         for (;;) {
             const bool cur_ok = cur < nfull;
             const bool have_q = q_tile != E4_NONE, have_p = p_tile != E4_NONE;

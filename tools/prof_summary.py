@@ -109,8 +109,7 @@ if total_in:
                  "FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes",
          "workload_key": f"{a['--dist']}:{float(a['--zipf-s']):g}:{a['--block-mib']}:{a['--blocks']}",
          "pipeline_key": (None if "--no-pipeline" in args else
-                          "pipeline:%s:%s" % (a["--block-mib"], min(int(a["--blocks"]), 32 if "--pipeline" in args else
-                                                                    int(next((args[i + 1] for i, x in enumerate(args) if x == "--pipeline-blocks"), 8))))),
+                          "pipeline:%s:%s" % (a["--block-mib"], min(int(a["--blocks"]), int(next((args[i + 1] for i, x in enumerate(args) if x == "--pipeline-blocks"), 32))))),
          "bench_args": args, "csrc_sha256": csrc_hash(),
          "bytes_per_input_byte": {"sf_encode": enc / total_in if enc else None, "sf_decode": dec / total_in if dec else None},
          "algorithmic_bytes_per_input_byte": 1 + ratio,
