@@ -37,6 +37,7 @@ import pkgload  # noqa: E402
 _synth = pkgload.load_submodule("synth")
 splitmix64, gen_bytes, zipf_table = _synth.splitmix64, _synth.gen_bytes, _synth.zipf_table
 zipf_mod256_table, runs_stream = _synth.zipf_mod256_table, _synth.runs_stream
+mixed_file_stream = _synth.mixed_file_stream
 
 
 def edge_stream():
@@ -117,6 +118,8 @@ def make_input(gen):
         return runs_stream(seed, n, zipf_table(1.2))
     if kind == "textlike":
         return textlike_stream(seed, n)
+    if kind == "mixed":
+        return mixed_file_stream(seed, n, gen.get("binary_first", True))
     if kind == "const":
         return np.full(n, gen["byte"], dtype=np.uint8)
     if kind == "alt01":
@@ -127,6 +130,8 @@ def make_input(gen):
 def run_case(name, files_in, cmds, note="", store_inputs=True, expect_rc=None, generators=None):
     """files_in: {fname: bytes}; cmds: list of argv lists (without the binary), run in order in a
     scratch dir; files whose name starts with 'decoded__' are produced by copying after -m d."""
+    if ONLY and name not in ONLY:
+        return
     out_dir = os.path.join(HERE, name)
     shutil.rmtree(out_dir, ignore_errors=True)
     os.makedirs(out_dir)
@@ -164,6 +169,9 @@ def run_case(name, files_in, cmds, note="", store_inputs=True, expect_rc=None, g
         json.dump(man, f, indent=1, sort_keys=True)
     total = sum(v["size"] for v in man["files"].values() if v["stored"])
     print(f"{name}: {len(man['files'])} files, {total} bytes stored")
+
+
+ONLY = set(sys.argv[1:])          # `python make_golden.py full_mixed_M` regenerates just that case
 
 
 def main():
@@ -263,6 +271,8 @@ def main():
     MiB = 1 << 20
 
     def big_case(name, fn, gen, cmds, note):
+        if ONLY and name not in ONLY:
+            return
         run_case(name, {fn: make_input(gen).tobytes()}, cmds, note=note, store_inputs=False, generators={fn: gen})
 
     # cfg-1 shape: uniform bytes at -b m (8 MiB blocks), 2 blocks; F (RLE rejected) -> T -> C, then D
@@ -297,6 +307,14 @@ def main():
         ["t", "-b", "M"], ["__copy__", "t", "orig__t"], ["__rm__", "t"],
         ["t.shaf"], ["__copy__", "t", "decoded__sf"],
     ], "64 MiB geometric symbol distribution with every byte present: Lmax 17-32")
+
+    # structured stand-in for BASELINE config[2] (Silesia is not available offline): a binary section (records, zero and
+    # 0xFF padding runs) in block 0, dictionary text in blocks 1 and 2.  Block 0 alone decides RLE for the whole file
+    # (f.c:250-258): it accepts, so the text blocks are RLE-coded although they would have declined.
+    big_case("full_mixed_M", "s", {"kind": "mixed", "seed": 4207, "n": 192 * MiB, "binary_first": True}, [
+        ["s", "-b", "M"], ["__copy__", "s", "orig__s"], ["__rm__", "s"],
+        ["s.rle.shaf"], ["__copy__", "s", "decoded__sf_rle"],
+    ], "3 x 64 MiB at -b M: binary section then dictionary text; RLE verdict of block 0 applied to the text blocks")
 
     # 9. CLI behaviour samples (exit codes + stderr text)
     run_case("cli_errors", {"z": runs_stream(11, 5000, zt).tobytes()}, [

@@ -83,7 +83,7 @@ GPU_CASES = ["runs_default", "edges_forced_rle", "uniform_no_rle", "uniform_forc
              "textlike_m", "tiny_1024", "tiny_1023", "cli_errors", "cfg0_K_runs", "cfg0_K_uniform"]
 # full-size blocks (8 MiB / 64 MiB; inputs rebuilt from the manifest's generators, outputs pinned by SHA-256)
 FULL_CASES = ["full_uniform_m", "full_zipf_M", "full_zipfmod_M_forced_rle", "full_single_run_M", "full_alt01_M",
-              "full_longtail_M"]
+              "full_longtail_M", "full_mixed_M"]
 
 
 def scratch_dir(tmp_path, case):

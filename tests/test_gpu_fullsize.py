@@ -86,7 +86,7 @@ def _cod_file(shafa, mode, sizes, tables):
 
 
 @pytest.mark.parametrize("case", ["full_uniform_m", "full_zipf_M", "full_zipfmod_M_forced_rle", "full_single_run_M",
-                                  "full_alt01_M", "full_longtail_M"])
+                                  "full_alt01_M", "full_longtail_M", "full_mixed_M"])
 def test_layer2_batches_reproduce_reference_files(case, shafa, oracle):
     S = Session(shafa, case)
     torch, bt, st, dev, nb = S.torch, S.bt, S.st, S.dev, S.nb

@@ -261,3 +261,31 @@ def test_roundtrip_property_random_tables(oracle):
         rle = oracle.rle_encode(data)
         rc, back = oracle.rle_decode(rle)
         assert rc == 0 and (back == data).all()
+
+
+def test_structured_mixed_file_pins_the_oracle(oracle):
+    """BASELINE config[2] stand-in with real-file structure (binary section in block 0, dictionary text after it,
+    3 x 64 MiB at -b M): the oracle's RLE sizes, RLE-byte histograms, block-0 RLE verdict and Shannon-Fano tables equal
+    what the reference binary wrote (.rle.freq / .rle.cod stored; .rle / .rle.shaf pinned by SHA-256 in the manifest and
+    replayed on the GPU box)."""
+    import golden.make_golden as mg
+    man, rd = case("full_mixed_M")
+    data = mg.make_input(man["generators"]["s"])
+    assert sha(data.tobytes()) == man["files"]["s"]["sha256"], "generator drifted from the fixture"
+    fmode, fblocks = parse_blocks_text(rd("s.rle.freq"))
+    cmode, cblocks = parse_blocks_text(rd("s.rle.cod"))
+    assert fmode == "R" and cmode == "R" and len(fblocks) == 3 == len(cblocks)
+    bs = 64 << 20
+    h = hashlib.sha256()
+    for b, ((fsize, ftext), (csize, ctext)) in enumerate(zip(fblocks, cblocks)):
+        r = oracle.rle_encode(data[b * bs:(b + 1) * bs])
+        assert r.size == fsize == csize, f"block {b}: RLE size {r.size} vs the reference's {fsize}"
+        h.update(r.tobytes())
+        freq = oracle.hist256(r)
+        assert oracle.freq_write_block(freq) == ftext, f"block {b}: .rle.freq"
+        assert oracle.cod_write_block(oracle.sf_build(freq)) == ctext, f"block {b}: .rle.cod"
+        if b == 0:      # f.c:250-258: block 0's gain (>= 5 %) switches RLE on for the text blocks too
+            assert (bs - r.size) / bs >= 0.05
+        else:           # ... which would have declined on their own
+            assert (bs - r.size) / bs < 0.05
+    assert h.hexdigest() == man["files"]["s.rle"]["sha256"], ".rle differs from the reference's"
