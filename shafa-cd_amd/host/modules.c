@@ -21,8 +21,10 @@
  */
 #include "shafa_host.h"
 
+#include <fcntl.h>
 #include <pthread.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -50,27 +52,87 @@ static int pipe_depth(void)
     return d > PIPE_SLOTS ? PIPE_SLOTS : d;
 }
 
+/* ------------------------------------------------------------------ block I/O
+ * A 64 MiB block through one fread / fwrite is a single-threaded copy between the page cache and the pinned buffer:
+ * about 12 ms per block, 5 GiB/s end to end, with the GPU pipeline (25-30 GiB/s PCIe-inclusive) waiting.
+ * Blocks are therefore moved with pread / pwrite at explicit offsets.  READS are split over a few helper threads for the
+ * duration of the call (the reference, too, touches a block from its own thread: multithread.c:126-194): page-cache /
+ * tmpfs reads scale with threads (tools/iobench/tmpfs_rw.c on the GPU box: 6.6 GiB/s with one thread, 15 with eight,
+ * 21-23 with sixteen).  WRITES of a new file do not: 5.5 GiB/s with one thread and LESS with more (2.8 with eight: the
+ * page allocations of one inode serialise), 7-7.7 into pages allocated beforehand — so a block is written by one thread
+ * and the file's pages are allocated ahead of the data by posix_fallocate where the final size is known.  That write path
+ * is what bounds the CLI end to end.  --no-multithread: everything inline. */
+enum { IO_THREADS = 12, IO_MIN_SLICE = 2 << 20 };
+typedef struct { int fd; uint8_t *buf; size_t n; off_t off; bool write; bool ok; } io_slice;
+
+static bool io_all(int fd, uint8_t *buf, size_t n, off_t off, bool write)
+{
+    while (n) {
+        const ssize_t k = write ? pwrite(fd, buf, n, off) : pread(fd, buf, n, off);
+        if (k <= 0) return false;                              /* error, or a file shorter than announced */
+        buf += k; n -= (size_t)k; off += k;
+    }
+    return true;
+}
+static void *io_slice_main(void *arg)
+{
+    io_slice *s = arg;
+    s->ok = io_all(s->fd, s->buf, s->n, s->off, s->write);
+    return NULL;
+}
+static bool par_io(int fd, const uint8_t *buf, size_t n, off_t off, bool write)
+{
+    size_t parts = (NO_MULTITHREAD || write) ? 1 : n / IO_MIN_SLICE;
+    if (parts > IO_THREADS) parts = IO_THREADS;
+    if (parts <= 1) return io_all(fd, (uint8_t *)buf, n, off, write);
+    io_slice sl[IO_THREADS];
+    pthread_t th[IO_THREADS];
+    bool started[IO_THREADS];
+    const size_t per = ((n / parts) + 4095) & ~(size_t)4095;
+    bool ok = true;
+    for (size_t i = 0; i < parts; ++i) {
+        const size_t lo = i * per, hi = (i + 1 == parts || (i + 1) * per > n) ? n : (i + 1) * per;
+        sl[i] = (io_slice){fd, (uint8_t *)buf + (lo < n ? lo : n), hi > lo ? hi - lo : 0, off + (off_t)lo, write, true};
+        started[i] = i > 0 && sl[i].n && pthread_create(&th[i], NULL, io_slice_main, &sl[i]) == 0;
+    }
+    for (size_t i = 0; i < parts; ++i)                           /* slice 0, and any slice whose thread did not start, inline */
+        if (!started[i] && sl[i].n) io_slice_main(&sl[i]);
+    for (size_t i = 0; i < parts; ++i) {
+        if (started[i]) pthread_join(th[i], NULL);
+        ok = ok && sl[i].ok;
+    }
+    return ok;
+}
+
 /* ------------------------------------------------------------------ ordered writer
  * The reference's write callbacks run in block order on the worker threads (multithread.c:75-86).
- * Here one writer thread takes "@size@" + payload jobs in order, so the main thread can already
- * read the next block while the previous result is written.  With --no-multithread the jobs are
- * written inline.  A job's payload is a slot's pinned result buffer: the slot must not be
+ * Here one writer thread takes "@size@" + payload jobs in order and appends them at the file offset it keeps, so the
+ * main thread can already read the next block while the previous result is written.  With --no-multithread the jobs
+ * are written inline.  A job's payload is a slot's pinned result buffer: the slot must not be
  * submitted again before writer_wait() on the job's ticket. */
-typedef struct { FILE *f; char hdr[40]; size_t hdr_n; const uint8_t *data; size_t n; } wjob;
+typedef struct { char hdr[40]; size_t hdr_n; const uint8_t *data; size_t n; } wjob;
 typedef struct {
     pthread_t th;
     pthread_mutex_t mu;
     pthread_cond_t cv;
     wjob q[8];
     uint64_t pushed, done;
+    int fd;                      /* every job of a writer goes to this file ... */
+    off_t off;                   /* ... at this offset (advanced by the thread that runs the jobs) */
     int err;
     bool threaded, stop;
+    pthread_t pre_th;            /* allocates the file's pages ahead of the data (writer_expect) */
+    bool pre_on;
+    off_t pre_from, pre_bytes;
 } writer_t;
 
-static int wjob_run(const wjob *j)
+static int wjob_run(writer_t *w, const wjob *j)
 {
-    if (j->hdr_n && fwrite(j->hdr, 1, j->hdr_n, j->f) != j->hdr_n) return SHAFA_FILE_STREAM_FAILED;
-    if (j->n && fwrite(j->data, 1, j->n, j->f) != j->n) return SHAFA_FILE_STREAM_FAILED;
+    if (w->fd < 0) return SHAFA_FILE_STREAM_FAILED;
+    if (j->hdr_n && !io_all(w->fd, (uint8_t *)j->hdr, j->hdr_n, w->off, true)) return SHAFA_FILE_STREAM_FAILED;
+    w->off += (off_t)j->hdr_n;
+    if (j->n && !par_io(w->fd, j->data, j->n, w->off, true)) return SHAFA_FILE_STREAM_FAILED;
+    w->off += (off_t)j->n;
     return SHAFA_SUCCESS;
 }
 
@@ -83,7 +145,7 @@ static void *writer_main(void *arg)
         if (w->done == w->pushed) break;
         const wjob j = w->q[w->done % 8];
         pthread_mutex_unlock(&w->mu);
-        const int e = wjob_run(&j);
+        const int e = wjob_run(w, &j);
         pthread_mutex_lock(&w->mu);
         if (e && !w->err) w->err = e;
         ++w->done;
@@ -96,19 +158,50 @@ static void *writer_main(void *arg)
 static void writer_start(writer_t *w)
 {
     memset(w, 0, sizeof(*w));
+    w->fd = -1;
     pthread_mutex_init(&w->mu, NULL);
     pthread_cond_init(&w->cv, NULL);
     w->threaded = !NO_MULTITHREAD && pthread_create(&w->th, NULL, writer_main, w) == 0;
 }
 
-/* returns the job's ticket (>= 1) */
-static uint64_t writer_push(writer_t *w, FILE *f, const char *hdr, const uint8_t *data, size_t n)
+/* the file the jobs go to (set before the first push; `off` = bytes already in it) */
+static void writer_target(writer_t *w, int fd, off_t off)
 {
-    wjob j = {.f = f, .data = data, .n = n};
+    pthread_mutex_lock(&w->mu);
+    w->fd = fd;
+    w->off = off;
+    pthread_mutex_unlock(&w->mu);
+}
+
+/* The file will grow by about `bytes` from the writer's current offset: a helper thread allocates those pages ahead of
+ * the data (posix_fallocate, 128 MiB at a time), which the writing thread then only has to fill.  An estimate is fine:
+ * writer_stop() cuts the file to what was written. */
+static void *writer_pre_main(void *arg)
+{
+    writer_t *w = arg;
+    const off_t step = (off_t)128 << 20;
+    for (off_t o = 0; o < w->pre_bytes; o += step) {
+        const off_t n = w->pre_bytes - o < step ? w->pre_bytes - o : step;
+        if (posix_fallocate(w->fd, w->pre_from + o, n) != 0) break;             /* not supported here: plain writes */
+    }
+    return NULL;
+}
+static void writer_expect(writer_t *w, uint64_t bytes)
+{
+    if (!w->threaded || w->fd < 0 || w->pre_on || bytes < ((uint64_t)32 << 20)) return;
+    w->pre_from = w->off;
+    w->pre_bytes = (off_t)bytes;
+    w->pre_on = pthread_create(&w->pre_th, NULL, writer_pre_main, w) == 0;
+}
+
+/* returns the job's ticket (>= 1) */
+static uint64_t writer_push(writer_t *w, const char *hdr, const uint8_t *data, size_t n)
+{
+    wjob j = {.data = data, .n = n};
     j.hdr_n = hdr ? strlen(hdr) : 0;
     if (j.hdr_n) memcpy(j.hdr, hdr, j.hdr_n);
     if (!w->threaded) {
-        const int e = wjob_run(&j);
+        const int e = wjob_run(w, &j);
         if (e && !w->err) w->err = e;
         return ++w->pushed, ++w->done;
     }
@@ -141,9 +234,26 @@ static int writer_stop(writer_t *w)
         pthread_mutex_unlock(&w->mu);
         pthread_join(w->th, NULL);
     }
+    if (w->pre_on) {
+        pthread_join(w->pre_th, NULL);
+        if (ftruncate(w->fd, w->off) != 0 && !w->err) w->err = SHAFA_FILE_STREAM_FAILED;   /* the estimate's surplus */
+    }
     pthread_mutex_destroy(&w->mu);
     pthread_cond_destroy(&w->cv);
     return w->err;
+}
+
+/* create / truncate an output file for the writer; the caller's text header (may be NULL) goes in first */
+static int out_open(const char *path, const char *header, off_t *off)
+{
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    *off = 0;
+    if (fd >= 0 && header) {
+        const size_t n = strlen(header);
+        if (!io_all(fd, (uint8_t *)header, n, 0, true)) { close(fd); return -2; }
+        *off = (off_t)n;
+    }
+    return fd;
 }
 
 static double now_ms(void)
@@ -196,11 +306,11 @@ static bool read_u64(text_t *t, uint64_t *v)
  * drivers count what they read: an ftell / fseek pair per block would drop the stdio read buffer on the path that feeds
  * the GPU pipeline.  A stream that is not a regular file (a pipe) has no bound: the fread that follows decides. */
 typedef struct { uint64_t size, used; bool bounded; } in_budget;
-static in_budget budget_of(FILE *f)
+static in_budget budget_of(int fd)
 {
     in_budget b = {0, 0, false};
     struct stat sb;
-    if (f && fstat(fileno(f), &sb) == 0 && S_ISREG(sb.st_mode)) { b.size = (uint64_t)sb.st_size; b.bounded = true; }
+    if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) { b.size = (uint64_t)sb.st_size; b.bounded = true; }
     return b;
 }
 static bool budget_has(const in_budget *b, uint64_t want) { return !b->bounded || want <= b->size - (b->used < b->size ? b->used : b->size); }
@@ -266,21 +376,20 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
 {
     const double t0 = now_ms();
     int err = SHAFA_SUCCESS;
-    FILE *in = fopen(*path, "rb");
-    if (!in) return SHAFA_FILE_INACCESSIBLE;
-    fseek(in, 0, SEEK_END);
-    const long fsz = ftell(in);
-    fseek(in, 0, SEEK_SET);
+    const int in = open(*path, O_RDONLY);
+    if (in < 0) return SHAFA_FILE_INACCESSIBLE;
+    const in_budget whole = budget_of(in);                                      /* fsize (f.c:212) */
     uint64_t bs = block_size, last = 0;
-    const uint64_t size_f = fsz > 0 ? (uint64_t)fsz : 0;
+    const uint64_t size_f = whole.bounded ? whole.size : 0;
     const uint64_t n_blocks = shafa_block_count(size_f, &bs, &last);
-    if (size_f < SHAFA_1KiB) { fclose(in); return SHAFA_FILE_TOO_SMALL; }      /* f.c:220,366 */
+    if (size_f < SHAFA_1KiB) { close(in); return SHAFA_FILE_TOO_SMALL; }       /* f.c:220,366 */
 
     char *p_rle = shafa_add_ext(*path, SHAFA_RLE_EXT);
     char *p_rle_freq = p_rle ? shafa_add_ext(p_rle, SHAFA_FREQ_EXT) : NULL;
     char *p_freq = shafa_add_ext(*path, SHAFA_FREQ_EXT);
     uint64_t *sizes = malloc(n_blocks * sizeof(uint64_t)), *rle_sizes = malloc(n_blocks * sizeof(uint64_t));
-    FILE *f_rle = NULL, *f_rle_freq = NULL, *f_freq = NULL;
+    FILE *f_rle_freq = NULL, *f_freq = NULL;
+    int f_rle = -1;
     bool use_rle = true;
     shafa_pipe *pipe = NULL;
     shafa_pipe_result *res = malloc(sizeof(*res));
@@ -300,7 +409,7 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
             uint8_t *buf = shafa_pipe_in(pipe, slot, n);
             if (!buf) { err = SHAFA_LACK_OF_MEMORY; break; }
             sizes[sub] = n;
-            if (fread(buf, 1, n, in) != n) { err = SHAFA_FILE_STREAM_FAILED; break; }
+            if (!par_io(in, buf, n, (off_t)(sub * bs), false)) { err = SHAFA_FILE_STREAM_FAILED; break; }
             /* block 0: RLE + both histograms (the decision is not known yet); later blocks: what is written */
             const int op = use_rle ? SHAFA_OP_RLE_ENCODE : SHAFA_OP_HIST;
             const int flags = (sub == 0 || force_freq) ? SHAFA_PIPE_INPUT_HIST : 0;
@@ -315,9 +424,12 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
         if (bk == 0) {                                                          /* f.c:250-295 */
             use_rle = shafa_rle_worthwhile(n, res->out_n, force_rle);
             if (use_rle) {
-                f_rle = fopen(p_rle, "wb");
+                off_t o0 = 0;
+                f_rle = out_open(p_rle, NULL, &o0);
                 f_rle_freq = fopen(p_rle_freq, "wb");
-                if (!f_rle || !f_rle_freq) { err = SHAFA_FILE_INACCESSIBLE; break; }
+                if (f_rle < 0 || !f_rle_freq) { err = SHAFA_FILE_INACCESSIBLE; break; }
+                writer_target(&wr, f_rle, 0);
+                writer_expect(&wr, size_f);
                 if (fprintf(f_rle_freq, "@R@%lu", (unsigned long)n_blocks) < 4) { err = SHAFA_FILE_STREAM_FAILED; break; }
             }
             if (!use_rle || force_freq) {
@@ -329,7 +441,7 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
         const bool was_rle = bk == 0 || use_rle;                                /* op the block ran with */
         if (use_rle) {
             rle_sizes[bk] = res->out_n;
-            ticket[bk % depth] = writer_push(&wr, f_rle, NULL, res->out, res->out_n);
+            ticket[bk % depth] = writer_push(&wr, NULL, res->out, res->out_n);
             err = put_freq_block(f_rle_freq, res->out_n, res->freq, bk + 1 == n_blocks);
             if (err) break;
         }
@@ -343,10 +455,10 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
     }
     shafa_pipe_destroy(pipe);
     free(res);
-    if (f_rle) fclose(f_rle);
+    if (f_rle >= 0) close(f_rle);
     if (f_rle_freq) fclose(f_rle_freq);
     if (f_freq) fclose(f_freq);
-    fclose(in);
+    close(in);
 
     if (!err) {
         const bool wrote_freq = !use_rle || force_freq;
@@ -430,16 +542,19 @@ _modules_error shafa_compress(char **path)
     uint64_t n_blocks = 0;
     if (!read_header(&t, &mode, &n_blocks)) { free(t.buf); return SHAFA_FILE_UNRECOGNIZABLE; }   /* c.c:333,447 */
 
-    FILE *in = fopen(*path, "rb");
-    if (!in) { free(t.buf); return SHAFA_FILE_INACCESSIBLE; }
+    const int in = open(*path, O_RDONLY);
+    if (in < 0) { free(t.buf); return SHAFA_FILE_INACCESSIBLE; }
     in_budget left = budget_of(in);
     char *p_shaf = shafa_add_ext(*path, SHAFA_SHAFA_EXT);
-    FILE *out = p_shaf ? fopen(p_shaf, "wb") : NULL;
+    char head[32];
+    snprintf(head, sizeof(head), "@%lu", (unsigned long)n_blocks);               /* c.c:351 */
+    off_t out_off = 0;
+    const int out = p_shaf ? out_open(p_shaf, head, &out_off) : -1;
     uint64_t *in_sizes = malloc((n_blocks ? n_blocks : 1) * 2 * sizeof(uint64_t));
     uint64_t *out_sizes = in_sizes ? in_sizes + n_blocks : NULL;
     if (!p_shaf || !in_sizes) err = SHAFA_LACK_OF_MEMORY;
-    else if (!out) err = SHAFA_FILE_INACCESSIBLE;
-    else if (fprintf(out, "@%lu", (unsigned long)n_blocks) < 2) err = SHAFA_FILE_STREAM_FAILED;
+    else if (out == -2) err = SHAFA_FILE_STREAM_FAILED;
+    else if (out < 0) err = SHAFA_FILE_INACCESSIBLE;
 
     shafa_pipe *pipe = NULL;
     shafa_pipe_result *res = malloc(sizeof(*res));
@@ -451,6 +566,8 @@ _modules_error shafa_compress(char **path)
     uint64_t sub = 0, ret = 0, ticket[PIPE_SLOTS] = {0};
     writer_t wr;
     writer_start(&wr);
+    writer_target(&wr, out, out_off);
+    if (!err && left.bounded) writer_expect(&wr, left.size);                     /* a .shaf is about as large as its input */
     while (!err && ret < n_blocks) {
         if (sub < n_blocks && sub - ret < depth) {
             uint64_t size = 0;
@@ -465,7 +582,7 @@ _modules_error shafa_compress(char **path)
             if (!budget_has(&left, size)) { err = SHAFA_FILE_STREAM_FAILED; break; }                  /* fread would come up short */
             uint8_t *buf = shafa_pipe_in(pipe, slot, size);
             if (!buf) { err = SHAFA_LACK_OF_MEMORY; break; }
-            if (fread(buf, 1, size, in) != size) { err = SHAFA_FILE_STREAM_FAILED; break; }          /* c.c:392 */
+            if (!par_io(in, buf, size, (off_t)left.used, false)) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* c.c:392 */
             left.used += size;
             unsigned lmax = 0;
             for (int q = 0; q < 256; ++q) lmax = tab.len[q] > lmax ? tab.len[q] : lmax;
@@ -475,6 +592,7 @@ _modules_error shafa_compress(char **path)
             out_sizes[sub] = (uint64_t)perr;
             trace("C:   read", t0);
             if ((err = writer_wait(&wr, ticket[slot]))) break;                  /* the slot's previous result is on disk */
+            trace("C:   slot's write done", t0);
             err = shafa_pipe_submit(pipe, slot, perr ? SHAFA_OP_HIST : SHAFA_OP_SF_ENCODE, perr ? 0 : size, &tab, 0, need, 0);
             trace("C:   submitted", t0);
             ++sub;
@@ -488,7 +606,7 @@ _modules_error shafa_compress(char **path)
         out_sizes[ret] = res->out_n;
         char hdr[40];
         snprintf(hdr, sizeof(hdr), "@%lu@", (unsigned long)res->out_n);         /* c.c:256-258 */
-        ticket[ret % depth] = writer_push(&wr, out, hdr, res->out, res->out_n);
+        ticket[ret % depth] = writer_push(&wr, hdr, res->out, res->out_n);
         trace("C:   write queued", t0);
         ++ret;
     }
@@ -500,8 +618,8 @@ _modules_error shafa_compress(char **path)
     shafa_pipe_destroy(pipe);
     trace("C: pipe destroyed", t0);
     free(res);
-    if (out) fclose(out);
-    fclose(in);
+    if (out >= 0) close(out);
+    close(in);
     if (!err) {
         if (SHAFA_VERBOSE) {
             printf("Module: C (Symbol codes' codification)\nNumber of blocks: %lu\n", (unsigned long)n_blocks);
@@ -535,13 +653,14 @@ static void d_summary(double ms, const uint64_t *before, const uint64_t *after, 
 _modules_error rle_decompress(char **path)
 {
     const double t0 = now_ms();
-    FILE *in = fopen(*path, "rb");
-    if (!in) return SHAFA_FILE_INACCESSIBLE;
+    const int in = open(*path, O_RDONLY);
+    if (in < 0) return SHAFA_FILE_INACCESSIBLE;
     char *p_out = shafa_rm_ext(*path);
-    FILE *out = p_out ? fopen(p_out, "wb") : NULL;                               /* d.c:256 */
+    off_t out_off = 0;
+    const int out = p_out ? out_open(p_out, NULL, &out_off) : -1;                /* d.c:256 */
     in_budget left = budget_of(in);
     char *p_freq = shafa_add_ext(*path, SHAFA_FREQ_EXT);
-    int err = (!p_out || !p_freq) ? SHAFA_LACK_OF_MEMORY : (!out ? SHAFA_FILE_INACCESSIBLE : SHAFA_SUCCESS);
+    int err = (!p_out || !p_freq) ? SHAFA_LACK_OF_MEMORY : (out < 0 ? SHAFA_FILE_INACCESSIBLE : SHAFA_SUCCESS);
     text_t t = {0};
     if (!err) err = slurp(p_freq, &t);
     char mode = 0;
@@ -563,13 +682,15 @@ _modules_error rle_decompress(char **path)
     uint64_t sub = 0, ret = 0, ticket[PIPE_SLOTS] = {0};
     writer_t wr;
     writer_start(&wr);
+    writer_target(&wr, out, out_off);
+    if (!err && left.bounded) writer_expect(&wr, left.size);                     /* at least the RLE bytes */
     while (!err && ret < n_blocks) {
         if (sub < n_blocks && sub - ret < depth) {
             const int slot = (int)(sub % depth);
             if (!budget_has(&left, sizes[sub])) { err = SHAFA_FILE_STREAM_FAILED; break; }
             uint8_t *buf = shafa_pipe_in(pipe, slot, sizes[sub]);
             if (!buf) { err = SHAFA_LACK_OF_MEMORY; break; }
-            if (fread(buf, 1, sizes[sub], in) != sizes[sub]) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* d.c:84 */
+            if (!par_io(in, buf, sizes[sub], (off_t)left.used, false)) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* d.c:84 */
             left.used += sizes[sub];
             if ((err = writer_wait(&wr, ticket[slot]))) break;
             err = shafa_pipe_submit(pipe, slot, SHAFA_OP_RLE_DECODE, sizes[sub], NULL, 0, 0, 0);   /* rle_block_decompressor */
@@ -579,7 +700,7 @@ _modules_error rle_decompress(char **path)
         err = shafa_pipe_wait(pipe, (int)(ret % depth), res);
         if (err) break;
         finals[ret] = res->out_n;
-        ticket[ret % depth] = writer_push(&wr, out, NULL, res->out, res->out_n);
+        ticket[ret % depth] = writer_push(&wr, NULL, res->out, res->out_n);
         ++ret;
     }
     {
@@ -588,8 +709,8 @@ _modules_error rle_decompress(char **path)
     }
     shafa_pipe_destroy(pipe);
     free(res);
-    if (out) fclose(out);
-    fclose(in);
+    if (out >= 0) close(out);
+    close(in);
     if (!err) {
         d_summary(now_ms() - t0, sizes, finals, n_blocks, p_out, 0);
         free(*path);
@@ -601,15 +722,21 @@ _modules_error rle_decompress(char **path)
 }
 
 /* "@<n>" then "@<size>@" + size raw bytes per block, from a binary stream (c.c:351,256) */
-static bool shaf_read_u64(FILE *f, char lead, uint64_t *v, bool trailing_at)
+static bool shaf_read_u64(int fd, off_t *off, char lead, uint64_t *v, bool trailing_at)
 {
-    if (fgetc(f) != lead) return false;
-    int c, digits = 0;
+    char b[32];
+    const ssize_t got = pread(fd, b, sizeof(b), *off);
+    if (got < 2 || b[0] != lead) return false;
+    ssize_t i = 1;
+    int digits = 0;
     uint64_t x = 0;
-    while ((c = fgetc(f)) >= '0' && c <= '9') { x = x * 10 + (uint64_t)(c - '0'); ++digits; }
+    while (i < got && b[i] >= '0' && b[i] <= '9' && digits < 20) { x = x * 10 + (uint64_t)(b[i] - '0'); ++digits; ++i; }
     if (!digits) return false;
-    if (trailing_at) { if (c != '@') return false; }
-    else if (c != EOF) ungetc(c, f);
+    if (trailing_at) {
+        if (i >= got || b[i] != '@') return false;
+        ++i;
+    }
+    *off += i;
     *v = x;
     return true;
 }
@@ -617,21 +744,23 @@ static bool shaf_read_u64(FILE *f, char lead, uint64_t *v, bool trailing_at)
 _modules_error shafa_decompress(char **path, bool decompress_rle)
 {
     const double t0 = now_ms();
-    FILE *in = fopen(*path, "rb");
-    if (!in) return SHAFA_FILE_INACCESSIBLE;
+    const int in = open(*path, O_RDONLY);
+    if (in < 0) return SHAFA_FILE_INACCESSIBLE;
     int err = SHAFA_SUCCESS;
     in_budget left = budget_of(in);
+    off_t in_off = 0;
     char *p_tmp = shafa_rm_ext(*path);                                                /* X[.rle] */
     char *p_out = p_tmp ? (decompress_rle ? shafa_rm_ext(p_tmp) : shafa_add_ext(p_tmp, "")) : NULL;
     char *p_cod = p_tmp ? shafa_add_ext(p_tmp, SHAFA_CODES_EXT) : NULL;
     if (!p_tmp || !p_out || !p_cod) err = SHAFA_LACK_OF_MEMORY;
-    FILE *out = !err ? fopen(p_out, "wb") : NULL;                                     /* d.c:663 (before any check) */
-    if (!err && !out) err = SHAFA_FILE_INACCESSIBLE;
+    off_t out_off = 0;
+    const int out = !err ? out_open(p_out, NULL, &out_off) : -1;                      /* d.c:663 (before any check) */
+    if (!err && out < 0) err = SHAFA_FILE_INACCESSIBLE;
     text_t t = {0};
     if (!err) err = slurp(p_cod, &t);
     uint64_t n_shaf = 0, n_blocks = 0;
     char mode = 0;
-    if (!err && !shaf_read_u64(in, '@', &n_shaf, false)) err = SHAFA_FILE_STREAM_FAILED;          /* d.c:673 */
+    if (!err && !shaf_read_u64(in, &in_off, '@', &n_shaf, false)) err = SHAFA_FILE_STREAM_FAILED; /* d.c:673 */
     if (!err && !read_header(&t, &mode, &n_blocks)) err = SHAFA_FILE_STREAM_FAILED;               /* d.c:676: .cod's count wins */
     if (!err && !((mode == 'N' && !decompress_rle) || mode == 'R')) err = SHAFA_FILE_UNRECOGNIZABLE;   /* d.c:678 */
 
@@ -646,15 +775,19 @@ _modules_error shafa_decompress(char **path, bool decompress_rle)
     uint64_t sub = 0, ret = 0, ticket[PIPE_SLOTS] = {0};
     writer_t wr;
     writer_start(&wr);
+    writer_target(&wr, out, out_off);
+    if (!err && left.bounded) writer_expect(&wr, left.size + left.size / 4);     /* decoded bytes: an estimate, cut at the end */
     while (!err && ret < n_blocks) {
         if (sub < n_blocks && sub - ret < depth) {
             uint64_t sf_n = 0, n_sym = 0;
-            if (!shaf_read_u64(in, '@', &sf_n, true)) { err = SHAFA_FILE_STREAM_FAILED; break; }     /* d.c:697 */
+            if (!shaf_read_u64(in, &in_off, '@', &sf_n, true)) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* d.c:697 */
             const int slot = (int)(sub % depth);
             if (!budget_has(&left, sf_n)) { err = SHAFA_FILE_STREAM_FAILED; break; }
             uint8_t *payload = shafa_pipe_in(pipe, slot, sf_n);
             if (!payload) { err = SHAFA_LACK_OF_MEMORY; break; }
-            if (fread(payload, 1, sf_n, in) != sf_n) { err = SHAFA_FILE_STREAM_FAILED; break; }       /* d.c:706 */
+            if (!par_io(in, payload, sf_n, in_off, false)) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* d.c:706 */
+            trace("D:   read", t0);
+            in_off += (off_t)sf_n;
             left.used += sf_n;
             char *codes = NULL;
             if (!read_block(&t, &n_sym, &codes, SHAFA_COD_BLOCK_MAX)) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* d.c:709,716 */
@@ -668,27 +801,32 @@ _modules_error shafa_decompress(char **path, bool decompress_rle)
             finals[sub] = (uint64_t)perr;                /* this block's own error, reported in block order */
             /* shafa_block_decompressor (+ rle_block_decompressor, d.c:574-586) */
             if ((err = writer_wait(&wr, ticket[slot]))) break;
+            trace("D:   slot's write done", t0);
             err = shafa_pipe_submit(pipe, slot, perr ? SHAFA_OP_HIST : (decompress_rle ? SHAFA_OP_SF_RLE_DECODE : SHAFA_OP_SF_DECODE),
                                     perr ? 0 : sf_n, &tab, n_sym, 0, 0);
+            trace("D:   submitted", t0);
             ++sub;
             continue;
         }
         const int perr = (int)finals[ret];
         err = shafa_pipe_wait(pipe, (int)(ret % depth), res);
+        trace("D:   waited", t0);
         if (perr) err = perr;
         if (err) break;
         finals[ret] = res->out_n;
-        ticket[ret % depth] = writer_push(&wr, out, NULL, res->out, res->out_n);
+        ticket[ret % depth] = writer_push(&wr, NULL, res->out, res->out_n);
         ++ret;
     }
     {
         const int werr = writer_stop(&wr);
         if (!err) err = werr;
     }
+    trace("D: loop done", t0);
     shafa_pipe_destroy(pipe);
+    trace("D: pipe destroyed", t0);
     free(res);
-    if (out) fclose(out);
-    fclose(in);
+    if (out >= 0) close(out);
+    close(in);
     if (!err) {
         d_summary(now_ms() - t0, sf_sizes, decompress_rle ? finals : sizes, n_blocks, p_out, decompress_rle ? 2 : 1);
         free(*path);

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 D=/dev/shm/shafa_e2e; rm -rf $D; mkdir -p $D
-timeout 300 python3 - 8 $D <<'PY'
+timeout 300 python3 - ${1:-8} $D <<'PY'
 import sys, os, torch
 sys.path.insert(0, "tests")
 from pkgload import load
@@ -18,5 +18,8 @@ PY
 export LD_LIBRARY_PATH=$PWD/shafa-cd_amd:$LD_LIBRARY_PATH
 O=shafa-cd_amd/bin/shafa
 timeout 300 $O $D/z -m f -b M > /dev/null; timeout 60 $O $D/z.freq -m t > /dev/null
-s=$(date +%s%N); SHAFA_TRACE=1 timeout 300 $O $D/z -m c 2>&1 >/dev/null | head -60; e=$(date +%s%N); echo "total $(( (e-s)/1000000 )) ms"
+s=$(date +%s%N); SHAFA_TRACE=1 timeout 300 $O $D/z -m c 2>&1 >/dev/null | tail -${2:-40}; e=$(date +%s%N); echo "total -m c $(( (e-s)/1000000 )) ms"
+cp $D/z $D/z.orig
+s=$(date +%s%N); SHAFA_TRACE=1 timeout 300 $O $D/z.shaf -m d 2>&1 >/dev/null | tail -${2:-40}; e=$(date +%s%N); echo "total -m d $(( (e-s)/1000000 )) ms"
+cmp $D/z $D/z.orig && echo "round trip identical"
 rm -rf $D
