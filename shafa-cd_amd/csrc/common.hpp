@@ -36,9 +36,23 @@ __device__ __forceinline__ u64 desc_load(const u64 *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Spin bound for every inter-workgroup wait: a lost predecessor sets the block's error instead of
-// hanging the GPU.
-#define SPIN_LIMIT (1u << 22)
+// Bound for every inter-workgroup wait: a lost predecessor sets the block's error instead of hanging the GPU.  The bound
+// is WALL-CLOCK time (s_memrealtime, the constant 100 MHz counter), not a number of polls: a predecessor that is merely
+// late — two processes sharing the GPU, a profiler, a pre-empted workgroup — is waited for; only several seconds without
+// progress count as lost.  (A poll count of 2^22 was about 0.15 s and turned contention into SHAFA_DEVICE_ERROR.)
+#define SPIN_SECONDS 4ull
+struct SpinClock {
+    u32 polls;
+    u64 t0;
+    __device__ __forceinline__ SpinClock() : polls(0), t0(0) {}
+    __device__ __forceinline__ bool expired()           // call once per unsuccessful poll
+    {
+        if ((++polls & 1023u) != 0) return false;       // look at the clock every 1024th poll
+        const u64 now = __builtin_amdgcn_s_memrealtime();
+        if (t0 == 0) { t0 = now | 1ull; return false; }
+        return now - t0 > SPIN_SECONDS * 100000000ull;
+    }
+};
 
 // LDS byte address of a __shared__ object.  Through the LDS address space, not the flat one: the cast of a flat
 // pointer carries a null check (s_cselect) that keeps the segment's base out of the ds instructions' offset field.
@@ -280,7 +294,7 @@ __device__ __forceinline__ u64 lookback_sum(const u64 *desc, int k, int *err, bo
     for (;;) {
         const int idx = j - lane;
         u64 d = 0;
-        u32 spins = 0;
+        SpinClock spin;
         for (;;) {
             if (have_first) d = first;
             else d = (idx >= 0) ? desc_load(desc + idx) : (DESC_PREFIX << 62);
@@ -290,7 +304,7 @@ __device__ __forceinline__ u64 lookback_sum(const u64 *desc, int k, int *err, bo
                 const u64 need = pm ? ((pm & (0 - pm)) - 1) : ~0ull;
                 if (!(em & need)) break;
             }
-            if (++spins > SPIN_LIMIT) {          // lost predecessor: flag instead of hanging
+            if (spin.expired()) {                // lost predecessor: flag instead of hanging
                 if (lane == 0) set_error(err, SHAFA_DEVICE_ERROR);
                 if ((d >> 62) == DESC_EMPTY) d = (DESC_PREFIX << 62);
                 break;
@@ -323,7 +337,7 @@ __device__ __forceinline__ u64 lookback_sum_dpp(const u64 *desc, int k, int *err
     for (;;) {
         const int idx = j - lane;
         u64 d = 0;
-        u32 spins = 0;
+        SpinClock spin;
         for (;;) {
             if (have_first) d = (idx >= 0) ? first : (DESC_PREFIX << 62);   // the caller loaded desc[max(idx, 0)]: no select there
             else d = (idx >= 0) ? desc_load(desc + idx) : (DESC_PREFIX << 62);
@@ -333,7 +347,7 @@ __device__ __forceinline__ u64 lookback_sum_dpp(const u64 *desc, int k, int *err
             // entries behind the nearest inclusive prefix are not needed
             const u64 need = pm ? ((pm & (0 - pm)) - 1) : ~0ull;       // lanes in front of the first prefix lane
             if (!(em & need)) break;
-            if (++spins > SPIN_LIMIT) {          // lost predecessor: flag instead of hanging
+            if (spin.expired()) {                // lost predecessor: flag instead of hanging
                 if (lane == 0) set_error(err, SHAFA_DEVICE_ERROR);
                 if ((d >> 62) == DESC_EMPTY) d = (DESC_PREFIX << 62);
                 break;

@@ -81,7 +81,7 @@ __device__ __forceinline__ u32 lookback_state(const u64 *desc, int k, int *err)
     for (;;) {
         const int idx = j - lane;
         u64 d = 0;
-        u32 spins = 0;
+        SpinClock spin;
         for (;;) {
             d = (idx >= 0) ? desc_load(desc + idx) : (DESC_PREFIX << 62);
             {   // entries behind the nearest tile that settles the state are not needed: do not wait for them
@@ -90,7 +90,7 @@ __device__ __forceinline__ u32 lookback_state(const u64 *desc, int k, int *err)
                 const u64 need = sm ? ((sm & (0 - sm)) - 1) : ~0ull;
                 if (!(em & need)) break;
             }
-            if (++spins > SPIN_LIMIT) {
+            if (spin.expired()) {
                 if (lane == 0) set_error(err, SHAFA_DEVICE_ERROR);
                 if ((d >> 62) == DESC_EMPTY) d = (DESC_PREFIX << 62);
                 break;

@@ -81,3 +81,26 @@ def test_no_entry_point_changes_the_callers_current_device(oracle, shafa):
     finally:
         shafa.init_devices([0])
         torch.cuda.set_device(0)
+
+
+def test_two_processes_sharing_the_gpu_finish_without_device_errors():
+    """Chained scans wait for predecessor tiles that belong to other workgroups; with a second process on the same GPU
+    (or a profiler) those may be late by milliseconds.  The wait is bounded by wall-clock seconds, not by a poll count,
+    so contention shows up as a slower run, never as SHAFA_DEVICE_ERROR."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["SHAFA_BENCH_ORACLE_CHECK"] = "0"
+    argv = [sys.executable, os.path.join(root, "bench.py"), "--blocks", "24", "--steps", "6", "--warmup", "1", "--no-cpu",
+            "--pipeline-blocks", "8"]
+    procs = [subprocess.Popen(argv, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for _ in range(3)]
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+        line = [ln for ln in out.splitlines() if ln.startswith("{")]
+        assert len(line) == 1 and json.loads(line[0])["value"] > 0

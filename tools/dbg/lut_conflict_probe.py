@@ -35,9 +35,12 @@ def table_for(hot):
     return t
 
 
-cases = {"32 slots (no conflicts)": list(range(32)),
+cases = {"warm-up (random 32)": list(np.random.RandomState(1).permutation(256)[:32]),     # the first case also pays the clock ramp
+         "32 slots (no conflicts)": list(range(32)),
+         "32 slots, other values": [7 * 32 + ((5 * i) % 32) for i in range(32)],
          "4 slots x 8 (worst)": [32 * k + j for j in range(4) for k in range(8)],
-         "random 32": list(np.random.RandomState(1).permutation(256)[:32])}
+         "random 32": list(np.random.RandomState(1).permutation(256)[:32]),
+         "random 32 (b)": list(np.random.RandomState(2).permutation(256)[:32])}
 for name, hot in cases.items():
     m = torch.tensor(hot, dtype=torch.uint8, device=dev)
     blk = m[torch.randint(0, 32, (bs,), device=dev)]
