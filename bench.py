@@ -130,7 +130,9 @@ def measured_traffic(workload_key):
                     j = json.load(f)
             except Exception:
                 continue
-            if j.get("csrc_sha256") == csrc_hash() and j.get("workload_key") == workload_key:
+            # profiles taken with the pipeline leg on mix its launches into the per-kernel means: headline traffic
+            # comes from a profile of the headline alone (--no-pipeline)
+            if j.get("csrc_sha256") == csrc_hash() and j.get("workload_key") == workload_key and not j.get("pipeline_key"):
                 best = (fn, j)
     return best
 

@@ -662,7 +662,9 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restri
         // (Measured and dropped, ms per 8 GiB against 3.34: this loop unrolled three times so that the three input register
         // sets take turns without the sixteen v_mov of the rotation 3.40 - the code no longer fits the instruction cache
         // as well; s_setprio 3 around wave 0's chain work 3.34; odd waves storing the resolved window AFTER they place
-        // the new tile 3.51; only waves 8..15 / 12..15 storing 3.37 / 3.47; 512-lane workgroups, two per CU, 3.48.)
+        // the new tile 3.51; only waves 8..15 / 12..15 storing 3.37 / 3.47; 512-lane workgroups, two per CU, 3.48; wave 0
+        // requesting q's descriptor window at the top and resolving it behind the barrier while the others store 3.44 - a
+        // request that early finds predecessors that have not published yet and the look-back polls.)
         for (;;) {
             const bool cur_ok = cur < nfull;
             const bool have_q = q_tile != E4_NONE, have_p = p_tile != E4_NONE;
