@@ -59,9 +59,8 @@ static int pipe_depth(void)
  * duration of the call (the reference, too, touches a block from its own thread: multithread.c:126-194): page-cache /
  * tmpfs reads scale with threads (tools/iobench/tmpfs_rw.c on the GPU box: 6.6 GiB/s with one thread, 15 with eight,
  * 21-23 with sixteen).  WRITES of a new file do not: 5.5 GiB/s with one thread and LESS with more (2.8 with eight: the
- * page allocations of one inode serialise), 7-7.7 into pages allocated beforehand — so a block is written by one thread
- * and the file's pages are allocated ahead of the data by posix_fallocate where the final size is known.  That write path
- * is what bounds the CLI end to end.  --no-multithread: everything inline. */
+ * page allocations of one inode serialise) — so a block is written by one thread.  That write path is what bounds the
+ * CLI end to end.  --no-multithread: everything inline. */
 enum { IO_THREADS = 12, IO_MIN_SLICE = 2 << 20 };
 typedef struct { int fd; uint8_t *buf; size_t n; off_t off; bool write; bool ok; } io_slice;
 
@@ -121,9 +120,6 @@ typedef struct {
     off_t off;                   /* ... at this offset (advanced by the thread that runs the jobs) */
     int err;
     bool threaded, stop;
-    pthread_t pre_th;            /* allocates the file's pages ahead of the data (writer_expect) */
-    bool pre_on;
-    off_t pre_from, pre_bytes;
 } writer_t;
 
 static int wjob_run(writer_t *w, const wjob *j)
@@ -173,27 +169,10 @@ static void writer_target(writer_t *w, int fd, off_t off)
     pthread_mutex_unlock(&w->mu);
 }
 
-/* The file will grow by about `bytes` from the writer's current offset: a helper thread allocates those pages ahead of
- * the data (posix_fallocate, 128 MiB at a time), which the writing thread then only has to fill.  An estimate is fine:
- * writer_stop() cuts the file to what was written. */
-static void *writer_pre_main(void *arg)
-{
-    writer_t *w = arg;
-    const off_t step = (off_t)128 << 20;
-    for (off_t o = 0; o < w->pre_bytes; o += step) {
-        const off_t n = w->pre_bytes - o < step ? w->pre_bytes - o : step;
-        if (posix_fallocate(w->fd, w->pre_from + o, n) != 0) break;             /* not supported here: plain writes */
-    }
-    return NULL;
-}
-static void writer_expect(writer_t *w, uint64_t bytes)
-{
-    if (!w->threaded || w->fd < 0 || w->pre_on || bytes < ((uint64_t)32 << 20)) return;
-    w->pre_from = w->off;
-    w->pre_bytes = (off_t)bytes;
-    w->pre_on = pthread_create(&w->pre_th, NULL, writer_pre_main, w) == 0;
-}
-
+/* (Allocating the file's pages ahead of the data with posix_fallocate on a helper thread was measured and removed: into
+ * allocated pages one thread writes 7-7.7 GiB/s instead of 5.5, but the allocation runs on the same inode and slowed the
+ * writer to 20 ms per block while it lasted, and an estimate's surplus has to be cut off at the end: -m c on an 8 GiB file
+ * 2.0 s with it, 1.5 s without.) */
 /* returns the job's ticket (>= 1) */
 static uint64_t writer_push(writer_t *w, const char *hdr, const uint8_t *data, size_t n)
 {
@@ -233,10 +212,6 @@ static int writer_stop(writer_t *w)
         pthread_cond_broadcast(&w->cv);
         pthread_mutex_unlock(&w->mu);
         pthread_join(w->th, NULL);
-    }
-    if (w->pre_on) {
-        pthread_join(w->pre_th, NULL);
-        if (ftruncate(w->fd, w->off) != 0 && !w->err) w->err = SHAFA_FILE_STREAM_FAILED;   /* the estimate's surplus */
     }
     pthread_mutex_destroy(&w->mu);
     pthread_cond_destroy(&w->cv);
@@ -429,7 +404,6 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
                 f_rle_freq = fopen(p_rle_freq, "wb");
                 if (f_rle < 0 || !f_rle_freq) { err = SHAFA_FILE_INACCESSIBLE; break; }
                 writer_target(&wr, f_rle, 0);
-                writer_expect(&wr, size_f);
                 if (fprintf(f_rle_freq, "@R@%lu", (unsigned long)n_blocks) < 4) { err = SHAFA_FILE_STREAM_FAILED; break; }
             }
             if (!use_rle || force_freq) {
@@ -567,7 +541,6 @@ _modules_error shafa_compress(char **path)
     writer_t wr;
     writer_start(&wr);
     writer_target(&wr, out, out_off);
-    if (!err && left.bounded) writer_expect(&wr, left.size);                     /* a .shaf is about as large as its input */
     while (!err && ret < n_blocks) {
         if (sub < n_blocks && sub - ret < depth) {
             uint64_t size = 0;
@@ -683,7 +656,6 @@ _modules_error rle_decompress(char **path)
     writer_t wr;
     writer_start(&wr);
     writer_target(&wr, out, out_off);
-    if (!err && left.bounded) writer_expect(&wr, left.size);                     /* at least the RLE bytes */
     while (!err && ret < n_blocks) {
         if (sub < n_blocks && sub - ret < depth) {
             const int slot = (int)(sub % depth);
@@ -776,7 +748,6 @@ _modules_error shafa_decompress(char **path, bool decompress_rle)
     writer_t wr;
     writer_start(&wr);
     writer_target(&wr, out, out_off);
-    if (!err && left.bounded) writer_expect(&wr, left.size + left.size / 4);     /* decoded bytes: an estimate, cut at the end */
     while (!err && ret < n_blocks) {
         if (sub < n_blocks && sub - ret < depth) {
             uint64_t sf_n = 0, n_sym = 0;
