@@ -81,6 +81,9 @@ def parse_args(argv=None):
                     help="blocks of the pipeline leg (`pipeline` object: per-family times and roofline fractions of K1, K2, K5 "
                          "on run-heavy data at this block size; bounded, a fraction of a second of GPU time)")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the pipeline leg")
+    ap.add_argument("--no-host-path", action="store_true",
+                    help="skip the `host_path` object (layer-3 pipe PCIe-inclusive rates and the CLI end to end on a tmpfs file)")
+    ap.add_argument("--host-path-blocks", type=int, default=32)
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="shafa_hip_set_option(NAME, VALUE) before anything runs (A/B of kernel variants)")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -235,6 +238,59 @@ class Comm:
     def close(self):
         if self.dist.is_initialized():
             self.dist.destroy_process_group()
+
+
+def host_path_leg(args, pkg, torch, dev, d_in):
+    """What sits between a file and the kernels, on the GPU box's host (never part of `value`): (1) layer 3, pinned host ->
+    pinned host through H2D, kernels and D2H (bin/pipe_rate); (2) the CLI end to end on a file in tmpfs, bit-exact round
+    trip included (bin/shafa; the reference's own drivers do the same four steps, shafa.c:157-250).  Child processes."""
+    import re
+    import shutil
+    out = {}
+    bs = args.block_mib << 20
+    nb = max(1, min(args.host_path_blocks, args.blocks))
+    exe_dir = os.path.join(PKG_DIR, "bin")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = PKG_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([os.path.join(exe_dir, "pipe_rate"), str(nb), str(args.block_mib), "3"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    m = {k: float(v) for k, v in re.findall(r"(sf_encode|sf_decode)\s.*?([0-9.]+) GiB/s", r.stdout)}
+    out["pipe_3_slots"] = {"blocks": nb, "sf_encode_GiBs": m.get("sf_encode"), "sf_decode_GiBs": m.get("sf_decode"),
+                           "what": "layer 3, pinned host -> pinned host: H2D + kernels + D2H, 3 blocks in flight",
+                           "round_trip_identical": "round trip identical" in r.stdout}
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    tmp = tempfile.mkdtemp(prefix="shafa_bench_", dir=shm)
+    try:
+        p = os.path.join(tmp, "z")
+        with open(p, "wb") as f:
+            for b in range(nb):
+                f.write(d_in[b * bs:(b + 1) * bs].cpu().numpy().tobytes())
+        h0 = hashlib.sha256(open(p, "rb").read()).hexdigest()
+        flag = {64: "M", 8: "m"}.get(args.block_mib)
+        cli = os.path.join(exe_dir, "shafa")
+        times = {}
+        for name, argv in (("f", [p, "-m", "f", "-b", flag]), ("t", [p + ".freq", "-m", "t"]), ("c", [p, "-m", "c"])):
+            t0 = time.perf_counter()
+            rr = subprocess.run([cli] + argv, capture_output=True, text=True, env=env, timeout=600)
+            times[name] = time.perf_counter() - t0
+            if rr.returncode != 0:
+                raise RuntimeError(f"shafa -m {name}: rc {rr.returncode} {rr.stderr[-200:]}")
+        os.remove(p)
+        t0 = time.perf_counter()
+        rr = subprocess.run([cli, p + ".shaf", "-m", "d"], capture_output=True, text=True, env=env, timeout=600)
+        times["d"] = time.perf_counter() - t0
+        ok = rr.returncode == 0 and hashlib.sha256(open(p, "rb").read()).hexdigest() == h0
+        gib = nb * bs / GIB
+        out["cli_tmpfs"] = {"file_GiB": gib, "seconds": times, "GiBs": {k: gib / v for k, v in times.items() if k != "t"},
+                            "round_trip_identical": ok,
+                            "what": "bin/shafa -m f / t / c / d on a file in tmpfs, wall clock of each process (start-up, HIP "
+                                    "initialisation, first use of the pinned buffers and teardown included: 0.4-0.5 s of each); the rest is bound by the host's tmpfs writes, DESIGN 1.1"}
+        assert ok, "CLI round trip differs"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 def pipeline_key(args, nb):
@@ -539,6 +595,17 @@ def main():
         except Exception as e:                         # (memory on a small device: the headline line must still come out)
             pipe = {"error": f"{type(e).__name__}: {e}"[:300]}
 
+    host_path = None
+    profiled = any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if (world == 1 and rank == 0 and not args.no_host_path and not profiled      # no child processes under a profiler
+            and args.dist != "uniform" and args.block_mib in (8, 64)):
+        try:
+            host_path = host_path_leg(args, pkg, torch, dev, d_in)
+        except AssertionError:
+            raise
+        except Exception as e:
+            host_path = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     dist_name = {"zipfmod": f"Zipf({args.zipf_s:g}) mod 256", "zipf": f"Zipf({args.zipf_s:g}) truncated to 256 ranks",
                  "uniform": "uniform"}[args.dist]
     if rank == 0:
@@ -571,6 +638,8 @@ def main():
             out["scatter_gather"] = sg
         if pipe:
             out["pipeline"] = pipe
+        if host_path:
+            out["host_path"] = host_path
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, pkg, zt)
         print(json.dumps(out), flush=True)

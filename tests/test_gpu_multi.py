@@ -149,3 +149,7 @@ def test_bench_single_gpu_line_has_the_contract_fields():
     for fam in ("K1_hist256", "K2_rle_encode_hist", "K3_sf_encode", "K4_sf_decode", "K5_rle_decode"):
         assert p[fam]["frac"] > 0
     assert 0.79 < j["config"]["compressed_ratio"] < 0.83      # the surveyed cfg-4 stream: SF output 0.812 n
+    hp = j["host_path"]                                        # layer 3 and the CLI on the box's host, never part of `value`
+    assert "error" not in hp and hp["pipe_3_slots"]["round_trip_identical"] and hp["cli_tmpfs"]["round_trip_identical"]
+    assert hp["pipe_3_slots"]["sf_encode_GiBs"] > 1 and hp["cli_tmpfs"]["GiBs"]["c"] > 0.1
+    assert len(j["per_rank"]["encode_ms"]) == 1

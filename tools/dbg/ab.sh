@@ -9,7 +9,7 @@ cp shafa-cd_amd/libshafa_hip.so /tmp/orig.so
 for i in 1 2 3; do
   for v in A B; do
     if [ $v = A ]; then cp "$A" shafa-cd_amd/libshafa_hip.so; else cp "$B" shafa-cd_amd/libshafa_hip.so; fi
-    echo "$v $(timeout 200 python bench.py --no-cpu "$@" 2>/dev/null | tail -1 | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print("enc %.3f dec %s" % (d["encode_ms"], d["decode_ms"]))')"
+    echo "$v $(timeout 200 python bench.py --no-cpu --no-host-path "$@" 2>/dev/null | tail -1 | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print("enc %.3f dec %s" % (d["encode_ms"], d["decode_ms"]))')"
   done
 done
 cp /tmp/orig.so shafa-cd_amd/libshafa_hip.so

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 out=$R/gpurun_out/kstats_quick
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o r -- python3 "$R/bench.py" --no-cpu "$@" > "$out/bench.json" 2> "$out/err.log"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o r -- python3 "$R/bench.py" --no-cpu --no-host-path "$@" > "$out/bench.json" 2> "$out/err.log"
 python3 - "$out" <<'PY'
 import csv, sys, glob
 f = glob.glob(sys.argv[1] + '/**/r_kernel_stats.csv', recursive=True)

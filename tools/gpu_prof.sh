@@ -12,7 +12,7 @@ make -C oracle --no-print-directory > /dev/null 2>&1
 export SHAFA_BENCH_ORACLE_CHECK=0
 export TMPDIR=/tmp
 tag=$1; shift
-ARGS="--no-cpu $*"
+ARGS="--no-cpu --no-host-path $*"
 out=$R/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp
