@@ -71,7 +71,9 @@ int shafa_hip_device_count(void);            /* 0 when no GPU is visible; never 
 int shafa_hip_init(int device);              /* select device, create the library's stream/workspace */
 /* Select the devices of the block pipeline (layer 3): slot i of every pipe created afterwards lives on
  * devices[i % n_devices] (its stream, buffers and kernels), so the blocks of one file are spread over the GPUs of the
- * node while the caller still retires them in order (multithread.c:70-87).  Layers 1 and 2 use devices[0].
+ * node while the caller still retires them in order (multithread.c:70-87) — of a pipe with n_slots slots only the first
+ * ceil(n_slots / 3) selected devices are used (three blocks in flight keep a GPU busy; a short file does not open a
+ * context on every GPU).  Layers 1 and 2 use devices[0].
  * n_devices == 0 selects every visible device.  Returns SHAFA_OUTSIDE_MODULE for an invalid device number. */
 int shafa_hip_init_devices(const int *devices, int n_devices);
 int shafa_hip_devices(void);                 /* number of devices selected for layer 3 (1 until shafa_hip_init_devices) */
@@ -80,8 +82,8 @@ const char *shafa_hip_last_error(void);      /* text of the last SHAFA_DEVICE_ER
 
 /* Tuning knobs (no reference counterpart).  Unknown names return SHAFA_OUTSIDE_MODULE.
  *   "sf_encode_one_pass_min_blocks": a shafa_hipd_sf_encode launch with at least this many blocks of <= 16-bit
- *       codes takes the one-pass encoder, smaller launches the count/scan/pack kernels; 0 (default) = the measured crossovers: 6 blocks when every code
- *       has <= 12 bits, 80 for codes of 13-16 bits.
+ *       codes takes the one-pass encoder, smaller launches the count/scan/pack kernels; 0 (default) = the measured crossovers: 6 blocks
+ *       where the 1024-lane form runs (every code <= 16 bits since round 3), 80 for the 256-lane form.
  *   "sf_decode_speculate": 1 (default) lets blocks whose code re-synchronises take the speculative entry kernels of
  *       the Shannon-Fano decoder (verified exactly; falls back to the exact kernels per block), 0 = exact kernels only,
  *       2 = speculate for every block the kernels apply to, whatever its code (for tests of the fall-back).
@@ -93,6 +95,10 @@ const char *shafa_hip_last_error(void);      /* text of the last SHAFA_DEVICE_ER
  *   "sf_decode_path": 0 (default) = the fastest kernels the tables allow, 1 = one code per look-up as for incomplete
  *       codes, 2 = the generic byte-map kernels of codes longer than 32 bits.
  *   "rle_encode_general": 1 = every tile takes the per-element general RLE code (long runs, ragged tiles), 0 = by data.
+ *   "sf_encode_window_bits": bits per symbol the 1024-lane encoder's LDS windows are sized for; 0 (default) = the launch's
+ *       longest code, at most 12.  A tile that needs more is not placed: its block is flagged on the device and encoded
+ *       again by the 256-lane form in the same call (what happens to 13..16-bit codes whose rare symbols fill a whole
+ *       32 KiB tile); small values make ordinary data take that path.
  * shafa_hip_init() reads the environment variables SHAFA_SF_ENCODE_ONE_PASS_MIN_BLOCKS and SHAFA_SF_DECODE_SPECULATE
  * once for the first two knobs. */
 int shafa_hip_set_option(const char *name, long value);

@@ -138,6 +138,12 @@ int shafa_hip_set_option(const char *name, long value)
         g_sfe_variant = (int)value;
         return SHAFA_SUCCESS;
     }
+    if (name && !strcmp(name, "sf_encode_window_bits")) {
+        extern int g_sfe_window_bits;
+        if (value < 0 || value > 16) return SHAFA_OUTSIDE_MODULE;
+        g_sfe_window_bits = (int)value;
+        return SHAFA_SUCCESS;
+    }
     if (name && !strcmp(name, "sf_encode_lanes")) {
         extern int g_sfe_lanes;
         if (value != 0 && value != 256 && value != 512) return SHAFA_OUTSIDE_MODULE;
@@ -480,8 +486,14 @@ int shafa_hip_rle_decode(const uint8_t *in, size_t in_n, uint8_t *out, size_t ou
 }  // extern "C"
 
 int api_lazy_init() { return lazy_init(); }     // layer 3 (pipe.hip)
-int api_pipe_device(int slot)
+// device of slot `slot` of a pipe with n_slots slots: the selected devices in turn, but no more devices than the pipe can
+// keep busy with three blocks in flight each (a two-block file on an eight-GPU node opens one context, not eight)
+int api_pipe_device(int slot, int n_slots)
 {
     std::lock_guard<std::recursive_mutex> l1_lock(g_l1_mu);
-    return g_ndevs ? g_devs[slot % g_ndevs] : g.device;
+    if (!g_ndevs) return g.device;
+    int used = (n_slots + 2) / 3;
+    if (used < 1) used = 1;
+    if (used > g_ndevs) used = g_ndevs;
+    return g_devs[slot % used];
 }

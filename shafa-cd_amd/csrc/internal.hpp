@@ -77,6 +77,13 @@ struct EncBlk {
     u32 pad;
 };
 
+// second chain (descriptors, tickets) and per-block flags of the one-pass encoder's encode-again fall-back (sf_encode4.hip)
+struct SfeRedo {
+    u64 *desc2;
+    u32 *tickets2;
+    u32 *redo;
+};
+
 // ---- launchers (one per reference function) ------------------------------------------------------
 int hist_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                 const u64 *h_in_n, u64 *d_freq);

@@ -14,7 +14,7 @@
 
 int shafa_set_hip_error(hipError_t e, const char *what);
 int api_lazy_init();      // api.hip: shafa_hip_init(0) unless a device was selected already
-int api_pipe_device(int slot);     // api.hip: device of pipe slot `slot` (shafa_hip_init_devices), else the layer-1 device
+int api_pipe_device(int slot, int n_slots);   // api.hip: device of slot `slot` of a pipe of n_slots (shafa_hip_init_devices), else the layer-1 device
 
 namespace {
 
@@ -148,7 +148,7 @@ int shafa_pipe_create(int n_slots, shafa_pipe **out)
     for (int i = 0; i < n_slots; ++i) {
         Slot &s = p->slots[i];
         shafa_hipd_batch *bh = nullptr;
-        s.device = api_pipe_device(i);
+        s.device = api_pipe_device(i, n_slots);
         DeviceGuard dg(s.device);
         hipError_t e = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc((void **)&s.d_small, 514 * sizeof(u64));

@@ -206,7 +206,9 @@ __global__ __launch_bounds__(ENC_THREADS) void sf_encode_generic(const EncBlk *_
 // host launcher
 // ------------------------------------------------------------------------------------------------
 void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 *d_tile_bits, u64 *d_tile_off, bool lut64);
-int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, u32 ragged);
+int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, u32 ragged, const SfeRedo &x);
+bool sfenc4_needs_redo(u32 lmax);
+extern int g_sfe4_wide, g_sfe_lanes;
 
 // A launch with at least this many class-1 blocks takes the one-pass encoder: every block is its own chain, and with this
 // many chains (<= ~10 workgroups per block) a tile's look-back stays inside one 64-entry descriptor window.  Measured
@@ -244,7 +246,11 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         cls_count[c]++;
         if (c == 1 && (u32)lmax > lmax1) lmax1 = (u32)lmax;
     }
-    const bool one_pass = cls_count[1] >= (g_sfe4_min_blocks > 0 ? g_sfe4_min_blocks : (lmax1 <= 12 ? 6 : 80));
+    // the one-pass encoder pays from 6 blocks per launch in its 1024-lane form (every Lmax <= 16 since the windows of
+    // 13..16-bit codes are sized for 12 bits per symbol with an encode-again fall-back), from 80 in the 256-lane form
+    const bool wide_form = g_sfe4_wide && g_sfe_lanes == 0 && (lmax1 <= 12 || sfenc4_needs_redo(lmax1));
+    const bool one_pass = cls_count[1] >= (g_sfe4_min_blocks > 0 ? g_sfe4_min_blocks : (wide_form ? 6 : 80));
+    const bool redo = one_pass && cls_count[1] && sfenc4_needs_redo(lmax1);
     const u64 tile_syms[4] = {1, 256 * 16 * 2, 256 * 16 * 2, GEN_TILE};
     u64 total_tiles[4] = {0, 0, 0, 0};
     u32 max_tiles[4] = {0, 0, 0, 0};
@@ -263,6 +269,9 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     size_t off = 0;
     const size_t o_desc = off; off += ndesc * 8;
     const size_t o_tick = off; off += (size_t)nblocks * 4; off = (off + 15) & ~(size_t)15;
+    const size_t o_desc2 = off; off += redo ? ndesc * 8 : 0;                 // the encode-again pass's chain and the flags
+    const size_t o_tick2 = off; off += redo ? (size_t)nblocks * 4 : 0; off = (off + 15) & ~(size_t)15;
+    const size_t o_redo = off; off += redo ? (size_t)nblocks * 4 : 0; off = (off + 15) & ~(size_t)15;
     const size_t o_zero_end = off;
     const size_t o_tbits = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;
     const size_t o_blk = off; off += (size_t)nblocks * sizeof(EncBlk); off = (off + 15) & ~(size_t)15;
@@ -338,7 +347,9 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
             u32 ragged = 0;                            // bit 0 / 1 / 2: a block has a remainder after its full 8 / 16 / 32 KiB tiles
             for (int b = 0; b < nblocks; ++b)
                 if (cls[b] == 1) ragged |= ((h_in_n[b] & 8191) ? 1u : 0u) | ((h_in_n[b] & 16383) ? 2u : 0u) | ((h_in_n[b] & 32767) ? 4u : 0u);
-            if ((rc = sfenc4_launch(st, dblk + cls_first[1], cls_count[1], ddesc, dtick, lmax1, ragged))) return rc;
+            const SfeRedo x = {redo ? (u64 *)(ws + o_desc2) : nullptr, redo ? (u32 *)(ws + o_tick2) : nullptr,
+                               redo ? (u32 *)(ws + o_redo) : nullptr};
+            if ((rc = sfenc4_launch(st, dblk + cls_first[1], cls_count[1], ddesc, dtick, lmax1, ragged, x))) return rc;
         } else sfenc3_launch(st, dblk + cls_first[1], cls_count[1], max_tiles[1], (u32 *)(ws + o_tbits), ddesc, false);
     }
     if (cls_count[2]) sfenc3_launch(st, dblk + cls_first[2], cls_count[2], max_tiles[2], (u32 *)(ws + o_tbits), ddesc, true);

@@ -34,6 +34,7 @@
 #include <mutex>
 
 int g_sfe4_wide = 1;                                   // 0: always the 256-lane form (A/B and tests)
+int g_sfe_window_bits = 0;                             // test knob: bits per symbol of the wide form's windows (0: min(Lmax, 12))
 int g_sfe_lanes = 0;                                   // 0: widest form that fits; 256 / 512: that workgroup width (A/B and tests)
 int g_sfe_variant = 5;                                 // 5: plain-store windows (sfe5_kernel); 4: atomic-OR windows (sfe4_kernel)
 
@@ -621,9 +622,15 @@ __device__ __forceinline__ u32 emit_oct(u32 *win, u32 *dump, const Oct &o, u32 e
     return j >= 1u ? x0 : v;
 }
 
+// cap_bits: what a window holds.  Launches whose longest code lets a tile outgrow the CU's LDS (13..16-bit codes in the
+// 1024-lane form) run with windows sized for 12 bits per symbol: a tile that does not fit (the block's rare symbols — every
+// one of them at most 2^-13 of the block — would have to fill a whole 32 KiB tile) is not placed, its block is flagged in
+// redo[] and encoded again by the 256-lane form (worst-case windows) in a follow-up launch that looks at flagged blocks
+// only (redo_only).  redo == nullptr: the windows hold the worst case.
 template <int NW, bool L16, int NT>
 __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restrict__ blks, int nblk, int nconc,
-                                                             u64 *__restrict__ desc, u32 *__restrict__ tickets, u32 win_stride)
+                                                             u64 *__restrict__ desc, u32 *__restrict__ tickets, u32 win_stride,
+                                                             u32 cap_bits, u32 *__restrict__ redo, int redo_only)
 {
     __shared__ E4Static sh;
     extern __shared__ __attribute__((aligned(16))) u32 dynwin[];     // three buffers of [E4_GUARD][window dwords]
@@ -633,6 +640,7 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restri
     constexpr u32 TILE = 32u * NT, TSHIFT = NT == 256 ? 13 : NT == 512 ? 14 : 15;        // symbols per tile
 
     for (int b = (int)(blockIdx.x % (u32)nconc); b < nblk; b += nconc) {
+        if (redo_only && gload<u32>(redo + b) == 0u) continue;        // follow-up launch: flagged blocks only (uniform)
         const EncBlk *bp = blks + b;
         const u8 *in = bp->in;
         const u32 nfull = (u32)(bp->n >> TSHIFT);      // full tiles of this kernel's size
@@ -729,6 +737,8 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restri
                         if (!ragged && nfull == 1) gstore<u64>(bp->out_n, ((u64)c_T + 7) >> 3);
                     } else desc_store(bdesc + cur, DESC_AGG, c_T);
                 }
+                const bool fits = c_T <= cap_bits;     // (uniform) else: the tile is not placed and its block is encoded again
+                if (!fits && tid == 0 && redo) gstore<u32>(redo + b, 1u);
                 const u32 E = woff + incl;             // the lane's string is window bits [E - tot, E)
                 u32 e = E - tot;
                 // partial dword in front of the lane: the previous lane's last E mod 32 bits (wave_shr:1; lane 0: nothing
@@ -740,12 +750,14 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restri
 #ifdef E5_ABL_NOEMIT
                 if (bp->n == 12345)
 #endif
+                if (fits) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    e += c_oct[k].ll;
-                    c = emit_oct<NW>(win, sh.dump + lane, c_oct[k], e, c);
+                    for (int k = 0; k < 4; ++k) {
+                        e += c_oct[k].ll;
+                        c = emit_oct<NW>(win, sh.dump + lane, c_oct[k], e, c);
+                    }
                 }
-                if (tid == NT - 1) {                   // the tile's final partial dword and the zero behind it; the lead word
+                if (fits && tid == NT - 1) {           // the tile's final partial dword and the zero behind it; the lead word
                     win[e >> 5] = c;                   //   (lead_bits ORs into it two iterations from now)
                     win[(e >> 5) + 1] = 0u;
                     win[-1] = 0u;
@@ -773,8 +785,9 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restri
 // launched after sfe4_kernel, so the prefix of the last full tile is final.
 template <int NW, bool L16, int NT>
 __global__ __launch_bounds__(NT) void sfe4_tail_kernel(const EncBlk *__restrict__ blks, const u64 *__restrict__ desc,
-                                                               u32 win_stride)
+                                                               u32 win_stride, const u32 *__restrict__ redo_only)
 {
+    if (redo_only && gload<u32>(redo_only + blockIdx.x) == 0u) return;      // follow-up launch: flagged blocks only
     __shared__ E4Static sh;
     extern __shared__ __attribute__((aligned(16))) u32 dynwin[];
     u32 *win = dynwin + E4_GUARD;
@@ -826,24 +839,28 @@ __global__ __launch_bounds__(NT) void sfe4_tail_kernel(const EncBlk *__restrict_
     if (tid == 0) gstore<u64>(blk.out_n, (B + T + 7) >> 3);
 }
 
+// lmax_win: bits per symbol the three windows are sized for (the launch's longest code, or less: see sfe5_kernel's
+// cap_bits); lmax: the launch's longest code (the tail kernel's one window always holds the worst case)
 template <int NW, bool L16, int NT>
-int e4_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, bool any_ragged)
+int e4_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax_win, u32 lmax, bool any_ragged,
+                 u32 *d_redo, int redo_only)
 {
     // per device: the LDS attribute below belongs to the device's copy of the kernel, and devices may differ in CUs.
     // (Statics of a template: one set per instantiation.  Guarded: pipes on several host threads launch concurrently.)
     constexpr int MAXDEV = 64;
-    static int wgs_by_dev_lmax[MAXDEV][17], cus_by_dev[MAXDEV];
+    static int wgs_by_dev_lmax[MAXDEV][17], cus_by_dev[MAXDEV], tail_attr_by_dev[MAXDEV];
     static std::mutex mu;
-    const u32 win_stride = ((u32)E4_GUARD + (u32)(((size_t)(32 * NT) * lmax) >> 5) + 8u + 3u) & ~3u;   // dwords per buffer
+    const u32 win_stride = ((u32)E4_GUARD + (u32)(((size_t)(32 * NT) * lmax_win) >> 5) + 8u + 3u) & ~3u;   // dwords per buffer
+    const u32 tail_stride = ((u32)E4_GUARD + (u32)(((size_t)(32 * NT) * lmax) >> 5) + 8u + 3u) & ~3u;
     const size_t dyn = (size_t)win_stride * 3 * 4;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= MAXDEV) return SHAFA_OUTSIDE_MODULE;
+    if (dev < 0 || dev >= MAXDEV || lmax_win > 16 || lmax > 16) return SHAFA_OUTSIDE_MODULE;
     int wgs_per_cu_v = 0, cus = 0;
     {
         std::lock_guard<std::mutex> lk(mu);
         int *wgs_by_lmax = wgs_by_dev_lmax[dev];
-        if (!wgs_by_lmax[lmax]) {
+        if (!wgs_by_lmax[lmax_win]) {
             int occ = 0;
             hipDeviceProp_t prop;
             HIP_TRY(hipGetDeviceProperties(&prop, dev));
@@ -853,9 +870,14 @@ int e4_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32
                 HIP_TRY(hipFuncSetAttribute((const void *)sfe5_kernel<NW, L16, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
             }
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)sfe4_kernel<NW, L16, NT>, NT, dyn));
-            wgs_by_lmax[lmax] = occ < 1 ? 1 : (occ > 6 ? 6 : occ);   // residency is a matter of speed only (tickets), 6 = what the registers allow
+            wgs_by_lmax[lmax_win] = occ < 1 ? 1 : (occ > 6 ? 6 : occ);   // residency is a matter of speed only (tickets), 6 = what the registers allow
         }
-        wgs_per_cu_v = wgs_by_lmax[lmax];
+        if (any_ragged && (size_t)tail_stride * 4 > 65536 && tail_attr_by_dev[dev] < (int)tail_stride) {
+            HIP_TRY(hipFuncSetAttribute((const void *)sfe4_tail_kernel<NW, L16, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)((size_t)tail_stride * 4)));
+            tail_attr_by_dev[dev] = (int)tail_stride;
+        }
+        wgs_per_cu_v = wgs_by_lmax[lmax_win];
         cus = cus_by_dev[dev];
     }
     const int wgs_per_cu = wgs_per_cu_v;
@@ -864,29 +886,46 @@ int e4_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32
     int nconc = count < target ? count : target;
     int per = target / nconc;
     if (per < 1) per = 1;
-    if (g_sfe_variant == 5)
+    const u32 cap_bits = (u32)(32u * NT) * lmax_win;
+    if (g_sfe_variant == 5 || d_redo)
         hipLaunchKernelGGL((sfe5_kernel<NW, L16, NT>), dim3((u32)(nconc * per)), dim3(NT), dyn, st, dblk, count, nconc, d_desc, d_tickets,
-                           win_stride);
+                           win_stride, cap_bits, d_redo, redo_only);
     else
         hipLaunchKernelGGL((sfe4_kernel<NW, L16, NT>), dim3((u32)(nconc * per)), dim3(NT), dyn, st, dblk, count, nconc, d_desc, d_tickets,
                            win_stride);
     if (any_ragged)
-        hipLaunchKernelGGL((sfe4_tail_kernel<NW, L16, NT>), dim3((u32)count), dim3(NT), (size_t)win_stride * 4, st, dblk,
-                           (const u64 *)d_desc, win_stride);
+        hipLaunchKernelGGL((sfe4_tail_kernel<NW, L16, NT>), dim3((u32)count), dim3(NT), (size_t)tail_stride * 4, st, dblk,
+                           (const u64 *)d_desc, tail_stride, (const u32 *)(redo_only ? d_redo : nullptr));
     return SHAFA_SUCCESS;
 }
 
-// the wide form — ONE workgroup of 1024 lanes per CU, 32 KiB tiles — when its three windows (and the 2 KiB of static
-// LDS) fit the CU's 160 KiB: Lmax <= 12
+constexpr u32 E5_CAP_LMAX = 12;                        // the 1024-lane form's windows hold at most this many bits per symbol
+
+__host__ u32 e5_window_bits(u32 lmax)                  // bits per symbol the wide form's windows are sized for
+{
+    u32 w = lmax < E5_CAP_LMAX ? lmax : E5_CAP_LMAX;
+    if (g_sfe_window_bits > 0 && (u32)g_sfe_window_bits < w) w = (u32)g_sfe_window_bits;    // test knob: provoke the re-encode path
+    return w;
+}
+
+// the wide form — ONE workgroup of 1024 lanes per CU, 32 KiB tiles — with three windows that fit the CU's 160 KiB next to
+// the 2.5 KiB of static LDS: sized for the launch's longest code up to 12 bits, for 12 bits per symbol beyond (13..16-bit
+// codes: with the flag-and-encode-again fall-back of sfe5_kernel, which needs the second chain `x`)
 template <int NW, bool L16>
-int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, u32 ragged)
+int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, u32 ragged, const SfeRedo &x)
 {
     const bool ragged8 = ragged & 1u, ragged16 = ragged & 2u, ragged32 = ragged & 4u;
-    if (g_sfe_lanes == 512 && g_sfe_variant == 5) return e4_launch_nt<NW, L16, 512>(st, dblk, count, d_desc, d_tickets, lmax, ragged16);
-    if (g_sfe_lanes == 256) return e4_launch_nt<NW, L16, 256>(st, dblk, count, d_desc, d_tickets, lmax, ragged8);
-    const size_t wide = (size_t)((((u32)E4_GUARD + (u32)(((size_t)32768 * lmax) >> 5) + 8u + 3u) & ~3u)) * 3 * 4 + sizeof(E4Static) + 64;
-    if (g_sfe4_wide && wide <= 160 * 1024) return e4_launch_nt<NW, L16, 1024>(st, dblk, count, d_desc, d_tickets, lmax, ragged32);
-    return e4_launch_nt<NW, L16, 256>(st, dblk, count, d_desc, d_tickets, lmax, ragged8);
+    if (g_sfe_lanes == 512 && g_sfe_variant == 5)
+        return e4_launch_nt<NW, L16, 512>(st, dblk, count, d_desc, d_tickets, lmax, lmax, ragged16, nullptr, 0);
+    if (g_sfe_lanes == 256 || !g_sfe4_wide)
+        return e4_launch_nt<NW, L16, 256>(st, dblk, count, d_desc, d_tickets, lmax, lmax, ragged8, nullptr, 0);
+    const u32 wbits = e5_window_bits(lmax);
+    if (wbits == lmax) return e4_launch_nt<NW, L16, 1024>(st, dblk, count, d_desc, d_tickets, lmax, lmax, ragged32, nullptr, 0);
+    if (g_sfe_variant != 5 || !x.redo)                 // the atomic-OR form has no fall-back: its 256-lane form holds the worst case
+        return e4_launch_nt<NW, L16, 256>(st, dblk, count, d_desc, d_tickets, lmax, lmax, ragged8, nullptr, 0);
+    int rc = e4_launch_nt<NW, L16, 1024>(st, dblk, count, d_desc, d_tickets, wbits, lmax, ragged32, x.redo, 0);
+    if (rc) return rc;
+    return e4_launch_nt<NW, L16, 256>(st, dblk, count, x.desc2, x.tickets2, lmax, lmax, ragged8, x.redo, 1);
 }
 
 }  // namespace
@@ -901,10 +940,16 @@ extern "C" int shafa_e4_read_stamps(unsigned long long *dst, int n)
 // launched from sfenc_launch (sf_encode.hip) for blocks whose codes are <= 16 bits when the launch holds enough blocks
 // to keep every chain short; desc (one u64 per tile) and tickets (one u32 per block) are zeroed by the caller;
 // tables are 256 x u64 {code, len}
-int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, u32 ragged)
+// does a launch with this longest code run the wide form with windows smaller than its worst case (then it needs `x`)?
+bool sfenc4_needs_redo(u32 lmax)
 {
-    if (lmax <= 8) return e4_launch_t<3, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged);
-    if (lmax <= 12) return e4_launch_t<4, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged);
-    if (lmax <= 15) return e4_launch_t<5, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged);
-    return e4_launch_t<5, true>(st, dblk, count, d_desc, d_tickets, lmax, ragged);
+    return g_sfe_variant == 5 && g_sfe4_wide && g_sfe_lanes == 0 && e5_window_bits(lmax) < lmax;
+}
+
+int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, u32 ragged, const SfeRedo &x)
+{
+    if (lmax <= 8) return e4_launch_t<3, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged, x);
+    if (lmax <= 12) return e4_launch_t<4, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged, x);
+    if (lmax <= 15) return e4_launch_t<5, false>(st, dblk, count, d_desc, d_tickets, lmax, ragged, x);
+    return e4_launch_t<5, true>(st, dblk, count, d_desc, d_tickets, lmax, ragged, x);
 }

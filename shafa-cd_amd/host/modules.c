@@ -45,11 +45,14 @@ static void trace(const char *what, double t0)
 enum { PIPE_SLOTS_PER_DEVICE = 3, PIPE_SLOTS = 64 };        /* PIPE_SLOTS: upper bound (ticket arrays) */
 /* three blocks in flight per selected GPU (shafa_hip_init_devices): slot i works on device i mod n, results are retired
  * in submission order by the one writer thread as before */
-static int pipe_depth(void)
+static int pipe_depth(uint64_t n_blocks)
 {
     if (NO_MULTITHREAD) return 1;
-    const int d = PIPE_SLOTS_PER_DEVICE * shafa_hip_devices();
-    return d > PIPE_SLOTS ? PIPE_SLOTS : d;
+    int d = PIPE_SLOTS_PER_DEVICE * shafa_hip_devices();
+    if (d > PIPE_SLOTS) d = PIPE_SLOTS;
+    if (n_blocks < (uint64_t)d) d = n_blocks ? (int)n_blocks : 1;      /* a short file does not open every GPU (layer 3 uses
+                                                                          ceil(slots / 3) of the selected devices) */
+    return d;
 }
 
 /* ------------------------------------------------------------------ block I/O
@@ -369,7 +372,7 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
     shafa_pipe *pipe = NULL;
     shafa_pipe_result *res = malloc(sizeof(*res));
     if (!p_rle || !p_rle_freq || !p_freq || !sizes || !rle_sizes || !res) err = SHAFA_LACK_OF_MEMORY;
-    if (!err) err = shafa_pipe_create(pipe_depth(), &pipe);
+    if (!err) err = shafa_pipe_create(pipe_depth(n_blocks), &pipe);
     const uint64_t depth = pipe ? (uint64_t)shafa_pipe_slots(pipe) : 1;
 
     /* submit block `sub`, retire block `ret`; block 0 is retired alone because it decides use_rle (f.c:250-258) */
@@ -534,7 +537,7 @@ _modules_error shafa_compress(char **path)
     shafa_pipe_result *res = malloc(sizeof(*res));
     if (!err && !res) err = SHAFA_LACK_OF_MEMORY;
     trace("C: files open", t0);
-    if (!err) err = shafa_pipe_create(pipe_depth(), &pipe);
+    if (!err) err = shafa_pipe_create(pipe_depth(n_blocks), &pipe);
     trace("C: pipe created", t0);
     const uint64_t depth = pipe ? (uint64_t)shafa_pipe_slots(pipe) : 1;
     uint64_t sub = 0, ret = 0, ticket[PIPE_SLOTS] = {0};
@@ -650,7 +653,7 @@ _modules_error rle_decompress(char **path)
     shafa_pipe *pipe = NULL;
     shafa_pipe_result *res = malloc(sizeof(*res));
     if (!err && !res) err = SHAFA_LACK_OF_MEMORY;
-    if (!err) err = shafa_pipe_create(pipe_depth(), &pipe);
+    if (!err) err = shafa_pipe_create(pipe_depth(n_blocks), &pipe);
     const uint64_t depth = pipe ? (uint64_t)shafa_pipe_slots(pipe) : 1;
     uint64_t sub = 0, ret = 0, ticket[PIPE_SLOTS] = {0};
     writer_t wr;
@@ -742,7 +745,7 @@ _modules_error shafa_decompress(char **path, bool decompress_rle)
     shafa_pipe *pipe = NULL;
     shafa_pipe_result *res = malloc(sizeof(*res));
     if (!err && !res) err = SHAFA_LACK_OF_MEMORY;
-    if (!err) err = shafa_pipe_create(pipe_depth(), &pipe);
+    if (!err) err = shafa_pipe_create(pipe_depth(n_blocks), &pipe);
     const uint64_t depth = pipe ? (uint64_t)shafa_pipe_slots(pipe) : 1;
     uint64_t sub = 0, ret = 0, ticket[PIPE_SLOTS] = {0};
     writer_t wr;

@@ -360,7 +360,7 @@ def test_sf_decode_codes_of_17_to_32_bits_fast_path(oracle, shafa):
         assert rc == shafa.FILE_UNRECOGNIZABLE
 
 
-DEFAULT_OPTIONS = {"sf_encode_one_pass_min_blocks": 0, "sf_encode_variant": 5, "sf_encode_lanes": 0,
+DEFAULT_OPTIONS = {"sf_encode_one_pass_min_blocks": 0, "sf_encode_variant": 5, "sf_encode_lanes": 0, "sf_encode_window_bits": 0,
                    "sf_decode_speculate": 1, "sf_decode_path": 0, "rle_encode_general": 0}
 
 
@@ -370,6 +370,7 @@ DEFAULT_OPTIONS = {"sf_encode_one_pass_min_blocks": 0, "sf_encode_variant": 5, "
     {"sf_encode_one_pass_min_blocks": 1, "sf_encode_variant": 4},          # ... with atomic-OR windows (sfe4_kernel)
     {"sf_encode_one_pass_min_blocks": 1, "sf_encode_lanes": 256},          # ... 256-lane workgroups, 8 KiB tiles
     {"sf_encode_one_pass_min_blocks": 1, "sf_encode_lanes": 512},          # ... 512-lane workgroups, 16 KiB tiles
+    {"sf_encode_one_pass_min_blocks": 1, "sf_encode_window_bits": 4},      # ... windows too small: flagged, encoded again (256 lanes)
     {"sf_decode_speculate": 0},                                            # exact DP kernels (sfd_sync16 / sfd_countfsm)
     {"sf_decode_speculate": 2},                                            # speculative entries whatever the code
     {"sf_decode_path": 1},                                                 # one code per look-up (sfd_count13 / sfd_write13, sfd_count / sfd_write)

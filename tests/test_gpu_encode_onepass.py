@@ -184,3 +184,43 @@ def test_one_pass_more_blocks_than_workgroups(shafa, oracle):
     blocks, tables = zipf_blocks(shafa, oracle, sizes, seed0=3000)
     shafa.lib().shafa_hip_init(0)
     run_batch(shafa, oracle, blocks, tables)
+
+
+@pytest.mark.parametrize("window_bits", [3, 6, 7, 9])
+def test_one_pass_windows_smaller_than_the_worst_case_encode_again(shafa, oracle, window_bits):
+    """The 1024-lane form sizes its LDS windows for at most 12 bits per symbol (13..16-bit codes) and encodes a block whose
+    tile does not fit again with the 256-lane form.  `sf_encode_window_bits` shrinks the windows so that ordinary data
+    takes that path: 3 = every tile of every block overflows, 6 / 7 = some tiles of some blocks (Zipf(1.2): 6.5 bits per
+    symbol on average), 9 = none.  Ragged sizes: the tail kernel of the second pass must touch flagged blocks only."""
+    shafa.lib().shafa_hip_init(0)
+    sizes = [(1 << 18) + 977 * i for i in range(10)] + [32768, 65536 + 5, 8192 * 9, 40000, 1 << 20]
+    blocks, tables = zipf_blocks(shafa, oracle, sizes, seed0=8100)
+    # a block whose first half is its rare symbols (long codes) and whose second half its frequent ones: with 7-bit windows
+    # the tiles of the first half overflow, those of the second do not
+    lens = tables[0].lens()
+    rare = np.nonzero(lens >= 8)[0].astype(np.uint8)
+    freq = np.nonzero((lens > 0) & (lens <= 5))[0].astype(np.uint8)
+    half = 1 << 18
+    mixed = np.concatenate([rare[oracle.gen_bytes(1, half) % rare.size], freq[oracle.gen_bytes(2, half) % freq.size]])
+    blocks.append(mixed)
+    tables.append(tables[0])
+    shafa.set_option("sf_encode_one_pass_min_blocks", 1)
+    shafa.set_option("sf_encode_window_bits", window_bits)
+    try:
+        run_batch(shafa, oracle, blocks, tables)
+    finally:
+        shafa.set_option("sf_encode_window_bits", 0)
+        shafa.set_option("sf_encode_one_pass_min_blocks", 0)
+
+
+def test_one_pass_wide_form_for_codes_of_13_to_16_bits(shafa, oracle):
+    """Default dispatch, >= 6 blocks of 13..16-bit codes: the 1024-lane form with 12-bit windows plus the (idle) second
+    pass; one block is made of its rarest symbols only (16-bit codes back to back: its tiles do not fit, it is encoded
+    again)."""
+    shafa.lib().shafa_hip_init(0)
+    otab, data = long_code_case(oracle, 600000, 17, 0.5, 3)
+    assert otab.lens().max() == 16
+    rare = np.nonzero(otab.lens() >= 14)[0].astype(np.uint8)
+    blocks = [data, data[:300001], data[5:250000], rare[oracle.gen_bytes(9, 200000) % rare.size], data[:32768], data[:70000],
+              data[100:500000], data[:8191]]
+    run_batch(shafa, oracle, blocks, [otab] * len(blocks))
