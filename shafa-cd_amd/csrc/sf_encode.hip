@@ -208,6 +208,8 @@ __global__ __launch_bounds__(ENC_THREADS) void sf_encode_generic(const EncBlk *_
 void sfenc3_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 *d_tile_bits, u64 *d_tile_off, bool lut64);
 int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, u32 ragged, const SfeRedo &x);
 bool sfenc4_needs_redo(u32 lmax);
+bool sfenc4_long_ok();
+int sfenc4_launch_long(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, u32 ragged, const SfeRedo &x);
 extern int g_sfe4_wide, g_sfe_lanes;
 
 // A launch with at least this many class-1 blocks takes the one-pass encoder: every block is its own chain, and with this
@@ -236,7 +238,7 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     // classify blocks: 0 = nothing to launch (empty table or empty block), 1 = Lmax <= 16, 2 = Lmax <= 32, 3 = generic
     int cls_count[4] = {0, 0, 0, 0};
     std::vector<int> cls(nblocks);
-    u32 lmax1 = 0;
+    u32 lmax1 = 0, lmax2 = 0;
     for (int b = 0; b < nblocks; ++b) {
         if ((h_in_off[b] & 15) || (h_out_off[b] & 15)) return SHAFA_OUTSIDE_MODULE;
         int lmax = 0;
@@ -245,12 +247,16 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         cls[b] = c;
         cls_count[c]++;
         if (c == 1 && (u32)lmax > lmax1) lmax1 = (u32)lmax;
+        if (c == 2 && (u32)lmax > lmax2) lmax2 = (u32)lmax;
     }
     // the one-pass encoder pays from 6 blocks per launch in its 1024-lane form (every Lmax <= 16 since the windows of
     // 13..16-bit codes are sized for 12 bits per symbol with an encode-again fall-back), from 80 in the 256-lane form
     const bool wide_form = g_sfe4_wide && g_sfe_lanes == 0 && (lmax1 <= 12 || sfenc4_needs_redo(lmax1));
     const bool one_pass = cls_count[1] >= (g_sfe4_min_blocks > 0 ? g_sfe4_min_blocks : (wide_form ? 6 : 80));
-    const bool redo = one_pass && cls_count[1] && sfenc4_needs_redo(lmax1);
+    // codes of 17..32 bits: the quad form of the one-pass encoder from 6 blocks per launch, else count / scan / pack with
+    // 64-bit groups
+    const bool one_pass2 = cls_count[2] >= (g_sfe4_min_blocks > 0 ? g_sfe4_min_blocks : 6) && sfenc4_long_ok();
+    const bool redo = (one_pass && cls_count[1] && sfenc4_needs_redo(lmax1)) || one_pass2;
     const u64 tile_syms[4] = {1, 256 * 16 * 2, 256 * 16 * 2, GEN_TILE};
     u64 total_tiles[4] = {0, 0, 0, 0};
     u32 max_tiles[4] = {0, 0, 0, 0};
@@ -322,6 +328,10 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
                 u32 *l = (u32 *)(htab + tpos);
                 for (int s = 0; s < 256; ++s) l[s] = t.len[s] ? (code_value(t, s) | ((u32)t.len[s] << 16)) : 0x80000000u;
                 tpos += 1024;
+            } else if (c == 2 && one_pass2) {         // {code, len}; a symbol without a code: len = 1 << 16
+                u64 *l = (u64 *)(htab + tpos);
+                for (int s = 0; s < 256; ++s) l[s] = t.len[s] ? ((u64)code_value(t, s) | ((u64)t.len[s] << 32)) : (1ull << 48);
+                tpos += 2048;
             } else if (c == 2) {                      // code | len << 32
                 u64 *l = (u64 *)(htab + tpos);
                 for (int s = 0; s < 256; ++s) l[s] = (u64)code_value(t, s) | ((u64)t.len[s] << 32);
@@ -333,7 +343,7 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
             ++pos;
         }
     }
-    const bool need_desc = cls_count[3] || (cls_count[1] && one_pass);
+    const bool need_desc = cls_count[3] || (cls_count[1] && one_pass) || one_pass2;
     if (o_zero_end && need_desc) HIP_TRY(hipMemsetAsync(ws, 0, o_zero_end, st));
     HIP_TRY(hipMemcpyAsync(ws + o_blk, hs, stage_bytes, hipMemcpyHostToDevice, st));
     for (int b = 0; b < nblocks; ++b)
@@ -348,11 +358,17 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
             for (int b = 0; b < nblocks; ++b)
                 if (cls[b] == 1) ragged |= ((h_in_n[b] & 8191) ? 1u : 0u) | ((h_in_n[b] & 16383) ? 2u : 0u) | ((h_in_n[b] & 32767) ? 4u : 0u);
             const SfeRedo x = {redo ? (u64 *)(ws + o_desc2) : nullptr, redo ? (u32 *)(ws + o_tick2) : nullptr,
-                               redo ? (u32 *)(ws + o_redo) : nullptr};
+                               redo ? (u32 *)(ws + o_redo) + cls_first[1] : nullptr};
             if ((rc = sfenc4_launch(st, dblk + cls_first[1], cls_count[1], ddesc, dtick, lmax1, ragged, x))) return rc;
         } else sfenc3_launch(st, dblk + cls_first[1], cls_count[1], max_tiles[1], (u32 *)(ws + o_tbits), ddesc, false);
     }
-    if (cls_count[2]) sfenc3_launch(st, dblk + cls_first[2], cls_count[2], max_tiles[2], (u32 *)(ws + o_tbits), ddesc, true);
+    if (cls_count[2] && one_pass2) {
+        u32 ragged = 0;
+        for (int b = 0; b < nblocks; ++b)
+            if (cls[b] == 2) ragged |= ((h_in_n[b] & 8191) ? 1u : 0u) | ((h_in_n[b] & 32767) ? 4u : 0u);
+        const SfeRedo x = {(u64 *)(ws + o_desc2), (u32 *)(ws + o_tick2), (u32 *)(ws + o_redo) + cls_first[2]};
+        if ((rc = sfenc4_launch_long(st, dblk + cls_first[2], cls_count[2], ddesc, dtick, lmax2, ragged, x))) return rc;
+    } else if (cls_count[2]) sfenc3_launch(st, dblk + cls_first[2], cls_count[2], max_tiles[2], (u32 *)(ws + o_tbits), ddesc, true);
     if (cls_count[3])
         hipLaunchKernelGGL(sf_encode_generic, dim3(max_tiles[3] * cls_count[3]), dim3(ENC_THREADS), 0, st,
                            dblk + cls_first[3], cls_count[3], ddesc, dtick);

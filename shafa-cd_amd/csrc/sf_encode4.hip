@@ -552,6 +552,39 @@ __device__ __forceinline__ void load_tile5(const u8 *in, u32 tile, int tid, Tile
 #endif
 }
 
+// Codes of up to 32 bits (class 2: a real file's rare bytes at -b M): the unit is a QUAD, the 4 symbols of one input
+// dword as a right-aligned string of up to 128 bits in the same Oct registers; eight quads per lane instead of four octs.
+// SAFE: lengths may be 0 (symbols past the block's end encode as nothing).
+template <bool SAFE>
+__device__ __forceinline__ Oct make_quad4(const u64 *lut, u32 w, u32 drop4)
+{
+    u64 e[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) e[j] = lut[(w >> (8 * j)) & 0xFFu];
+    if (SAFE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((drop4 >> j) & 1u) e[j] = 0;
+    }
+    const u32 c0 = (u32)e[0], c1 = (u32)e[1], c2 = (u32)e[2], c3 = (u32)e[3];
+    const u32 l0 = (u32)(e[0] >> 32), l1 = (u32)(e[1] >> 32), l2 = (u32)(e[2] >> 32), l3 = (u32)(e[3] >> 32);
+    const u64 p0 = ((u64)c0 << (l1 & 63u)) | c1;       // <= 64 bits
+    const u64 p1 = ((u64)c2 << (l3 & 63u)) | c3;
+    const u32 s = (l2 + l3) & 0xFFFFu;                 // 2 .. 64 on the plain path
+    u64 lo = p0 << (s & 63u);
+    u64 hi = p0 >> ((64u - s) & 63u);                  // s == 64: everything moves into hi (a shift by 64 wraps to 0)
+    if (s >= 64u) lo = 0;
+    if (SAFE && s == 0u) hi = 0;
+    lo |= p1;
+    Oct o;
+    o.r0 = (u32)lo;
+    o.r1 = (u32)(lo >> 32);
+    o.r2 = (u32)hi;
+    o.r3 = (u32)(hi >> 32);
+    o.ll = l0 + l1 + l2 + l3;
+    return o;
+}
+
 // the lane's four octs, its inclusive bit prefix inside the wave and the last 32 bits of its string
 template <int NW, bool L16>
 __device__ __forceinline__ void tile_octs5(const u64 *lut, const TileIn5 &in, Oct (&oct)[4], u32 &tot, u32 &incl, u32 &tail,
@@ -576,6 +609,27 @@ __device__ __forceinline__ void tile_octs5(const u64 *lut, const TileIn5 &in, Oc
         for (int k = 1; k < 4; ++k) v = oct[k].ll >= 32u ? oct[k].r0 : ((v << (oct[k].ll & 31u)) | oct[k].r0);
         tail = v;
     }
+}
+
+// the same for the quad form: the lane's eight quads (a quad of short codes has fewer than 32 bits: the last 32 bits of the
+// lane's string always come from several of them)
+__device__ __forceinline__ void tile_quads5(const u64 *lut, const TileIn5 &in, Oct (&qd)[8], u32 &tot, u32 &incl, u32 &tail,
+                                            u32 &absent)
+{
+    const u32 w[8] = {in.v[0].x, in.v[0].y, in.v[0].z, in.v[0].w, in.v[1].x, in.v[1].y, in.v[1].z, in.v[1].w};
+    tot = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        qd[k] = make_quad4<false>(lut, w[k], 0u);
+        absent |= qd[k].ll >> 16;
+        qd[k].ll &= 0xFFFFu;
+        tot += qd[k].ll;                                           // <= 1024
+    }
+    incl = dpp_scan_add(tot);                                      // a wave's total <= 65536
+    u32 v = qd[0].r0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v = qd[k].ll >= 32u ? qd[k].r0 : ((v << (qd[k].ll & 31u)) | qd[k].r0);
+    tail = v;
 }
 
 // exclusive offset of this wave and the tile total from the NWV (4 or 16) wave totals: a scan inside one 16-lane DPP row
@@ -627,7 +681,7 @@ __device__ __forceinline__ u32 emit_oct(u32 *win, u32 *dump, const Oct &o, u32 e
 // one of them at most 2^-13 of the block — would have to fill a whole 32 KiB tile) is not placed, its block is flagged in
 // redo[] and encoded again by the 256-lane form (worst-case windows) in a follow-up launch that looks at flagged blocks
 // only (redo_only).  redo == nullptr: the windows hold the worst case.
-template <int NW, bool L16, int NT>
+template <int NW, bool L16, int NT, int UNITS = 4>
 __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restrict__ blks, int nblk, int nconc,
                                                              u64 *__restrict__ desc, u32 *__restrict__ tickets, u32 win_stride,
                                                              u32 cap_bits, u32 *__restrict__ redo, int redo_only)
@@ -655,9 +709,12 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restri
         if (cur >= nfull) continue;
         u32 req = E4_NONE;
         if (tid == 0) req = atomicAdd(tick, 1u);
-        TileIn5 cin, nin, nin2;                        // inputs are requested two tiles ahead
+        // inputs are requested two tiles ahead (octs) or one (quads: their iterations are half as long again and the forty
+        // registers of eight quads leave no room for a third input set)
+        constexpr bool PF2 = UNITS == 4;
+        TileIn5 cin, nin, nin2;
         load_tile5<NT>(in, cur, tid, cin);
-        if (nxt < nfull) load_tile5<NT>(in, nxt, tid, nin);
+        if (PF2 && nxt < nfull) load_tile5<NT>(in, nxt, tid, nin);
         u64 first_w = 0;
         u32 pv_w = 0;
 
@@ -680,7 +737,7 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restri
             const u32 pbuf = buf >= 2 ? buf - 2 : buf + 1;
             u32 *win = dynwin + buf * win_stride + E4_GUARD;               // this tile's window
             u32 *pwin = dynwin + pbuf * win_stride + E4_GUARD;             // the window that is stored in this iteration
-            Oct c_oct[4];
+            Oct c_oct[UNITS];
             u32 tot = 0, incl = 0, tail = 0;
 
             // ---- wave 0, before it issues anything new (see sfe4_kernel) -----------------------------------------------
@@ -702,13 +759,19 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restri
             }
 
             // ---- this tile: look up, group, scan -----------------------------------------------------------------------
-            if (rotate_in) { cin = nin; nin = nin2; }
+            if (PF2) {
+                if (rotate_in) { cin = nin; nin = nin2; }
+                if (cur_ok && nn < nfull) load_tile5<NT>(in, nn, tid, nin2);
+            } else {
+                if (rotate_in) cin = nin;
+                if (cur_ok && nxt < nfull) load_tile5<NT>(in, nxt, tid, nin);
+            }
             rotate_in = true;
-            if (cur_ok && nn < nfull) load_tile5<NT>(in, nn, tid, nin2);
             if (tid == 0) req = atomicAdd(tick, 1u);
             if (cur_ok) {
                 u32 absent = 0;
-                tile_octs5<NW, L16>(sh.lut, cin, c_oct, tot, incl, tail, absent);
+                if constexpr (UNITS == 4) tile_octs5<NW, L16>(sh.lut, cin, c_oct, tot, incl, tail, absent);
+                else tile_quads5(sh.lut, cin, c_oct, tot, incl, tail, absent);
                 if (absent) set_error(bp->err, SHAFA_FILE_UNRECOGNIZABLE);   // data symbol without a code (output undefined, in bounds)
                 if (lane == 63) {
                     sh.wtot5[par][wv] = incl;
@@ -752,7 +815,7 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restri
 #endif
                 if (fits) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < UNITS; ++k) {
                         e += c_oct[k].ll;
                         c = emit_oct<NW>(win, sh.dump + lane, c_oct[k], e, c);
                     }
@@ -837,6 +900,119 @@ __global__ __launch_bounds__(NT) void sfe4_tail_kernel(const EncBlk *__restrict_
     __syncthreads();
     store_window(win, blk.out, blk.out_cap, blk.err, B, T, true, tid, NT);
     if (tid == 0) gstore<u64>(blk.out_n, (B + T + 7) >> 3);
+}
+
+// The ragged remainder of blocks with codes of up to 32 bits (quads): one workgroup per block, launched after the main
+// kernel; lanes take 32 consecutive symbols as there, symbols past the block's end encode as nothing, quads are ORed into
+// a zeroed window (atomics: a quad may be shorter than a dword here).
+template <int NT>
+__global__ __launch_bounds__(NT) void sfe5q_tail_kernel(const EncBlk *__restrict__ blks, const u64 *__restrict__ desc,
+                                                                u32 win_stride, const u32 *__restrict__ redo_only)
+{
+    if (redo_only && gload<u32>(redo_only + blockIdx.x) == 0u) return;      // follow-up launch: flagged blocks only
+    __shared__ E4Static sh;
+    extern __shared__ __attribute__((aligned(16))) u32 dynwin[];
+    u32 *win = dynwin + E4_GUARD;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NWV = NT / 64;
+    constexpr u32 TILE = 32u * NT, TSHIFT = NT == 256 ? 13 : NT == 512 ? 14 : 15;
+    const EncBlk blk = blks[blockIdx.x];
+    const u32 rem = (u32)(blk.n & (TILE - 1));
+    if (!rem) return;
+    const u32 nfull = (u32)(blk.n >> TSHIFT);
+    const u8 *tb = blk.in + (u64)nfull * TILE;
+    if (tid < 256) sh.lut[tid] = gload<u64>((const u64 *)blk.lut + tid);
+    for (u32 i = (u32)tid; i < win_stride / 4; i += NT) ((uint4 *)dynwin)[i] = make_uint4(0, 0, 0, 0);
+    u32 w[8];
+    const u32 base = (u32)tid * 32u;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const u32 idx = base + 4u * (u32)q;
+        w[q] = 0;
+        if (idx + 4 <= rem) w[q] = gload<u32>(tb + idx);
+        else if (idx < rem)
+            for (u32 j = 0; j < rem - idx; ++j) w[q] |= (u32)gload<u8>(tb + idx + j) << (8 * j);
+    }
+    const u32 pv = (tid < 32 && nfull > 0) ? (u32)gload<u8>(tb - 1 - tid) : 0u;
+    const u64 B = nfull ? (desc_load(desc + blk.desc_base + nfull - 1) & DESC_VALUE_MASK) : 0ull;   // inclusive prefix of the last full tile
+    __syncthreads();
+    Oct qd[8];
+    u32 tot = 0, absent = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const u32 idx = base + 4u * (u32)q;
+        const u32 keep = idx >= rem ? 0u : (rem - idx >= 4u ? 4u : rem - idx);
+        qd[q] = make_quad4<true>(sh.lut, w[q], (0xFu << keep) & 0xFu);
+        absent |= qd[q].ll >> 16;
+        qd[q].ll &= 0xFFFFu;
+        tot += qd[q].ll;
+    }
+    if (absent) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
+    const u32 incl = dpp_scan_add(tot);
+    if (lane == 63) sh.wtot5[0][wv] = incl;
+    if (wv == 0 && ((u32)B & 31u) && nfull > 0) lead_bits(sh.lut, win, pv, (u32)B & 31u, lane);
+    __syncthreads();
+    u32 woff;
+    const u32 T = tile_offsets5<NWV>(sh.wtot5[0], lane, wv, woff);
+    u32 e = woff + incl - tot;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        e += qd[q].ll;
+        if (qd[q].ll) place<5>(win, qd[q], e);
+    }
+    __syncthreads();
+    store_window(win, blk.out, blk.out_cap, blk.err, B, T, true, tid, NT);
+    if (tid == 0) gstore<u64>(blk.out_n, (B + T + 7) >> 3);
+}
+
+// the quad form's launcher (codes of 17..32 bits): as e4_launch_nt, windows of lmax_win bits per symbol
+template <int NT>
+int e5q_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax_win, u32 lmax, bool any_ragged,
+                  u32 *d_redo, int redo_only)
+{
+    constexpr int MAXDEV = 64;
+    static int wgs_by_dev_lmax[MAXDEV][33], cus_by_dev[MAXDEV], tail_attr_by_dev[MAXDEV];
+    static std::mutex mu;
+    const u32 win_stride = ((u32)E4_GUARD + (u32)(((size_t)(32 * NT) * lmax_win) >> 5) + 8u + 3u) & ~3u;   // dwords per buffer
+    const u32 tail_stride = ((u32)E4_GUARD + (u32)(((size_t)(32 * NT) * lmax) >> 5) + 8u + 3u) & ~3u;
+    const size_t dyn = (size_t)win_stride * 3 * 4;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAXDEV || lmax_win > 32 || lmax > 32) return SHAFA_OUTSIDE_MODULE;
+    int wgs_per_cu = 0, cus = 0;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        int *wgs_by_lmax = wgs_by_dev_lmax[dev];
+        if (!wgs_by_lmax[lmax_win]) {
+            int occ = 0;
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, dev));
+            cus_by_dev[dev] = prop.multiProcessorCount;
+            if (dyn > 65536)
+                HIP_TRY(hipFuncSetAttribute((const void *)sfe5_kernel<5, false, NT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)sfe5_kernel<5, false, NT, 8>, NT, dyn));
+            wgs_by_lmax[lmax_win] = occ < 1 ? 1 : (occ > 6 ? 6 : occ);
+        }
+        if (any_ragged && (size_t)tail_stride * 4 > 65536 && tail_attr_by_dev[dev] < (int)tail_stride) {
+            HIP_TRY(hipFuncSetAttribute((const void *)sfe5q_tail_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)((size_t)tail_stride * 4)));
+            tail_attr_by_dev[dev] = (int)tail_stride;
+        }
+        wgs_per_cu = wgs_by_lmax[lmax_win];
+        cus = cus_by_dev[dev];
+    }
+    int target = cus * wgs_per_cu;
+    int nconc = count < target ? count : target;
+    int per = target / nconc;
+    if (per < 1) per = 1;
+    const u32 cap_bits = (u32)(32u * NT) * lmax_win;
+    hipLaunchKernelGGL((sfe5_kernel<5, false, NT, 8>), dim3((u32)(nconc * per)), dim3(NT), dyn, st, dblk, count, nconc, d_desc, d_tickets,
+                       win_stride, cap_bits, d_redo, redo_only);
+    if (any_ragged)
+        hipLaunchKernelGGL((sfe5q_tail_kernel<NT>), dim3((u32)count), dim3(NT), (size_t)tail_stride * 4, st, dblk,
+                           (const u64 *)d_desc, tail_stride, (const u32 *)(redo_only ? d_redo : nullptr));
+    return SHAFA_SUCCESS;
 }
 
 // lmax_win: bits per symbol the three windows are sized for (the launch's longest code, or less: see sfe5_kernel's
@@ -944,6 +1120,20 @@ extern "C" int shafa_e4_read_stamps(unsigned long long *dst, int n)
 bool sfenc4_needs_redo(u32 lmax)
 {
     return g_sfe_variant == 5 && g_sfe4_wide && g_sfe_lanes == 0 && e5_window_bits(lmax) < lmax;
+}
+
+// can launches of codes of 17..32 bits take the one-pass encoder (quad form)?  It always runs with windows smaller than
+// its worst case, so it needs the second chain.
+bool sfenc4_long_ok() { return g_sfe_variant == 5 && g_sfe4_wide && g_sfe_lanes == 0; }
+
+// blocks whose codes are 17..32 bits (tables 256 x u64 {code, len}, len = 1 << 16 for a symbol without a code)
+int sfenc4_launch_long(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, u32 ragged, const SfeRedo &x)
+{
+    if (!x.redo) return SHAFA_OUTSIDE_MODULE;
+    const u32 wbits = e5_window_bits(lmax);
+    int rc = e5q_launch_nt<1024>(st, dblk, count, d_desc, d_tickets, wbits, lmax, (ragged & 4u) != 0, x.redo, 0);
+    if (rc) return rc;
+    return e5q_launch_nt<256>(st, dblk, count, x.desc2, x.tickets2, lmax, lmax, (ragged & 1u) != 0, x.redo, 1);
 }
 
 int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, u32 ragged, const SfeRedo &x)

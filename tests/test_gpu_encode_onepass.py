@@ -224,3 +224,65 @@ def test_one_pass_wide_form_for_codes_of_13_to_16_bits(shafa, oracle):
     blocks = [data, data[:300001], data[5:250000], rare[oracle.gen_bytes(9, 200000) % rare.size], data[:32768], data[:70000],
               data[100:500000], data[:8191]]
     run_batch(shafa, oracle, blocks, [otab] * len(blocks))
+
+
+def _long_tail_blocks(shafa, oracle, sizes, seed0):
+    """Zipf data over 200 common symbols plus 56 rare ones (1 .. a few hundred occurrences): Lmax 17..32, what a real file
+    gives at -b M (tools/longtail_time.py)."""
+    zt = shafa.zipf_table(1.2)
+    zt = np.where(zt >= 200, zt % 200, zt).astype(np.uint8)
+    rng = np.random.default_rng(seed0)
+    blocks, tables = [], []
+    for i, n in enumerate(sizes):
+        b = oracle.gen_bytes(seed0 + i, n, zt).copy()
+        for k in range(56):
+            cnt = 1 + (k * k) // 9
+            b[rng.integers(0, n, size=min(cnt, n))] = 200 + k
+        blocks.append(b)
+        tables.append(oracle.sf_build(oracle.hist256(b)))
+    return blocks, tables
+
+
+@pytest.mark.parametrize("window_bits", [0, 5, 7])
+def test_one_pass_codes_of_17_to_32_bits(shafa, oracle, window_bits):
+    """The quad form of the one-pass encoder (codes of up to 32 bits: four symbols per unit, windows sized for 12 bits per
+    symbol, flagged blocks encoded again by its 256-lane form): ragged sizes, blocks made of their longest codes only (these
+    do not fit the windows), a missing code and a short output region in one block among many; with smaller windows the
+    second pass also runs for ordinary blocks."""
+    shafa.lib().shafa_hip_init(0)
+    sizes = [300000 + 1013 * i for i in range(7)] + [32768, 32768 * 3 + 5, 8192 * 5, 70001, (1 << 20) + 77, 33, 4097]
+    blocks, tables = _long_tail_blocks(shafa, oracle, sizes, 9100)
+    lm = [int(t.lens().max()) for t in tables]
+    assert all(l > 16 for l in lm[:7]) and max(lm) <= 32, lm
+    lens = tables[0].lens()
+    rare = np.nonzero(lens >= 17)[0].astype(np.uint8)
+    assert rare.size >= 2
+    blocks.append(rare[oracle.gen_bytes(3, 150000) % rare.size])          # only codes of 17+ bits: no tile fits a 12-bit window
+    tables.append(tables[0])
+    # same-length 32-bit codes next to each other need the 64-bit shift edge cases of the quad: the deepest table we can make
+    otab, data = long_code_case(oracle, 120000, 33, 0.5, 11)
+    assert otab.lens().max() == 32
+    deep = np.nonzero(otab.lens() == 32)[0].astype(np.uint8)
+    blocks += [data, deep[oracle.gen_bytes(4, 50000) % deep.size]]
+    tables += [otab, otab]
+    shafa.set_option("sf_encode_one_pass_min_blocks", 1)
+    shafa.set_option("sf_encode_window_bits", window_bits)
+    try:
+        run_batch(shafa, oracle, blocks, tables)
+        # errors stay with their block
+        f = oracle.hist256(blocks[2])
+        bad = blocks[2].copy()
+        bad[777] = 199 if f[199] == 0 else 198
+        f2 = f.copy()
+        f2[bad[777]] = 0
+        t_bad = oracle.sf_build(f2)
+        if t_bad.lens()[bad[777]] == 0 and int(t_bad.lens().max()) > 16:
+            want = [oracle.sf_encode(b, t)[1].size for b, t in zip(blocks[:6], tables[:6])]
+            caps = [((w + 15) // 16 + 1) * 16 for w in want]
+            caps[4] = (want[4] // 2) // 16 * 16
+            bl, tb = list(blocks[:6]), list(tables[:6])
+            bl[2], tb[2] = bad, t_bad
+            run_batch(shafa, oracle, bl, tb, caps=caps, expect_err={2: shafa.FILE_UNRECOGNIZABLE, 4: shafa.LACK_OF_MEMORY})
+    finally:
+        shafa.set_option("sf_encode_window_bits", 0)
+        shafa.set_option("sf_encode_one_pass_min_blocks", 0)
