@@ -431,8 +431,8 @@ def main():
     with torch.cuda.stream(st):
         pkg.gen_bytes(st, SEED, rank * shard, d_in, shard, d_map)
     bt = pkg.Batch(nb, bs)
-    in_off = [b * bs for b in range(nb)]
-    in_n = [bs] * nb
+    in_off = np.arange(nb, dtype=np.uint64) * np.uint64(bs)       # host arrays once, not per call: at -b m the launcher's
+    in_n = np.full(nb, bs, dtype=np.uint64)                        # host time is of the order of the kernels' time
     d_freq = torch.zeros(nb * 256, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()              # torch's fills run on its own stream: finish them before ours starts
     bt.hist256(st, d_in, in_off, in_n, d_freq)
@@ -443,8 +443,9 @@ def main():
     enc_bits = (freq * lens).sum(axis=1)
     enc_bytes = (enc_bits + 7) // 8
     cap = int(((int(enc_bytes.max()) + 4096 + 255) // 256) * 256)
-    out_off = [b * cap for b in range(nb)]
-    out_cap = [cap] * nb
+    out_off = np.arange(nb, dtype=np.uint64) * np.uint64(cap)
+    out_cap = np.full(nb, cap, dtype=np.uint64)
+    enc_bytes = enc_bytes.astype(np.uint64)
     d_enc = torch.empty(nb * cap, dtype=torch.uint8, device=dev)
     d_enc_n = torch.zeros(nb, dtype=torch.int64, device=dev)
     d_dec = torch.empty(shard, dtype=torch.uint8, device=dev)
@@ -566,7 +567,7 @@ def main():
                          d_enc_n)                                            # same tables: same stream
             bt.finish(st, sg_nb)
             t2 = time.perf_counter()
-            got = shd.gather_payloads(d_enc, out_off[:sg_nb], [int(x) for x in enc_bytes[:sg_nb]], world * sg_nb, dev)   # X2
+            got = shd.gather_payloads(d_enc, [int(x) for x in out_off[:sg_nb]], [int(x) for x in enc_bytes[:sg_nb]], world * sg_nb, dev)   # X2
             torch.cuda.synchronize()
             comm.barrier()
             t3 = time.perf_counter()
