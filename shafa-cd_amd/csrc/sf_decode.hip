@@ -1323,7 +1323,7 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
             const u32 i = tid + it * DEC_THREADS;
             const long long off = base + (long long)i * 16;
             v[it] = make_uint4(0, 0, 0, 0);
-            if (i < UNITS && off >= 0 && (u64)off + 16 <= blk.in_n) v[it] = gload<uint4>(blk.in + off);
+            if (i < UNITS && off >= 0 && (u64)off + 16 <= blk.in_n) v[it] = gload_nt<uint4>(blk.in + off);
         }
 #pragma unroll
         for (u32 it = 0; it < NIT; ++it) {
@@ -1618,7 +1618,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
     const u32 mask4 = ((1u << K3) - 1u) << 2;
     // 16 stream bytes at `off` (zeros past the end)
     auto fetch16 = [&](const u64 off) -> uint4 {
-        if (off + 16 <= blk.in_n) return gload<uint4>(blk.in + off);
+        if (off + 16 <= blk.in_n) return gload_nt<uint4>(blk.in + off);
         u32 w[4] = {0, 0, 0, 0};
         if (off < blk.in_n) {
             const int nv = (int)(blk.in_n - off);
@@ -1762,7 +1762,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                 *ip = make_uint4(0, 0, 0, 0);
                 u8 *ga = gout - mis + 16 * u;
                 if (16 * u >= mis && 16 * u + 16 <= end) {
-                    gstore<uint4>(ga, v);
+                    gstore_nt<uint4>(ga, v);
                 } else {
                     const u32 wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
