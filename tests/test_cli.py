@@ -150,3 +150,22 @@ def _replay_and_check(case, tmp_path):
         p = tmp_path / fn
         assert os.path.getsize(p) == meta["size"], f"{case}/{fn}: size {os.path.getsize(p)} != {meta['size']}"
         assert sha(p) == meta["sha256"], f"{case}/{fn}: content differs from the reference's file"
+
+
+@pytest.mark.gpu
+def test_cli_device_list_errors_are_reported(tmp_path):
+    """SHAFA_DEVICES naming a GPU the node does not have (or garbage) is an error message and exit 1 before any module
+    runs — not a silent fall-back to device 0; a valid list works; Module T alone ignores the variable (it touches no GPU)."""
+    shutil.copyfile(os.path.join(GOLD, "cli_errors", "z"), tmp_path / "z")
+    for bad in ("99", "0,99", "x", "-1", "0;1"):
+        env = dict(os.environ, SHAFA_DEVICES=bad)
+        r = subprocess.run([CLI, "z", "-m", "f"], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode == 1 and "SHAFA_DEVICES" in r.stderr, (bad, r.returncode, r.stderr)
+        assert not os.path.exists(tmp_path / "z.rle") and not os.path.exists(tmp_path / "z.freq"), bad
+    env = dict(os.environ, SHAFA_DEVICES="0")
+    r = subprocess.run([CLI, "z", "-m", "f"], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    stem = "z.rle" if os.path.exists(tmp_path / "z.rle") else "z"
+    env = dict(os.environ, SHAFA_DEVICES="99")
+    r = subprocess.run([CLI, stem + ".freq", "-m", "t"], cwd=tmp_path, capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and os.path.exists(tmp_path / (stem + ".cod")), r.stderr
