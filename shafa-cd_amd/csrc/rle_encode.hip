@@ -8,12 +8,10 @@
 // r needs the run length that enters a tile from the left, e needs at most 255 bytes of look-ahead (a halo read), the
 // output offset of a tile the sizes of all tiles before it.  Two passes over the input by independent workgroups and
 // three tiny launches in between deliver them (rle3_* below: no tickets, no look-backs); tokens are staged in LDS and
-// stored as aligned 16-byte pieces.  (A single chained pass — one read of the input — was built three times.  Rounds 1 and
-// 2: a workgroup per tile with the size published and looked back at once: no faster, 10 of its 15 us are waits.  Round 3:
-// persistent workgroups, per-block tickets, a pair's size published a whole step before its own look-back, the next
-// pair's bytes and the ticket after it requested ahead, stores a step later, the flagged-block fall-back to these passes:
-// bit-exact, 1.81 ms for 32 x 64 MiB against 1.54 for rle3_first + rle3_emit, and slower still with more workgroups per
-// CU: per pair four barriers, a ticket and a look-back cost more than the second read of the input.)
+// stored as aligned 16-byte pieces.  (A single chained pass — one read of the input — was built twice, rounds 1 and 2: on inputs that
+// take the mask code it is no faster, a workgroup spends 10 of its 15 us waiting for its ticket, its loads and its two
+// look-backs, and on long runs its general tile code is 40 times slower; it needs the deferred look-backs of a
+// persistent pipeline like sfe4's to pay)
 //
 // Algorithmic HBM bytes per block: n read + rle_n written.
 #include "common.hpp"
