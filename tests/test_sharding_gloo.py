@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the multi-GPU path's host logic (block split, X1 scatter, X2 gatherv):
+"""world_size-2 and -8 gloo tests of the multi-GPU path's host logic (block split, X1 scatter, X2 gatherv):
 rank 0 owns the input, both ranks encode their blocks (here with the oracle standing in for the GPU
 kernel — the data movement is what is under test), rank 0 re-assembles the payloads in block order
 and compares with the single-process result."""
@@ -60,6 +60,22 @@ def test_scatter_encode_gather_two_ranks(total, bs):
         p.start()
     for p in procs:
         p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+@pytest.mark.parametrize("total,bs", [(13 * 4096 + 5, 4096), (3 * 4096, 4096)])
+def test_scatter_encode_gather_eight_ranks(total, bs):
+    """The world size of the node the scaling bench runs on: 14 blocks over 8 ranks (two ranks hold two blocks, the last
+    block is ragged) and 3 blocks over 8 ranks (five ranks hold nothing and still take part in every collective)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + total) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, total, bs, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
 
