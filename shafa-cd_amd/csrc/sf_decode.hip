@@ -399,12 +399,15 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
 {
     const DecBlk blk = blks[blockIdx.x];
     if (!blk.n_tiles) return;
+    // gridDim.y workgroups share a block's tables (an entry is a chain of up to fifteen dependent look-ups in global
+    // memory: one workgroup per block took 45 us for 12-bit tables, as long as the symbol pass of a small launch)
+    const u32 T0 = threadIdx.x + blockIdx.y * DEC_THREADS, TS = DEC_THREADS * gridDim.y;
     const u32 K1 = blk.K1, mask = (1u << K1) - 1;
-    for (u32 i = threadIdx.x; blk.pairlut && i < (2u << K1); i += DEC_THREADS)
+    for (u32 i = T0; blk.pairlut && i < (2u << K1); i += TS)
         blk.pairlut[i] = (u8)((blk.lenlut[i >> 1] - 1u) | ((blk.lenlut[i & mask] - 1u) << 4));
     const u32 K3 = sym3_window(K1);
     const u32 KW = spec_window(K1), maskw = (1u << KW) - 1;      // the counting window may be wider than the longest code
-    for (u32 i = threadIdx.x; i <= maskw; i += DEC_THREADS) {
+    for (u32 i = T0; i <= maskw; i += TS) {
         u32 pos = 0, n = 0, l0 = 0;
         for (; n < 15; ++n) {
             const u32 L = blk.lut13[((i << pos) & maskw) >> (KW - K1)] >> 8;      // window shifted left, zero filled
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
         ((u8 *)blk.cnt3)[j] = (u8)(pos | (n << 4));
         ((u8 *)blk.cnt3)[(1u << KW) + j] = (u8)l0;
     }
-    for (u32 i = threadIdx.x; i < (1u << K3); i += DEC_THREADS) {   // K3-bit window; n = 0: first code is longer
+    for (u32 i = T0; i < (1u << K3); i += TS) {   // K3-bit window; n = 0: first code is longer
         u32 pos = 0, n = 0, syms = 0;
         for (; n < 3; ++n) {
             const u32 e = blk.lut13[K3 >= K1 ? (((i << pos) & ((1u << K3) - 1u)) >> (K3 - K1)) : (((i << (K1 - K3)) << pos) & mask)];
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
     }
     // counting automaton: state = internal trie node (0 = root = between two codes); consuming a nibble (or a bit)
     // moves to the next state and completes 0..4 codes.  next state is stored as the byte offset of its row.
-    for (u32 i = threadIdx.x; i < blk.n_states * 16; i += DEC_THREADS) {
+    for (u32 i = T0; i < blk.n_states * 16; i += TS) {
         u32 node = i >> 4, done = 0;
         for (int b = 3; b >= 0; --b) {
             const u32 c = blk.trie[2 * node + ((i >> b) & 1u)];
@@ -437,7 +440,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
         }
         blk.fsm4[i] = (node * 64u) | (done << 16);
     }
-    for (u32 i = threadIdx.x; i < blk.n_states * 2; i += DEC_THREADS) {
+    for (u32 i = T0; i < blk.n_states * 2; i += TS) {
         const u32 c = blk.trie[i];
         blk.fsm1[i] = (c & 0x80000000u) ? (1u << 16) : (c * 64u);
     }
@@ -1478,7 +1481,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_spec_check(const DecBlk *__re
     const DecBlk blk = blks[blockIdx.x];
     if (!blk.n_tiles || !blk.run_dp || __hip_atomic_load(blk.run_dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     bool any = false;
-    for (u32 t = threadIdx.x; t < blk.n_tiles; t += DEC_THREADS) {
+    for (u32 t = threadIdx.x + blockIdx.y * DEC_THREADS; t < blk.n_tiles; t += DEC_THREADS * gridDim.y) {   // gridDim.y workgroups per block
         const size_t gt = (size_t)blk.tile_base + t;
         const bool diff = t > 0 && tile_guess[gt] != tile_exit[gt - 1];
         if (!FINAL) tile_fix[gt] = diff ? 1 : 0;
@@ -1789,15 +1792,27 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_offsets(const DecBlk *__restr
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) carry = 0;
     __syncthreads();
-    for (u32 t0 = 0; t0 < blk.n_tiles; t0 += DEC_THREADS) {
-        const u32 t = t0 + tid;
-        const u64 c = t < blk.n_tiles ? (u64)tile_cnt[blk.tile_base + t] : 0ull;
-        const u64 incl = wave_incl_scan_add<u64>(c);
+    // a thread takes OFF_EPT consecutive tiles a round, all of its loads issued before the first is used (one tile per
+    // thread and round: 32 rounds of a load and three barriers for a 64 MiB block, 28 us)
+    constexpr u32 OFF_EPT = 16;
+    for (u32 r0 = 0; r0 < blk.n_tiles; r0 += DEC_THREADS * OFF_EPT) {
+        const u32 t0 = r0 + tid * OFF_EPT;
+        u32 x[OFF_EPT];
+#pragma unroll
+        for (u32 j = 0; j < OFF_EPT; ++j) x[j] = t0 + j < blk.n_tiles ? tile_cnt[blk.tile_base + t0 + j] : 0u;
+        u64 mine = 0;
+#pragma unroll
+        for (u32 j = 0; j < OFF_EPT; ++j) mine += x[j];
+        const u64 incl = wave_incl_scan_add<u64>(mine);
         if (lane == 63) wtot[wv] = incl;
         __syncthreads();
-        u64 base = carry;
+        u64 base = carry + incl - mine;
         for (u32 w = 0; w < wv; ++w) base += wtot[w];
-        if (t < blk.n_tiles) tile_off[blk.tile_base + t] = base + incl - c;
+#pragma unroll
+        for (u32 j = 0; j < OFF_EPT; ++j) {
+            if (t0 + j < blk.n_tiles) tile_off[blk.tile_base + t0 + j] = base;
+            base += x[j];
+        }
         __syncthreads();
         if (tid == 0) carry += wtot[0] + wtot[1] + wtot[2] + wtot[3];
         __syncthreads();
@@ -2317,10 +2332,10 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         };
         spec(std::false_type{}, grid_s);
         for (int round = 0; round < 2; ++round) {
-            hipLaunchKernelGGL(sfd_spec_check<false>, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
+            hipLaunchKernelGGL(sfd_spec_check<false>, dim3((u32)nblocks, 4), dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
             spec(std::true_type{}, grid_sf);
         }
-        hipLaunchKernelGGL(sfd_spec_check<true>, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
+        hipLaunchKernelGGL(sfd_spec_check<true>, dim3((u32)nblocks, 4), dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
     };
     // when every block of the launch speculates, the exact kernels are fall-backs that normally return at once:
     // fat workgroups (256 tiles each) make that a launch of a few thousand workgroups instead of a few hundred thousand
@@ -2330,7 +2345,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const dim3 grid_fd((u32)ceil_div_u64(max_tiles, tpw_dp), (u32)nblocks);
     if (packed) {
         const size_t lds_count16 = lds_data + DEC_THREADS * 8 + lds_lut + 32 + DEC_THREADS + 64;
-        if (need_tabs) hipLaunchKernelGGL(sfd_tables, grid_b, dim3(DEC_THREADS), 0, st, dblk);
+        if (need_tabs) hipLaunchKernelGGL(sfd_tables, dim3((u32)nblocks, 8), dim3(DEC_THREADS), 0, st, dblk);
         if (any_spec) launch_spec();
         const dim3 grid_cd((u32)ceil_div_u64(max_tiles, tpw_dp * CSUBS), (u32)nblocks);
         u32 k1_all = 0;                                // common K1 of the running blocks, 0 when they differ
@@ -2368,7 +2383,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
                                (u32 *)(ws + o_tcnt));
         }
     } else if (mid32) {
-        hipLaunchKernelGGL(sfd_tables, grid_b, dim3(DEC_THREADS), 0, st, dblk);
+        hipLaunchKernelGGL(sfd_tables, dim3((u32)nblocks, 8), dim3(DEC_THREADS), 0, st, dblk);
         if (any_spec) launch_spec();
         hipLaunchKernelGGL(sfd_sync32, grid_fd, dim3(DEC_THREADS), 0, st, dblk, ws + o_cfn, ws + o_tilefn, tpw_dp);
         hipLaunchKernelGGL(sfd_tiles, grid_b, dim3(DEC_THREADS), lds_tiles, st, dblk, R, (const u8 *)(ws + o_tilefn),
