@@ -27,7 +27,9 @@
 #include "common.hpp"
 #include "internal.hpp"
 
+#include <atomic>
 #include <mutex>
+#include <thread>
 
 #include <algorithm>
 
@@ -2152,9 +2154,32 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     bool pair_all = true;
     bool c16_all = true;
     bool c32_all = true;
-    for (int b = 0; b < nblocks; ++b) {
+    for (int b = 0; b < nblocks; ++b)
         if ((h_in_off[b] & 15) || (h_out_off[b] & 15)) return SHAFA_OUTSIDE_MODULE;
-        build_host_tab(h_tables[b], tabs[b]);
+    {   // The tables of a launch are prepared by a few helper threads next to the caller: 10 us a table (prefix check and
+        // trie, four look-up tables) is 2 ms for 128 blocks — hidden behind the kernels of 64 MiB blocks, but twice the
+        // kernels' time for 8 MiB blocks of compressible data.  Blocks are handed out by a counter, so the launch does
+        // not depend on how many helpers could be started.
+        std::atomic<int> next{0};
+        auto work = [&]() {
+            for (;;) {
+                const int b = next.fetch_add(1, std::memory_order_relaxed);
+                if (b >= nblocks) break;
+                build_host_tab(h_tables[b], tabs[b]);
+            }
+        };
+        int helpers = nblocks / 16;                        // a helper is worth starting for sixteen tables or more
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (helpers > 7) helpers = 7;
+        if (hw > 0 && helpers > hw - 1) helpers = hw - 1;
+        std::vector<std::thread> th;
+        for (int i = 0; i < helpers; ++i) {
+            try { th.emplace_back(work); } catch (...) { break; }
+        }
+        work();
+        for (auto &t : th) t.join();
+    }
+    for (int b = 0; b < nblocks; ++b) {
         HostTab &h = tabs[b];
         bool run = h_n_symbols[b] > 0;
         if (run && (!h.ok || h.empty)) {          // malformed table, or single-symbol block
