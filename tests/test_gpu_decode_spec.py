@@ -165,3 +165,51 @@ def test_spec_long_codes(oracle, shafa, modes):
         lm = oracle.sf_build(oracle.hist256(b)).lens().max()
         assert 16 < lm <= 32, lm
     check(shafa, oracle, deep, modes, out_shift=32)
+
+
+def test_many_blocks_with_malformed_tables_among_them(oracle, shafa, modes):
+    """A launch of 48 blocks with 48 different tables (the launcher prepares them on helper threads, sf_decode.hip) of
+    which two are not prefix-free: those two blocks — and only those — report FILE_UNRECOGNIZABLE, the others decode."""
+    import torch
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    blocks = [zipfmod(oracle, 900 + i, 8192 * (1 + i % 4) + 7 * i) for i in range(48)]
+    tables = [oracle.sf_build(oracle.hist256(b)) for b in blocks]
+    enc = [oracle.sf_encode(b, t)[1] for b, t in zip(blocks, tables)]
+    stabs = [to_shafa_table(shafa, t) for t in tables]
+    broken = (5, 33)
+    for i in broken:                                        # symbol b takes symbol a's code: a duplicate, not prefix-free
+        used = [s for s in range(256) if stabs[i].len[s]]
+        a, b = used[0], used[1]
+        stabs[i].len[b] = stabs[i].len[a]
+        for q in range(32):
+            stabs[i].bits[b][q] = stabs[i].bits[a][q]
+    off, pos = [], 0
+    for e in enc:
+        off.append(pos)
+        pos += (e.size + 15) // 16 * 16
+    host = np.zeros(pos, dtype=np.uint8)
+    for o, e in zip(off, enc):
+        host[o:o + e.size] = e
+    d_in = torch.from_numpy(host).to(dev)
+    ooff, opos = [], 0
+    for b in blocks:
+        ooff.append(opos)
+        opos += (b.size + 15) // 16 * 16 + 48
+    d_out = torch.full((opos + 64,), 0xEE, dtype=torch.uint8, device=dev)
+    for mode in modes:
+        shafa.set_option("sf_decode_speculate", mode)
+        d_out.fill_(0xEE)
+        bt = shafa.Batch(len(blocks), max(e.size for e in enc))
+        torch.cuda.synchronize()
+        bt.sf_decode(st, d_in, off, [e.size for e in enc], stabs, [b.size for b in blocks], d_out, ooff)
+        rc, errs = bt.finish(st, len(blocks), raise_on_error=False)
+        out = d_out.cpu().numpy()
+        bt.close()
+        for i, b in enumerate(blocks):
+            if i in broken:
+                assert errs[i] == shafa.FILE_UNRECOGNIZABLE, (mode, i, errs[i])
+                assert (out[ooff[i]:ooff[i] + b.size] == 0xEE).all(), f"mode {mode}: block {i} has no valid table and was written"
+            else:
+                assert errs[i] == 0, (mode, i, errs[i])
+                assert out[ooff[i]:ooff[i] + b.size].tobytes() == b.tobytes(), f"mode {mode} block {i}: {first_diff(out[ooff[i]:ooff[i] + b.size], b)}"
