@@ -1595,14 +1595,17 @@ constexpr int WS_MISC = 32;
 template <int LONG, bool ESC>
 __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restrict__ blks, const u8 *__restrict__ chunk_entry,
                                                           const u16 *__restrict__ chunk_cnt, const u64 *__restrict__ tile_off,
-                                                          u32 tpw, u32 tab_bytes, u32 cap)
+                                                          u32 tpw, u32 tab_bytes, u32 cap, u32 long_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const DecBlk blk = blks[blockIdx.y];
     const u32 first_tile = blockIdx.x * tpw;
     if (first_tile >= blk.n_tiles) return;
     if (tile_off[(size_t)blk.tile_base + first_tile] >= blk.n_sym) return;   // all padding / past the end
-    constexpr u32 LONGB = LONG == 1 ? LONG_BYTES : LONG == 2 ? LONG32_BYTES : 0;
+    // LONG == 1: the table of the 13..16-bit codes is kept up to the launch's largest group count only (`long_bytes` = header
+    // + prefixes + that many groups: a few hundred bytes for a real file's rare symbols, 4.3 KB in full — the difference
+    // decides whether four workgroups share a CU or two)
+    const u32 LONGB = LONG == 1 ? long_bytes : LONG == 2 ? (u32)LONG32_BYTES : 0u;
     u32 *rows = (u32 *)(smem + 16);
     const u32 tab_off = WS_ROWS_BYTES;
     const u16 *lt = (const u16 *)(smem + tab_off + tab_bytes);
@@ -2447,8 +2450,15 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         if (c > ws_cap) ws_cap = (u32)(c > 40960 ? 40960 : c);
         if (t > ws_tight) ws_tight = (u32)(t > 40960 ? 40960 : t);
     }
+    u32 long_used = 0;                                 // bytes of the 13..16-bit codes' table that the launch's blocks fill
+    if (long_all) {
+        u32 gmax = 0;
+        for (int b = 0; b < nblocks; ++b)
+            if (ntiles[b] && !tabs[b].longtab.empty() && tabs[b].longtab[0] > gmax) gmax = tabs[b].longtab[0];
+        long_used = (16u + (u32)LONG_PFX * 2u + gmax * 32u + 15u) & ~15u;
+    }
     {
-        const u32 longb = mid32 ? (u32)LONG32_BYTES : long_all ? (u32)LONG_BYTES : 0u;
+        const u32 longb = mid32 ? (u32)LONG32_BYTES : long_all ? long_used : 0u;
         const u32 base = (u32)WS_ROWS_BYTES + ws_tab + longb + (u32)WS_MISC;
         const u32 most = 65536u - base;                                           // 64 KiB of dynamic LDS
         if (ws_cap > most) ws_cap = most;
@@ -2469,18 +2479,18 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const dim3 grid_ws((u32)ceil_div_u64(max_tiles, tpw_ws), (u32)nblocks);
     if (mid32) {
         hipLaunchKernelGGL((sfd_wstage<2, true>), grid_ws, dim3(DEC_THREADS), lds_ws + LONG32_BYTES, st, dblk,
-                           (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap);
+                           (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap, 0u);
     } else if (fast13) {
         if (multi && long_all)
-            hipLaunchKernelGGL((sfd_wstage<1, true>), grid_ws, dim3(DEC_THREADS), lds_ws + LONG_BYTES, st, dblk,
-                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap);
+            hipLaunchKernelGGL((sfd_wstage<1, true>), grid_ws, dim3(DEC_THREADS), lds_ws + long_used, st, dblk,
+                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap, long_used);
         else if (multi)
             if (lmax_all > (u32)SYM3_MAXK)
                 hipLaunchKernelGGL((sfd_wstage<0, true>), grid_ws, dim3(DEC_THREADS), lds_ws, st, dblk,
-                                   (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap);
+                                   (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap, 0u);
             else
                 hipLaunchKernelGGL((sfd_wstage<0, false>), grid_ws, dim3(DEC_THREADS), lds_ws, st, dblk,
-                                   (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap);
+                                   (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap, 0u);
         else
             hipLaunchKernelGGL((sfd_write13<WSUBS>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
                                (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw);

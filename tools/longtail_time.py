@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """SF encode/decode of a block with a realistic long tail (a few bytes that occur 1..1000 times in 64 MiB: Lmax ~ 20-26):
-the generic decode path.  usage: longtail_time.py [blocks=8]"""
+the generic decode path.  usage: longtail_time.py [blocks=8] [least occurrences of a rare symbol=1]
+(1: codes of 20-26 bits; 1500: codes of up to 15-16 bits, the 13..16-bit tables)"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,6 +9,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import pkgload
 pkg = pkgload.load()
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+mincnt = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 bs = 64 << 20
 dev = torch.device("cuda", 0); pkg.lib().shafa_hip_init(0); st = torch.cuda.Stream(device=dev)
 zt = pkg.zipf_table(1.2)
@@ -19,7 +21,7 @@ torch.cuda.synchronize()
 g = torch.Generator(device=dev); g.manual_seed(5)
 for b in range(nb):
     for k, sym in enumerate(range(200, 256)):                        # 56 rare symbols: 1 .. ~3000 occurrences per block
-        cnt = 1 + (k * k * k) // 60
+        cnt = mincnt + (k * k * k) // 60
         pos = torch.randint(0, bs, (cnt,), device=dev, generator=g) + b * bs
         d_in[pos] = sym
 bt = pkg.Batch(nb, bs)
