@@ -82,6 +82,7 @@ struct DecBlk {
     u32 n_tiles;
     u32 n_l2;              // level-2 entries
     u32 n_states;          // internal trie nodes = states of the counting automaton (<= 255 for a complete code)
+    u32 KW;                // window of sfd_spec's counting tables (spec_window(K1), or 12 for 13-bit tables whose 13-bit codes are few)
     u32 *fsm4;             // [state][nibble]: next state * 64 | codes completed << 16   (complete codes; sfd_tables)
     u32 *fsm1;             // [state][bit]   : same, for one bit
     const u8 *lenlut32;    // 2^13 entries: len <= 13, or 128 + k = internal node root13[k] of long32 (16 < Lmax <= 32 launches)
@@ -408,11 +409,12 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
     for (u32 i = T0; blk.pairlut && i < (2u << K1); i += TS)
         blk.pairlut[i] = (u8)((blk.lenlut[i >> 1] - 1u) | ((blk.lenlut[i & mask] - 1u) << 4));
     const u32 K3 = sym3_window(K1);
-    const u32 KW = spec_window(K1), maskw = (1u << KW) - 1;      // the counting window may be wider than the longest code
-    for (u32 i = T0; i <= maskw; i += TS) {
+    const u32 KW = blk.KW, maskw = (1u << KW) - 1;               // the counting window may be wider than the longest code, or
+    for (u32 i = T0; i <= maskw; i += TS) {                      // one bit narrower than the 13-bit table (host: sfdec_launch)
         u32 pos = 0, n = 0, l0 = 0;
         for (; n < 15; ++n) {
-            const u32 L = blk.lut13[((i << pos) & maskw) >> (KW - K1)] >> 8;      // window shifted left, zero filled
+            const u32 wv = (i << pos) & maskw;                   // window shifted left, zero filled
+            const u32 L = blk.lut13[KW >= K1 ? wv >> (KW - K1) : wv << (K1 - KW)] >> 8;
             if (L == 0 || L > KW - pos) break;                   // longer than the window / would use bits outside it
             if (n == 0) l0 = L;
             pos += L;
@@ -1314,7 +1316,7 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
     const u32 tab_off = SPEC_LDS_DATA;
     u8 *ex = smem + SPEC_LDS_DATA + tab_bytes;
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 K1 = spec_window(blk.K1);                 // the counting table's window
+    const u32 K1 = blk.KW;                              // the counting table's window
     fill_lds16((void *)(smem + tab_off), (const void *)blk.cnt3, 2u << K1);
     const u16 *lt = (const u16 *)(smem + SPEC_LDS_DATA + tab_bytes + DEC_THREADS + 16 + 32);
     if (LONG) {
@@ -2244,6 +2246,21 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     // (long_all and mid32 launches too: a code of more than 13 bits is an escape inside the walk)
     const bool spec_path = ((packed && fast13 && multi) || mid32) && g_sfd_speculate != 0;
     const int spec_long = mid32 ? 2 : long_all ? 1 : 0;
+    // window of sfd_spec's counting tables.  A 13-bit table in a launch with the table of long codes (which holds every code
+    // of more than 12 bits, by 12-bit prefix) may count with 12-bit windows: the 13-bit codes become escapes like the 14..16-
+    // bit ones, 8 KB of tables instead of 16 fit six workgroups on a CU instead of four.  Worth it while the
+    // 13-bit codes are few (an escape is a binary search that the whole wave waits for): at most eight of them, 0.1 % of the
+    // symbols of a block coded near its entropy.
+    std::vector<u32> hblk_kw(nblocks, 0);
+    for (int b = 0; b < nblocks; ++b) {
+        if (!ntiles[b]) continue;
+        hblk_kw[b] = spec_window(tabs[b].K1);
+        if (spec_long == 1 && tabs[b].K1 == 13) {
+            u32 n13 = 0;
+            for (int sy = 0; sy < 256; ++sy) n13 += h_tables[b].len[sy] == 13;
+            if (n13 <= 8) hblk_kw[b] = 12;
+        }
+    }
     std::vector<char> spec_blk(nblocks, 0);
     bool any_spec = false;
     for (int b = 0; spec_path && b < nblocks; ++b)
@@ -2282,6 +2299,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         HostTab &h = tabs[b];
         e.K = h.K;
         e.K1 = h.K1;
+        e.KW = hblk_kw[b];
         e.lmax = h.lmax;
         e.n_states = (u32)(h.trie.size() / 2);
         e.lut2 = (const u16 *)(ws + tpos);
@@ -2344,7 +2362,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     auto launch_spec = [&]() {
         u8 *tg = ws + o_tguess, *tx = ws + o_texit, *tf = ws + o_tfix;
         u32 k1_max = 1;
-        for (int b = 0; b < nblocks; ++b) if (spec_blk[b] && spec_window(tabs[b].K1) > k1_max) k1_max = spec_window(tabs[b].K1);
+        for (int b = 0; b < nblocks; ++b) if (spec_blk[b] && hblk_kw[b] > k1_max) k1_max = hblk_kw[b];
         const u32 tabb = 2u << k1_max;
         const size_t lds_spec = (size_t)SPEC_LDS_DATA + tabb + DEC_THREADS + 16 + 32 +
                                 (spec_long == 2 ? (size_t)((LONG32_BYTES + 15) & ~15) : spec_long == 1 ? (size_t)LONG_BYTES : 0);
