@@ -1308,7 +1308,7 @@ template <bool FIX, int LONG>
 __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u32 tile0, u8 *__restrict__ chunk_entry,
                                             u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt,
                                             u8 *__restrict__ tile_guess, u8 *__restrict__ tile_exit,
-                                            const u8 *__restrict__ tile_fix, u32 tab_bytes)
+                                            const u8 *__restrict__ tile_fix, u32 tab_bytes, u32 long_bytes)
 {
     const size_t gt0 = (size_t)blk.tile_base + tile0;
     const u32 ntl = blk.n_tiles - tile0 < (u32)SPEC_TILES ? blk.n_tiles - tile0 : (u32)SPEC_TILES;   // tiles of the region
@@ -1321,7 +1321,7 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
     const u16 *lt = (const u16 *)(smem + SPEC_LDS_DATA + tab_bytes + DEC_THREADS + 16 + 32);
     if (LONG) {
         const u16 *src = LONG == 1 ? blk.longtab : blk.long32;
-        if (src) fill_lds16((void *)lt, src, LONG == 1 ? LONG_BYTES : LONG32_BYTES);
+        if (src) fill_lds16((void *)lt, src, LONG == 1 ? long_bytes : (u32)LONG32_BYTES);     // LONG == 1: up to the launch's largest group count, as sfd_wstage
         else if (threadIdx.x == 0) *(u16 *)lt = 0;
     }
     {   // the region's stream from one strip before it, 16 bytes a lane; frame word f -> LDS word f + f / SPEC_SW.
@@ -1452,14 +1452,14 @@ template <bool FIX, int LONG>
 __global__ __launch_bounds__(DEC_THREADS) void sfd_spec(const DecBlk *__restrict__ blks, u8 *__restrict__ chunk_entry,
                                                         u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt,
                                                         u8 *__restrict__ tile_guess, u8 *__restrict__ tile_exit,
-                                                        const u8 *__restrict__ tile_fix, u32 tab_bytes)
+                                                        const u8 *__restrict__ tile_fix, u32 tab_bytes, u32 long_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const DecBlk blk = blks[blockIdx.y];
     if (!blk.run_dp || __hip_atomic_load(blk.run_dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // exact path
     if (!FIX) {
         const u32 tile0 = blockIdx.x * SPEC_TILES;      // first tile of this workgroup's region
-        if (tile0 < blk.n_tiles) spec_region<false, LONG>(smem, blk, tile0, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tile_fix, tab_bytes);
+        if (tile0 < blk.n_tiles) spec_region<false, LONG>(smem, blk, tile0, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tile_fix, tab_bytes, long_bytes);
         return;
     }
     // repair launch: a workgroup looks at the flags of SPEC_FIX_REGIONS regions and redoes the few that are marked
@@ -1476,7 +1476,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_spec(const DecBlk *__restrict
         for (u32 q = 0; q < SPEC_TILES && tile0 + q < blk.n_tiles; ++q) any |= tile_fix[(size_t)blk.tile_base + tile0 + q] != 0;
         if (!any) continue;                             // uniform
         __syncthreads();                                // the region before is done with the LDS
-        spec_region<true, LONG>(smem, blk, tile0, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tile_fix, tab_bytes);
+        spec_region<true, LONG>(smem, blk, tile0, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tile_fix, tab_bytes, long_bytes);
     }
 }
 
@@ -2261,6 +2261,13 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
             if (n13 <= 8) hblk_kw[b] = 12;
         }
     }
+    u32 long_used = 0;                                 // bytes of the 13..16-bit codes' table that the launch's blocks fill
+    if (long_all) {
+        u32 gmax = 0;
+        for (int b = 0; b < nblocks; ++b)
+            if (ntiles[b] && !tabs[b].longtab.empty() && tabs[b].longtab[0] > gmax) gmax = tabs[b].longtab[0];
+        long_used = (16u + (u32)LONG_PFX * 2u + gmax * 32u + 15u) & ~15u;
+    }
     std::vector<char> spec_blk(nblocks, 0);
     bool any_spec = false;
     for (int b = 0; spec_path && b < nblocks; ++b)
@@ -2365,20 +2372,20 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         for (int b = 0; b < nblocks; ++b) if (spec_blk[b] && hblk_kw[b] > k1_max) k1_max = hblk_kw[b];
         const u32 tabb = 2u << k1_max;
         const size_t lds_spec = (size_t)SPEC_LDS_DATA + tabb + DEC_THREADS + 16 + 32 +
-                                (spec_long == 2 ? (size_t)((LONG32_BYTES + 15) & ~15) : spec_long == 1 ? (size_t)LONG_BYTES : 0);
+                                (spec_long == 2 ? (size_t)((LONG32_BYTES + 15) & ~15) : spec_long == 1 ? (size_t)long_used : 0);
         const dim3 grid_s((u32)ceil_div_u64(max_tiles, SPEC_TILES), (u32)nblocks);
         const dim3 grid_sf((u32)ceil_div_u64(max_tiles, SPEC_TILES * SPEC_FIX_REGIONS), (u32)nblocks);
         auto spec = [&](auto fix, const dim3 grid) {
             constexpr bool FIX = decltype(fix)::value;
             if (spec_long == 2)
                 hipLaunchKernelGGL((sfd_spec<FIX, 2>), grid, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
-                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb);
+                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb, long_used);
             else if (spec_long == 1)
                 hipLaunchKernelGGL((sfd_spec<FIX, 1>), grid, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
-                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb);
+                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb, long_used);
             else
                 hipLaunchKernelGGL((sfd_spec<FIX, 0>), grid, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
-                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb);
+                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb, long_used);
         };
         spec(std::false_type{}, grid_s);
         for (int round = 0; round < 2; ++round) {
@@ -2467,13 +2474,6 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         const u64 c = per_tile + per_tile / 8 + 1024, t = per_tile + per_tile / 32 + 256;
         if (c > ws_cap) ws_cap = (u32)(c > 40960 ? 40960 : c);
         if (t > ws_tight) ws_tight = (u32)(t > 40960 ? 40960 : t);
-    }
-    u32 long_used = 0;                                 // bytes of the 13..16-bit codes' table that the launch's blocks fill
-    if (long_all) {
-        u32 gmax = 0;
-        for (int b = 0; b < nblocks; ++b)
-            if (ntiles[b] && !tabs[b].longtab.empty() && tabs[b].longtab[0] > gmax) gmax = tabs[b].longtab[0];
-        long_used = (16u + (u32)LONG_PFX * 2u + gmax * 32u + 15u) & ~15u;
     }
     {
         const u32 longb = mid32 ? (u32)LONG32_BYTES : long_all ? long_used : 0u;
