@@ -1321,7 +1321,7 @@ __device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u
     const u16 *lt = (const u16 *)(smem + SPEC_LDS_DATA + tab_bytes + DEC_THREADS + 16 + 32);
     if (LONG) {
         const u16 *src = LONG == 1 ? blk.longtab : blk.long32;
-        if (src) fill_lds16((void *)lt, src, LONG == 1 ? long_bytes : (u32)LONG32_BYTES);     // LONG == 1: up to the launch's largest group count, as sfd_wstage
+        if (src) fill_lds16((void *)lt, src, long_bytes);                                     // up to what the launch's blocks use, as sfd_wstage
         else if (threadIdx.x == 0) *(u16 *)lt = 0;
     }
     {   // the region's stream from one strip before it, 16 bytes a lane; frame word f -> LDS word f + f / SPEC_SW.
@@ -1607,7 +1607,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
     // LONG == 1: the table of the 13..16-bit codes is kept up to the launch's largest group count only (`long_bytes` = header
     // + prefixes + that many groups: a few hundred bytes for a real file's rare symbols, 4.3 KB in full — the difference
     // decides whether four workgroups share a CU or two)
-    const u32 LONGB = LONG == 1 ? long_bytes : LONG == 2 ? (u32)LONG32_BYTES : 0u;
+    const u32 LONGB = LONG ? long_bytes : 0u;           // (LONG == 2: header, prefixes, roots and the sub-trie nodes in use)
     u32 *rows = (u32 *)(smem + 16);
     const u32 tab_off = WS_ROWS_BYTES;
     const u16 *lt = (const u16 *)(smem + tab_off + tab_bytes);
@@ -2002,6 +2002,7 @@ void build_host_tab(const shafa_code_table &t, HostTab &h)
         if (order.size() > 256) h.complete32 = false;
         if (h.complete32) {
             h.long32[0] = (u16)roots.size();
+            h.long32[1] = (u16)order.size();               // sub-trie nodes in use (the passes that walk them keep only those in LDS)
             for (size_t g = 0; g < roots.size(); ++g) {
                 h.long32[8 + g] = (u16)roots[g].key;
                 h.long32[8 + LONG_PFX + g] = (u16)newid[roots[g].node];
@@ -2255,7 +2256,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     for (int b = 0; b < nblocks; ++b) {
         if (!ntiles[b]) continue;
         hblk_kw[b] = spec_window(tabs[b].K1);
-        if (spec_long == 1 && tabs[b].K1 == 13) {
+        if (spec_long && tabs[b].K1 == 13) {
             u32 n13 = 0;
             for (int sy = 0; sy < 256; ++sy) n13 += h_tables[b].len[sy] == 13;
             if (n13 <= 8) hblk_kw[b] = 12;
@@ -2267,6 +2268,11 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         for (int b = 0; b < nblocks; ++b)
             if (ntiles[b] && !tabs[b].longtab.empty() && tabs[b].longtab[0] > gmax) gmax = tabs[b].longtab[0];
         long_used = (16u + (u32)LONG_PFX * 2u + gmax * 32u + 15u) & ~15u;
+    } else if (mid32) {                                // header, prefixes, roots, the sub-trie nodes in use (not the DP's root13)
+        u32 nmax = 0;
+        for (int b = 0; b < nblocks; ++b)
+            if (ntiles[b] && !tabs[b].long32.empty() && tabs[b].long32[1] > nmax) nmax = tabs[b].long32[1];
+        long_used = (16u + (u32)LONG_PFX * 4u + nmax * 4u + 15u) & ~15u;
     }
     std::vector<char> spec_blk(nblocks, 0);
     bool any_spec = false;
@@ -2372,7 +2378,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         for (int b = 0; b < nblocks; ++b) if (spec_blk[b] && hblk_kw[b] > k1_max) k1_max = hblk_kw[b];
         const u32 tabb = 2u << k1_max;
         const size_t lds_spec = (size_t)SPEC_LDS_DATA + tabb + DEC_THREADS + 16 + 32 +
-                                (spec_long == 2 ? (size_t)((LONG32_BYTES + 15) & ~15) : spec_long == 1 ? (size_t)long_used : 0);
+                                (spec_long ? (size_t)long_used : 0);
         const dim3 grid_s((u32)ceil_div_u64(max_tiles, SPEC_TILES), (u32)nblocks);
         const dim3 grid_sf((u32)ceil_div_u64(max_tiles, SPEC_TILES * SPEC_FIX_REGIONS), (u32)nblocks);
         auto spec = [&](auto fix, const dim3 grid) {
@@ -2476,7 +2482,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         if (t > ws_tight) ws_tight = (u32)(t > 40960 ? 40960 : t);
     }
     {
-        const u32 longb = mid32 ? (u32)LONG32_BYTES : long_all ? long_used : 0u;
+        const u32 longb = long_used;
         const u32 base = (u32)WS_ROWS_BYTES + ws_tab + longb + (u32)WS_MISC;
         const u32 most = 65536u - base;                                           // 64 KiB of dynamic LDS
         if (ws_cap > most) ws_cap = most;
@@ -2496,8 +2502,8 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     while (tpw_ws > 1 && (u64)ceil_div_u64(max_tiles, tpw_ws) * nblocks < 2048) tpw_ws >>= 1;
     const dim3 grid_ws((u32)ceil_div_u64(max_tiles, tpw_ws), (u32)nblocks);
     if (mid32) {
-        hipLaunchKernelGGL((sfd_wstage<2, true>), grid_ws, dim3(DEC_THREADS), lds_ws + LONG32_BYTES, st, dblk,
-                           (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap, 0u);
+        hipLaunchKernelGGL((sfd_wstage<2, true>), grid_ws, dim3(DEC_THREADS), lds_ws + long_used, st, dblk,
+                           (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap, long_used);
     } else if (fast13) {
         if (multi && long_all)
             hipLaunchKernelGGL((sfd_wstage<1, true>), grid_ws, dim3(DEC_THREADS), lds_ws + long_used, st, dblk,
