@@ -459,7 +459,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_sync16(const DecBlk *__restri
 {
     // static LDS: constant addresses fold into the ds_read offset field (no per-lookup address add)
     // (the chunk maps of a wave live in that wave's own rows of the stream frame, which it is done with by then: with a
-    // separate 2 KiB for them the pair-table form is 27.8 KB, just above the 26.7 KB that let six workgroups share a CU)
+    // separate 2 KiB for them the pair-table form is 27.8 KB, just above the 26 KiB that let six workgroups share a CU)
     __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + (PAIR ? 2 : 1) * (1 << LEN_MAXK) + 64 + (LONG ? LONG_BYTES : 0)];
     if (dp_skipped_early(blks + blockIdx.y)) return;
     const DecBlk blk = blks[blockIdx.y];
@@ -2471,7 +2471,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     // image: the densest block's average symbols per tile + 1/8 + 1 KiB, 4 .. 40 KiB — unless a smaller margin (1/32 +
     // 256 bytes; a tile that exceeds the image goes in rounds) lets more workgroups share a CU: the symbol pass loses time
     // almost in proportion to the waves it loses, and a CU's LDS is handed out as two halves of 80 KiB (8 workgroups up to
-    // 20 KiB each, 6 up to 26.7, 4 up to 40, 2 above: DESIGN.md §3.2).  Codes of up to 12 bits on run-heavy data: 41.7 KB
+    // 20 KiB each, 6 up to 26.25, 4 up to 40, 2 above: DESIGN.md §3.2).  Codes of up to 12 bits on run-heavy data: 41.7 KB
     // with the wide margin = 2 workgroups per CU, 40 KB with the narrow one = 4.
     u32 ws_cap = 4096, ws_tight = 4096;
     for (int b = 0; b < nblocks; ++b) {
@@ -2486,11 +2486,13 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         const u32 base = (u32)WS_ROWS_BYTES + ws_tab + longb + (u32)WS_MISC;
         const u32 most = 65536u - base;                                           // 64 KiB of dynamic LDS
         if (ws_cap > most) ws_cap = most;
-        constexpr u32 steps[3] = {20480u, 27306u, 40960u};                        // 8, 6, 4 workgroups per CU
+        constexpr u32 steps[3] = {20480u, 26880u, 40960u};                        // 8, 6, 4 workgroups per CU as launches show them
+                                                                                  //   (tools/ubench/occ_lds.hip: 27136 bytes are 5 already)
         for (u32 k = 0; k < 3; ++k) {
             if (base + ((ws_tight + 15u) & ~15u) <= steps[k]) {                   // this step is within reach of the narrow margin:
-                if (base + ws_cap > steps[k]) ws_cap = steps[k] - base;           //   the margin is what the step leaves
-                break;
+                ws_cap = steps[k] - base;                                         //   the image gets all that the step leaves
+                if (ws_cap > most) ws_cap = most;                                 //   (more than the wide margin costs nothing:
+                break;                                                            //   zeroed once, stored as far as it is used)
             }
         }
     }
