@@ -72,6 +72,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-sample-blocks", type=int, default=16)
     ap.add_argument("--encode-only", action="store_true")
+    ap.add_argument("--no-tiles", action="store_true",
+                    help="Module C without Module F's tile histograms: the chained one-pass encoder (sf_encode4.hip) instead of the "
+                         "one-shot grid (sf_encode6.hip); the default line reports it beside the headline as `encode_chained`")
     ap.add_argument("--scatter-gather", action="store_true",
                     help="time X1 (root scatters whole blocks) + encode + X2 (root gathers the payloads) also at N=1")
     ap.add_argument("--no-scatter-gather", action="store_true", help="skip the X1/X2 leg at N>1")
@@ -434,8 +437,17 @@ def main():
     in_off = np.arange(nb, dtype=np.uint64) * np.uint64(bs)       # host arrays once, not per call: at -b m the launcher's
     in_n = np.full(nb, bs, dtype=np.uint64)                        # host time is of the order of the kernels' time
     d_freq = torch.zeros(nb * 256, dtype=torch.int64, device=dev)
+    # Module F's products, prepared before the timed region like the .freq / .cod files: the block histograms and (unless
+    # --no-tiles) the histogram of every 32 KiB tile, which depends on the data only (include/shafa_hip.h "Tile histograms")
+    use_tiles = not args.no_tiles
+    thb = pkg.tile_hist_bytes(bs)
+    th_off = np.arange(nb, dtype=np.uint64) * np.uint64(thb)
+    d_th = torch.zeros(nb * thb if use_tiles else 16, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()              # torch's fills run on its own stream: finish them before ours starts
-    bt.hist256(st, d_in, in_off, in_n, d_freq)
+    if use_tiles:
+        bt.hist256_tiles(st, d_in, in_off, in_n, d_freq, d_th, th_off)
+    else:
+        bt.hist256(st, d_in, in_off, in_n, d_freq)
     bt.finish(st, nb)
     freq = d_freq.cpu().numpy().astype(np.uint64).reshape(nb, 256)
     tables = bt._tables([pkg.sf_build_codes(freq[b]) for b in range(nb)])     # Module T, host
@@ -453,8 +465,13 @@ def main():
 
     have_decode = not args.encode_only
 
-    def encode():
+    def encode_chained():
         bt.sf_encode(st, d_in, in_off, in_n, tables, d_enc, out_off, out_cap, d_enc_n)
+
+    def encode_tiles():
+        bt.sf_encode_tiles(st, d_in, in_off, in_n, tables, d_th, th_off, d_enc, out_off, out_cap, d_enc_n)
+
+    encode = encode_tiles if use_tiles else encode_chained
 
     def decode():
         bt.sf_decode(st, d_enc, out_off, enc_bytes, tables, in_n, d_dec, in_off)
@@ -477,6 +494,27 @@ def main():
         t = pkg.CodeTable()
         C.memmove(C.byref(t), C.byref(otab), C.sizeof(t))
         assert pkg.sf_encode(blk, t).tobytes() == want.tobytes(), "HIP encode differs from oracle"
+
+    # the other encoder on the same blocks: same bytes (and its time, for the line)
+    chained = None
+    if use_tiles:
+        ref_enc = d_enc.clone()
+        d_enc.zero_()
+        encode_chained()
+        bt.finish(st, nb)
+        for b in range(nb):
+            o, m = int(out_off[b]), int(enc_bytes[b])
+            assert torch.equal(d_enc[o:o + m], ref_enc[o:o + m]), f"tile path and chained encoder differ in block {b}"
+        del ref_enc
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(3):
+            encode_chained()
+        e1.record(st)
+        bt.finish(st, nb)
+        chained = e0.elapsed_time(e1) / 3 * 1e-3
+        encode()
+        bt.finish(st, nb)
 
     def step():
         encode()
@@ -631,7 +669,13 @@ def main():
             "roofline_decode": ({"bound": "hbm", "achieved": dec_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": dec_gbs / HBM_PEAK_GBS, "traffic": traffic["sf_decode"],
                                  "algorithmic_bytes_per_launch": alg} if have_decode else None),
+            "encode_path": ("tile histograms from Module F (prepared once, like the .cod tables) -> tile offsets (dot + scan, "
+                            "inside the timed encode) -> one-shot grid sf_encode6" if use_tiles
+                            else "chained one-pass encoder sf_encode4 (no tile histograms)"),
         }
+        if chained:
+            out["encode_chained"] = {"ms": chained * 1e3, "frac": alg / chained / 1e9 / HBM_PEAK_GBS,
+                                     "what": "the same blocks through shafa_hipd_sf_encode (no tile histograms): sf_encode4's chained scan"}
         out["per_rank"] = per_rank
         if comm.oversubscribed:
             out["invalid"] = "oversubscribed: ranks share GPUs (plumbing test only)"

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SHAFA_HIP_ABI_VERSION 4
+#define SHAFA_HIP_ABI_VERSION 5
 
 /* utils/errors.h:5-16 (_modules_error), same numbers */
 enum shafa_error {
@@ -164,6 +164,38 @@ int shafa_hipd_sf_encode(shafa_hipd_batch *b, void *stream, int nblocks, const u
                          const uint64_t *h_in_off, const uint64_t *h_in_n,
                          const shafa_code_table *h_tables, uint8_t *d_out, const uint64_t *h_out_off,
                          const uint64_t *h_out_cap, uint64_t *d_out_n);
+
+/* ---- Tile histograms: Module F's by-product that lets Module C run without any tile waiting for another ----------------
+ * The reference's F -> T -> C sequence reads a block three times: make_freq (f.c:63-79), then — with the codes of Module T —
+ * binary_coding (c.c:52-83), whose output position of byte i depends on the code lengths of all bytes before it.  A caller
+ * that keeps a block resident in HBM between F and C can hand C what F already saw: the histogram of every
+ * SHAFA_TILE_BYTES (32 KiB) tile of the block, 256 x uint16_t per tile (a tile holds at most 32768 of one byte value),
+ * shafa_hip_tile_hist_bytes(n) bytes for a block of n bytes, tile t's counts at offset 512 t.  With them the bit offset of
+ * every tile in the encoded block is (tile histograms . code lengths), scanned — known BEFORE the encoder starts — and the
+ * encoder is a one-shot grid of independent workgroups (sf_encode6.hip) instead of a chained scan.  The histograms depend
+ * on the data only, not on the codes.  Block b's tile histograms live at d_tile_hist + h_tile_hist_off[b] (offsets
+ * multiples of 16).  Results are identical to the entry points without `_tiles`; histograms that are not the block's own
+ * are detected (SHAFA_OUTSIDE_MODULE for the block, nothing is written outside its output region). */
+#define SHAFA_TILE_BYTES 32768
+size_t shafa_hip_tile_hist_bytes(size_t n);
+
+/* make_freq per block as shafa_hipd_hist256, plus the tile histograms. */
+int shafa_hipd_hist256_tiles(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
+                             const uint64_t *h_in_off, const uint64_t *h_in_n, uint64_t *d_freq,
+                             uint8_t *d_tile_hist, const uint64_t *h_tile_hist_off);
+
+/* block_compression + make_freq of the RLE bytes as shafa_hipd_rle_encode (d_freq required), plus the tile histograms of
+ * the RLE bytes: block b's region must hold shafa_hip_tile_hist_bytes(h_out_cap[b]) bytes. */
+int shafa_hipd_rle_encode_tiles(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
+                                const uint64_t *h_in_off, const uint64_t *h_in_n, uint8_t *d_out,
+                                const uint64_t *h_out_off, const uint64_t *h_out_cap, uint64_t *d_out_n,
+                                uint64_t *d_freq, uint8_t *d_tile_hist, const uint64_t *h_tile_hist_off);
+
+/* binary_coding per block as shafa_hipd_sf_encode, given the tile histograms of the input blocks. */
+int shafa_hipd_sf_encode_tiles(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
+                               const uint64_t *h_in_off, const uint64_t *h_in_n, const shafa_code_table *h_tables,
+                               const uint8_t *d_tile_hist, const uint64_t *h_tile_hist_off, uint8_t *d_out,
+                               const uint64_t *h_out_off, const uint64_t *h_out_cap, uint64_t *d_out_n);
 
 /* shafa_block_decompressor per block: block b decodes h_n_symbols[b] symbols from the h_in_n[b]
  * bytes at d_in + h_in_off[b] into d_out + h_out_off[b] (which must hold h_n_symbols[b] bytes). */

@@ -99,6 +99,11 @@ def lib():
     L.shafa_hipd_sf_encode.argtypes = [vp, vp, C.c_int, u8p, u64p, u64p, tp, u8p, u64p, u64p, vp]
     L.shafa_hipd_sf_decode.argtypes = [vp, vp, C.c_int, u8p, u64p, u64p, tp, u64p, u8p, u64p]
     L.shafa_hipd_rle_decode.argtypes = [vp, vp, C.c_int, u8p, u64p, u64p, u8p, u64p, u64p, vp]
+    L.shafa_hip_tile_hist_bytes.argtypes = [C.c_size_t]
+    L.shafa_hip_tile_hist_bytes.restype = C.c_size_t
+    L.shafa_hipd_hist256_tiles.argtypes = [vp, vp, C.c_int, u8p, u64p, u64p, vp, u8p, u64p]
+    L.shafa_hipd_rle_encode_tiles.argtypes = [vp, vp, C.c_int, u8p, u64p, u64p, u8p, u64p, u64p, vp, vp, u8p, u64p]
+    L.shafa_hipd_sf_encode_tiles.argtypes = [vp, vp, C.c_int, u8p, u64p, u64p, tp, u8p, u64p, u8p, u64p, u64p, vp]
     L.shafa_hipd_finish.argtypes = [vp, vp, C.c_int, C.POINTER(C.c_int)]
     L.shafa_hipd_gen_bytes.argtypes = [vp, C.c_uint64, C.c_uint64, u8p, u8p, C.c_size_t]
     L.shafa_pipe_create.argtypes = [C.c_int, C.POINTER(vp)]
@@ -120,7 +125,8 @@ def lib():
                  "shafa_hip_sf_decode", "shafa_hip_rle_decode", "shafa_hipd_batch_create",
                  "shafa_hipd_hist256", "shafa_hipd_rle_encode", "shafa_hipd_sf_encode",
                  "shafa_hipd_sf_decode", "shafa_hipd_rle_decode", "shafa_hipd_finish",
-                 "shafa_hipd_gen_bytes"):
+                 "shafa_hipd_gen_bytes", "shafa_hipd_hist256_tiles", "shafa_hipd_rle_encode_tiles",
+                 "shafa_hipd_sf_encode_tiles"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -271,6 +277,25 @@ class Batch:
                                           tarr, d_out.data_ptr(), _p64(oo), _p64(oc), d_out_n.data_ptr()),
                "hipd_sf_encode")
 
+    # ---- with tile histograms (include/shafa_hip.h: "Tile histograms"): block b's at d_thist + thist_off[b] ----
+    def hist256_tiles(self, stream, d_in, in_off, in_n, d_freq, d_thist, thist_off):
+        io, il, to = _u64arr(in_off), _u64arr(in_n), _u64arr(thist_off)
+        _check(lib().shafa_hipd_hist256_tiles(self.h, self._st(stream), len(io), d_in.data_ptr(), _p64(io), _p64(il),
+                                              d_freq.data_ptr(), d_thist.data_ptr(), _p64(to)), "hipd_hist256_tiles")
+
+    def rle_encode_tiles(self, stream, d_in, in_off, in_n, d_out, out_off, out_cap, d_out_n, d_freq, d_thist, thist_off):
+        io, il, oo, oc, to = _u64arr(in_off), _u64arr(in_n), _u64arr(out_off), _u64arr(out_cap), _u64arr(thist_off)
+        _check(lib().shafa_hipd_rle_encode_tiles(self.h, self._st(stream), len(io), d_in.data_ptr(), _p64(io), _p64(il),
+                                                 d_out.data_ptr(), _p64(oo), _p64(oc), d_out_n.data_ptr(), d_freq.data_ptr(),
+                                                 d_thist.data_ptr(), _p64(to)), "hipd_rle_encode_tiles")
+
+    def sf_encode_tiles(self, stream, d_in, in_off, in_n, tables, d_thist, thist_off, d_out, out_off, out_cap, d_out_n):
+        io, il, oo, oc, to = _u64arr(in_off), _u64arr(in_n), _u64arr(out_off), _u64arr(out_cap), _u64arr(thist_off)
+        tarr = tables if isinstance(tables, C.Array) else self._tables(tables)
+        _check(lib().shafa_hipd_sf_encode_tiles(self.h, self._st(stream), len(io), d_in.data_ptr(), _p64(io), _p64(il),
+                                                tarr, d_thist.data_ptr(), _p64(to), d_out.data_ptr(), _p64(oo), _p64(oc),
+                                                d_out_n.data_ptr()), "hipd_sf_encode_tiles")
+
     def sf_decode(self, stream, d_in, in_off, in_n, tables, n_symbols, d_out, out_off):
         io, il, oo, ns = _u64arr(in_off), _u64arr(in_n), _u64arr(out_off), _u64arr(n_symbols)
         tarr = tables if isinstance(tables, C.Array) else self._tables(tables)
@@ -327,6 +352,14 @@ class Pipe:
             _check(rc, "pipe_wait")
         out = C.string_at(r.out, r.out_n) if rc == 0 and r.out_n else b""
         return rc, out, r
+
+
+TILE_BYTES = 32768            # SHAFA_TILE_BYTES: the tile of the tile histograms
+
+
+def tile_hist_bytes(n):
+    """bytes of the tile histograms of a block of n bytes (256 x u16 per 32 KiB tile)."""
+    return int(lib().shafa_hip_tile_hist_bytes(int(n)))
 
 
 def gen_bytes(stream, seed, first_index, d_out, n, d_map=None):

@@ -178,7 +178,7 @@ int shafa_hipd_batch_create(int max_blocks, size_t max_block_bytes, shafa_hipd_b
     if (!b->h_hosterr) { free(b); return SHAFA_LACK_OF_MEMORY; }
     hipError_t e = hipMalloc((void **)&b->d_err, (size_t)max_blocks * sizeof(int));
     if (e == hipSuccess) e = hipMemset(b->d_err, 0, (size_t)max_blocks * sizeof(int));
-    if (e == hipSuccess) e = hipMalloc(&b->d_par_hist, (size_t)max_blocks * 32);
+    if (e == hipSuccess) e = hipMalloc(&b->d_par_hist, (size_t)max_blocks * 48);
     if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_err, (size_t)max_blocks * sizeof(int), hipHostMallocDefault);
     if (e != hipSuccess) {
         if (b->d_err) hipFree(b->d_err);
@@ -214,6 +214,40 @@ int shafa_hipd_hist256(shafa_hipd_batch *b, void *stream, int nblocks, const uin
 {
     if (int rc = batch_enter((Batch *)b, (hipStream_t)stream)) return rc;
     return hist_launch((Batch *)b, (hipStream_t)stream, nblocks, d_in, h_in_off, h_in_n, d_freq);
+}
+
+size_t shafa_hip_tile_hist_bytes(size_t n) { return ((n + SHAFA_TILE_BYTES - 1) / SHAFA_TILE_BYTES) * 512; }
+
+int shafa_hipd_hist256_tiles(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
+                             const uint64_t *h_in_off, const uint64_t *h_in_n, uint64_t *d_freq,
+                             uint8_t *d_tile_hist, const uint64_t *h_tile_hist_off)
+{
+    if (!d_tile_hist || !h_tile_hist_off) return SHAFA_OUTSIDE_MODULE;
+    if (int rc = batch_enter((Batch *)b, (hipStream_t)stream)) return rc;
+    return hist_launch_dev((Batch *)b, (hipStream_t)stream, nblocks, d_in, h_in_off, h_in_n, nullptr, d_freq, d_tile_hist,
+                           h_tile_hist_off);
+}
+
+int shafa_hipd_rle_encode_tiles(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
+                                const uint64_t *h_in_off, const uint64_t *h_in_n, uint8_t *d_out,
+                                const uint64_t *h_out_off, const uint64_t *h_out_cap, uint64_t *d_out_n,
+                                uint64_t *d_freq, uint8_t *d_tile_hist, const uint64_t *h_tile_hist_off)
+{
+    if (!d_freq || !d_tile_hist || !h_tile_hist_off) return SHAFA_OUTSIDE_MODULE;
+    if (int rc = batch_enter((Batch *)b, (hipStream_t)stream)) return rc;
+    return rleenc_launch((Batch *)b, (hipStream_t)stream, nblocks, d_in, h_in_off, h_in_n, d_out, h_out_off,
+                         h_out_cap, d_out_n, d_freq, d_tile_hist, h_tile_hist_off);
+}
+
+int shafa_hipd_sf_encode_tiles(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
+                               const uint64_t *h_in_off, const uint64_t *h_in_n, const shafa_code_table *h_tables,
+                               const uint8_t *d_tile_hist, const uint64_t *h_tile_hist_off, uint8_t *d_out,
+                               const uint64_t *h_out_off, const uint64_t *h_out_cap, uint64_t *d_out_n)
+{
+    if (!d_tile_hist || !h_tile_hist_off) return SHAFA_OUTSIDE_MODULE;
+    if (int rc = batch_enter((Batch *)b, (hipStream_t)stream)) return rc;
+    return sfenc_launch((Batch *)b, (hipStream_t)stream, nblocks, d_in, h_in_off, h_in_n, h_tables, d_out,
+                        h_out_off, h_out_cap, d_out_n, d_tile_hist, h_tile_hist_off);
 }
 
 int shafa_hipd_rle_encode(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,

@@ -17,7 +17,8 @@ constexpr int HIST_THREADS = 256;
 constexpr u64 HIST_CHUNK = 256 * 1024;
 constexpr int HIST_REP = 32;
 
-struct HistBlk { const u8 *in; u64 n; u64 *freq; const u64 *n_dev; };
+struct HistBlk { const u8 *in; u64 n; u64 *freq; const u64 *n_dev; u16 *thist; };
+constexpr u64 HIST_TILE = 32768;                       // SHAFA_TILE_BYTES: a tile of the sidecar (sf_encode6.hip)
 
 __global__ __launch_bounds__(HIST_THREADS) void hist256_kernel(const HistBlk *__restrict__ blks)
 {
@@ -62,20 +63,78 @@ __global__ __launch_bounds__(HIST_THREADS) void hist256_kernel(const HistBlk *__
     if (c) atomicAdd((unsigned long long *)(blk.freq + tid), (unsigned long long)c);
 }
 
+// The same with the SIDECAR of the one-shot Shannon-Fano encoder (sf_encode6.hip): every 32 KiB tile's own histogram,
+// 256 x u16 (a tile holds at most 32768 of one byte), at thist + 256 * tile.  The LDS replicas keep RUNNING totals over the
+// workgroup's eight tiles — nothing is zeroed between tiles; behind each tile every lane sums the 32 replicas of its symbol
+// and stores the difference to the previous sum.  Two barriers per tile: counts complete before they are summed, sums
+// read before the next tile's counts arrive.
+__global__ __launch_bounds__(HIST_THREADS) void hist256_tiles_kernel(const HistBlk *__restrict__ blks)
+{
+    __shared__ u32 h[256 * HIST_REP];
+    const int tid = threadIdx.x;
+    const HistBlk blk = blks[blockIdx.y];
+    const u64 n = blk.n_dev ? *blk.n_dev : blk.n;
+    const u64 start = (u64)blockIdx.x * HIST_CHUNK;
+    if (start >= n) return;
+    const u64 end = (start + HIST_CHUNK < n) ? start + HIST_CHUNK : n;
+
+    for (int i = tid; i < 256 * HIST_REP; i += HIST_THREADS) h[i] = 0;
+    __syncthreads();
+
+    const u32 rep = tid & (HIST_REP - 1);
+    auto count16 = [&](const uint4 v) {
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const u32 sym = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            atomicAdd(&h[sym * HIST_REP + rep], 1u);
+        }
+    };
+    constexpr u64 STEP = (u64)HIST_THREADS * 16;
+    u16 *th = blk.thist + (start / HIST_TILE) * 256;
+    u32 prev = 0;
+    for (u64 ts = start; ts < end; ts += HIST_TILE, th += 256) {
+        const u64 te = ts + HIST_TILE < end ? ts + HIST_TILE : end;
+        u64 p = ts + (u64)tid * 16;
+        for (; p + 3 * STEP + 16 <= te; p += 4 * STEP) {   // four loads in flight per lane
+            const uint4 v0 = gload_nt<uint4>(blk.in + p), v1 = gload_nt<uint4>(blk.in + p + STEP);
+            const uint4 v2 = gload_nt<uint4>(blk.in + p + 2 * STEP), v3 = gload_nt<uint4>(blk.in + p + 3 * STEP);
+            count16(v0);
+            count16(v1);
+            count16(v2);
+            count16(v3);
+        }
+        for (; p < te; p += STEP) {
+            if (p + 16 <= te) count16(*(const uint4 *)(blk.in + p));
+            else for (u64 q = p; q < te; ++q) atomicAdd(&h[(u32)blk.in[q] * HIST_REP + rep], 1u);
+        }
+        __syncthreads();
+        u32 c = 0;
+#pragma unroll
+        for (int r = 0; r < HIST_REP; ++r) c += h[tid * HIST_REP + ((r + tid) & (HIST_REP - 1))];
+        th[tid] = (u16)(c - prev);
+        prev = c;
+        __syncthreads();
+    }
+    if (prev) atomicAdd((unsigned long long *)(blk.freq + tid), (unsigned long long)prev);
+}
+
 }  // namespace
 
 // h_in_n[b] is the block size, or (with d_n != NULL) an upper bound of the size the device wrote to d_n[b]
 int hist_launch_dev(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
-                    const u64 *h_in_n, const u64 *d_n, u64 *d_freq)
+                    const u64 *h_in_n, const u64 *d_n, u64 *d_freq, u8 *d_thist, const u64 *h_thist_off)
 {
     if (nblocks <= 0) return SHAFA_SUCCESS;
     if (nblocks > bt->max_blocks) return SHAFA_LACK_OF_MEMORY;
+    if ((d_thist == nullptr) != (h_thist_off == nullptr)) return SHAFA_OUTSIDE_MODULE;
     const size_t pbytes = (size_t)nblocks * sizeof(HistBlk);
     HistBlk *hp = (HistBlk *)batch_stage(bt, st, pbytes);
     if (!hp) return SHAFA_LACK_OF_MEMORY;
     u64 max_n = 0;
     for (int b = 0; b < nblocks; ++b) {
-        if (h_in_off[b] & 15) return SHAFA_OUTSIDE_MODULE;
+        if ((h_in_off[b] & 15) || (d_thist && (h_thist_off[b] & 15))) return SHAFA_OUTSIDE_MODULE;
+        hp[b].thist = d_thist ? (u16 *)(d_thist + h_thist_off[b]) : nullptr;
         hp[b].in = d_in + h_in_off[b];
         hp[b].n = h_in_n[b];
         hp[b].freq = d_freq + (size_t)b * 256;
@@ -86,7 +145,8 @@ int hist_launch_dev(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, cons
     if (max_n == 0) return SHAFA_SUCCESS;
     HIP_TRY(hipMemcpyAsync(bt->d_par_hist, hp, pbytes, hipMemcpyHostToDevice, st));
     const dim3 grid((u32)ceil_div_u64(max_n, HIST_CHUNK), (u32)nblocks);
-    hipLaunchKernelGGL(hist256_kernel, grid, dim3(HIST_THREADS), 0, st, (const HistBlk *)bt->d_par_hist);
+    if (d_thist) hipLaunchKernelGGL(hist256_tiles_kernel, grid, dim3(HIST_THREADS), 0, st, (const HistBlk *)bt->d_par_hist);
+    else hipLaunchKernelGGL(hist256_kernel, grid, dim3(HIST_THREADS), 0, st, (const HistBlk *)bt->d_par_hist);
     HIP_TRY(hipGetLastError());
     return SHAFA_SUCCESS;
 }

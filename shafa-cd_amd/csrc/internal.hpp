@@ -28,7 +28,7 @@ struct Batch {
     size_t stage_bytes;    //   fenced by an event recorded on the stream that copies from it; a region is reused only
     size_t stage_used;     //   after ITS event (no device-wide synchronisation on the enqueue path)
     std::vector<StageSeg> *segs;
-    void *d_par_hist;      // max_blocks * 32 B of hist256 parameters (separate from d_ws: hist256 may
+    void *d_par_hist;      // max_blocks * 48 B of hist256 parameters (separate from d_ws: hist256 may
                            //   run right after another op that still owns the workspace)
     int *d_err;            // one error code per block (first error wins)
     int *h_err;            // pinned mirror
@@ -75,6 +75,7 @@ struct EncBlk {
     u32 n_tiles;
     u32 ticket;
     u32 pad;
+    const void *thist;     // sfe6 (sf_encode6.hip): the block's tile histograms (256 x u16 per 32 KiB tile), else unused
 };
 
 // second chain (descriptors, tickets) and per-block flags of the one-pass encoder's encode-again fall-back (sf_encode4.hip)
@@ -87,17 +88,19 @@ struct SfeRedo {
 // ---- launchers (one per reference function) ------------------------------------------------------
 int hist_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                 const u64 *h_in_n, u64 *d_freq);
+// d_thist / h_thist_off (both or neither): also write every 32 KiB tile's own histogram (256 x u16) to d_thist + h_thist_off[b]
 int hist_launch_dev(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
-                    const u64 *h_in_n, const u64 *d_n, u64 *d_freq);
+                    const u64 *h_in_n, const u64 *d_n, u64 *d_freq, u8 *d_thist = nullptr, const u64 *h_thist_off = nullptr);
+// d_thist / h_thist_off (both or neither): the tile histograms of shafa_hipd_hist256_tiles, block b's at d_thist + h_thist_off[b]
 int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                  const u64 *h_in_n, const shafa_code_table *h_tables, u8 *d_out, const u64 *h_out_off,
-                 const u64 *h_out_cap, u64 *d_out_n);
+                 const u64 *h_out_cap, u64 *d_out_n, const u8 *d_thist = nullptr, const u64 *h_thist_off = nullptr);
 int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                  const u64 *h_in_n, const shafa_code_table *h_tables, const u64 *h_n_symbols, u8 *d_out,
                  const u64 *h_out_off);
 int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                   const u64 *h_in_n, u8 *d_out, const u64 *h_out_off, const u64 *h_out_cap, u64 *d_out_n,
-                  u64 *d_freq);
+                  u64 *d_freq, u8 *d_thist = nullptr, const u64 *h_thist_off = nullptr);
 int rledec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                   const u64 *h_in_n, u8 *d_out, const u64 *h_out_off, const u64 *h_out_cap, u64 *d_out_n);
 void sfenc_configure(int sfe4_min_blocks);

@@ -990,7 +990,7 @@ void rleenc_configure(int force_general) { g_rle_force_general = force_general; 
 
 int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                   const u64 *h_in_n, u8 *d_out, const u64 *h_out_off, const u64 *h_out_cap, u64 *d_out_n,
-                  u64 *d_freq)
+                  u64 *d_freq, u8 *d_thist, const u64 *h_thist_off)
 {
     if (nblocks <= 0) return SHAFA_SUCCESS;
     if (nblocks > bt->max_blocks) return SHAFA_LACK_OF_MEMORY;
@@ -1046,7 +1046,7 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
         HIP_TRY(hipGetLastError());
     }
     if (d_freq) {   // make_freq of the RLE bytes (f.c:310): sizes are on the device
-        rc = hist_launch_dev(bt, st, nblocks, d_out, h_out_off, h_out_cap, d_out_n, d_freq);
+        rc = hist_launch_dev(bt, st, nblocks, d_out, h_out_off, h_out_cap, d_out_n, d_freq, d_thist, h_thist_off);
         if (rc) return rc;
     }
     return SHAFA_SUCCESS;

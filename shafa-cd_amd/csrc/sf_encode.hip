@@ -210,6 +210,7 @@ int sfenc4_launch(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u3
 bool sfenc4_needs_redo(u32 lmax);
 bool sfenc4_long_ok();
 int sfenc4_launch_long(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, u32 ragged, const SfeRedo &x);
+int sfenc6_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, u32 lmax, bool any_ragged, u32 *d_tbits, u64 *d_toff);
 extern int g_sfe4_wide, g_sfe_lanes;
 
 // A launch with at least this many class-1 blocks takes the one-pass encoder: every block is its own chain, and with this
@@ -235,17 +236,20 @@ static u32 code_value(const shafa_code_table &t, int s)
 
 int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                  const u64 *h_in_n, const shafa_code_table *h_tables, u8 *d_out, const u64 *h_out_off,
-                 const u64 *h_out_cap, u64 *d_out_n)
+                 const u64 *h_out_cap, u64 *d_out_n, const u8 *d_thist, const u64 *h_thist_off)
 {
     if (nblocks <= 0) return SHAFA_SUCCESS;
     if (nblocks > bt->max_blocks) return SHAFA_LACK_OF_MEMORY;
+    if ((d_thist == nullptr) != (h_thist_off == nullptr)) return SHAFA_OUTSIDE_MODULE;
+    // with the tile histograms at hand, blocks of <= 16-bit codes take the one-shot encoder (sf_encode6.hip), whatever their number
+    const bool tiles = d_thist != nullptr;
 
     // classify blocks: 0 = nothing to launch (empty table or empty block), 1 = Lmax <= 16, 2 = Lmax <= 32, 3 = generic
     int cls_count[4] = {0, 0, 0, 0};
     std::vector<int> cls(nblocks);
     u32 lmax1 = 0, lmax2 = 0;
     for (int b = 0; b < nblocks; ++b) {
-        if ((h_in_off[b] & 15) || (h_out_off[b] & 15)) return SHAFA_OUTSIDE_MODULE;
+        if ((h_in_off[b] & 15) || (h_out_off[b] & 15) || (tiles && (h_thist_off[b] & 15))) return SHAFA_OUTSIDE_MODULE;
         int lmax = 0;
         for (int s = 0; s < 256; ++s) lmax = h_tables[b].len[s] > lmax ? h_tables[b].len[s] : lmax;
         const int c = (lmax == 0 || h_in_n[b] == 0) ? 0 : (lmax <= 16 ? 1 : (lmax <= 32 ? 2 : 3));
@@ -257,19 +261,20 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     // the one-pass encoder pays from 6 blocks per launch in its 1024-lane form (every Lmax <= 16 since the windows of
     // 13..16-bit codes are sized for 12 bits per symbol with an encode-again fall-back), from 80 in the 256-lane form
     const bool wide_form = g_sfe4_wide && g_sfe_lanes == 0 && (lmax1 <= 12 || sfenc4_needs_redo(lmax1));
-    const bool one_pass = cls_count[1] >= (g_sfe4_min_blocks > 0 ? g_sfe4_min_blocks : (wide_form ? 6 : 80));
+    const bool one_pass = tiles || cls_count[1] >= (g_sfe4_min_blocks > 0 ? g_sfe4_min_blocks : (wide_form ? 6 : 80));
     // codes of 17..32 bits: the quad form of the one-pass encoder from 6 blocks per launch, else count / scan / pack with
     // 64-bit groups
     const bool one_pass2 = cls_count[2] >= (g_sfe4_min_blocks > 0 ? g_sfe4_min_blocks : 6) && sfenc4_long_ok();
-    const bool redo = (one_pass && cls_count[1] && sfenc4_needs_redo(lmax1)) || one_pass2;
-    const u64 tile_syms[4] = {1, 256 * 16 * 2, 256 * 16 * 2, GEN_TILE};
+    const bool redo = (one_pass && !tiles && cls_count[1] && sfenc4_needs_redo(lmax1)) || one_pass2;
+    // class 1 with tile histograms: 32 KiB tiles, and one entry more per block (the block's total behind its tile offsets)
+    const u64 tile_syms[4] = {1, tiles ? 32768u : 256 * 16 * 2, 256 * 16 * 2, GEN_TILE};
     u64 total_tiles[4] = {0, 0, 0, 0};
     u32 max_tiles[4] = {0, 0, 0, 0};
     for (int b = 0; b < nblocks; ++b) {
         const int c = cls[b];
         if (!c) continue;
         const u64 t = ceil_div_u64(h_in_n[b], tile_syms[c]);
-        total_tiles[c] += t;
+        total_tiles[c] += t + (c == 1 && tiles ? 1 : 0);
         if (t > max_tiles[c]) max_tiles[c] = (u32)t;
     }
     const u64 ndesc = total_tiles[1] + total_tiles[2] + total_tiles[3];
@@ -322,7 +327,8 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
             e.n_tiles = (u32)ceil_div_u64(n, tile_syms[c]);
             e.ticket = (u32)pos;
             e.pad = 0;
-            dbase += e.n_tiles;
+            e.thist = (c == 1 && tiles) ? d_thist + h_thist_off[b] : nullptr;
+            dbase += e.n_tiles + (c == 1 && tiles ? 1 : 0);
             e.lut = ws + o_tab + tpos;
             const shafa_code_table &t = h_tables[b];
             if (c == 1 && one_pass) {                 // {code, len}; a symbol without a code: len = 1 << 16
@@ -348,7 +354,7 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
             ++pos;
         }
     }
-    const bool need_desc = cls_count[3] || (cls_count[1] && one_pass) || one_pass2;
+    const bool need_desc = cls_count[3] || (cls_count[1] && one_pass && !tiles) || one_pass2;
     if (o_zero_end && need_desc) HIP_TRY(hipMemsetAsync(ws, 0, o_zero_end, st));
     HIP_TRY(hipMemcpyAsync(ws + o_blk, hs, stage_bytes, hipMemcpyHostToDevice, st));
     for (int b = 0; b < nblocks; ++b)
@@ -357,7 +363,12 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const EncBlk *dblk = (const EncBlk *)(ws + o_blk);
     u64 *ddesc = (u64 *)(ws + o_desc);
     u32 *dtick = (u32 *)(ws + o_tick);
-    if (cls_count[1]) {
+    if (cls_count[1] && tiles) {                       // tile offsets from the histograms: u64 per entry in the descriptor area,
+        bool any_ragged = false;                       //   the tile totals (u32) in the tile-bits area
+        for (int b = 0; b < nblocks; ++b)
+            if (cls[b] == 1 && (h_in_n[b] & 32767)) any_ragged = true;
+        if ((rc = sfenc6_launch(st, dblk + cls_first[1], cls_count[1], max_tiles[1], lmax1, any_ragged, (u32 *)(ws + o_tbits), ddesc))) return rc;
+    } else if (cls_count[1]) {
         if (one_pass) {
             u32 ragged = 0;                            // bit 0 / 1 / 2: a block has a remainder after its full 8 / 16 / 32 KiB tiles
             for (int b = 0; b < nblocks; ++b)
