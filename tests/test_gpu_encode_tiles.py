@@ -171,7 +171,7 @@ def test_tiles_mixed_with_longer_codes_in_one_launch(shafa, oracle):
     they take without tile histograms; the others are not disturbed."""
     shafa.lib().shafa_hip_init(0)
     blocks, tables = zipf_blocks(shafa, oracle, [200000, 65536, 70000], seed0=6400)
-    lb, lt = _long_tail_blocks(shafa, oracle, [300000, 40000], 9300)
+    lb, lt = _long_tail_blocks(shafa, oracle, [300000, 250000], 9300)
     assert all(int(t.lens().max()) > 16 for t in lt)
     otab, data = long_code_case(oracle, 60000, 40, 0.5, 11)
     assert otab.lens().max() > 32
