@@ -500,7 +500,7 @@ def main():
 
     # the other encoder on the same blocks: same bytes (and its time, for the line)
     chained = None
-    if use_tiles and not ablation:
+    if use_tiles and not ablation and nb <= 256:          # (a second copy of the encoded blocks: not at cfg[3]'s full 1024)
         ref_enc = d_enc.clone()
         d_enc.zero_()
         encode_chained()

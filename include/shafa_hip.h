@@ -88,8 +88,6 @@ const char *shafa_hip_last_error(void);      /* text of the last SHAFA_DEVICE_ER
  *   "sf_decode_speculate": 1 (default) lets blocks whose code re-synchronises take the speculative entry kernels of
  *       the Shannon-Fano decoder (verified exactly; falls back to the exact kernels per block), 0 = exact kernels only,
  *       2 = speculate for every block the kernels apply to, whatever its code (for tests of the fall-back).
- *   "sf_encode_variant": 5 (default) = one-pass encoder with plain-store LDS windows and one barrier per tile
- *       (sfe5_kernel), 4 = the form with atomic-OR windows (sfe4_kernel).
  *   "sf_encode_lanes": 0 (default) = the widest workgroup whose windows fit the CU's LDS (1024 lanes, 32 KiB tiles, for
  *       codes of <= 12 bits; 256 lanes otherwise), 256 / 512 = that width.
  * Test knobs that force the fall-back kernels the library otherwise takes by itself (tests/test_gpu_codec.py):

@@ -132,12 +132,6 @@ int shafa_hip_set_option(const char *name, long value)
         sfenc_configure(value < 0 ? 0 : (value > (1 << 30) ? (1 << 30) : (int)value));      // 0: measured defaults
         return SHAFA_SUCCESS;
     }
-    if (name && !strcmp(name, "sf_encode_variant")) {
-        extern int g_sfe_variant;
-        if (value != 4 && value != 5) return SHAFA_OUTSIDE_MODULE;
-        g_sfe_variant = (int)value;
-        return SHAFA_SUCCESS;
-    }
     if (name && !strcmp(name, "sf_encode_window_bits")) {
         extern int g_sfe_window_bits;
         if (value < 0 || value > 16) return SHAFA_OUTSIDE_MODULE;

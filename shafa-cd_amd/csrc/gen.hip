@@ -48,9 +48,14 @@ int gen_launch(hipStream_t st, u64 seed, u64 first, const u8 *d_map, u8 *d_out, 
 {
     if ((first & 15) || ((uintptr_t)d_out & 15)) return SHAFA_OUTSIDE_MODULE;
     if (!n) return SHAFA_SUCCESS;
-    const u64 threads = ceil_div_u64(n, 16);
-    hipLaunchKernelGGL(gen_kernel, dim3((u32)ceil_div_u64(threads, 256)), dim3(256), 0, st, seed, first,
-                       d_map, d_out, (u64)n);
+    // at most 8 GiB per launch: a grid holds fewer than 2^32 threads (64 GiB in one launch is an invalid configuration)
+    constexpr u64 PART = 8ull << 30;
+    for (u64 done = 0; done < (u64)n; done += PART) {
+        const u64 m = (u64)n - done < PART ? (u64)n - done : PART;
+        const u64 threads = ceil_div_u64(m, 16);
+        hipLaunchKernelGGL(gen_kernel, dim3((u32)ceil_div_u64(threads, 256)), dim3(256), 0, st, seed, first + done,
+                           d_map, d_out + done, m);
+    }
     HIP_TRY(hipGetLastError());
     return SHAFA_SUCCESS;
 }

@@ -1,11 +1,11 @@
-// sf_encode4.hip — Shannon-Fano bit-pack encoder for codes <= 16 bits in ONE pass over the input
-// (compress_to_buffer + binary_coding, reference c.c:52-237): n bytes read + ceil(bits / 8) bytes written,
-// which is the kernel's algorithmic HBM traffic.
+// sf_encode4.hip — Shannon-Fano bit-pack encoder for codes <= 32 bits in ONE pass over the input, for callers WITHOUT
+// tile histograms (compress_to_buffer + binary_coding, reference c.c:52-237): n bytes read + ceil(bits / 8) bytes written,
+// which is the kernel's algorithmic HBM traffic.  (With Module F's tile histograms the tile offsets
+// exist before the launch and the encoder is a one-shot grid: sf_encode6.hip.)
 //
 // Why one pass: the three-kernel form (sf_encode3.hip: count, scan, pack) reads the input twice, 2.67 n of traffic on
-// Zipf data, and sits at the HBM ceiling of that traffic (a stream that reads n and writes 2n/3 tops out at
-// 5.3-5.9 TB/s on this part, tools/ubench).  The prefix problem (where does tile t start in the output?) is solved
-// here with a chained scan whose waiting never reaches the critical path:
+// Zipf data, and sits at the HBM ceiling of that traffic.  The prefix problem (where does tile t start in the output?) is
+// solved here with a chained scan whose waiting never reaches the critical path (sfe5_kernel):
 //
 //   * workgroups are persistent and stick to one block at a time (block = blockIdx % nconc, then + nconc): the
 //     block's look-up table is loaded once, and with many blocks per launch every block is a separate chain with
@@ -13,21 +13,18 @@
 //   * tiles of a block are handed out by a per-block ticket (atomicAdd), requested three iterations ahead: a tile's
 //     predecessors were always taken by workgroups that are running, so the chain cannot deadlock whatever part
 //     of the grid is resident (other kernels on other streams included);
-//   * iteration i looks up, groups and scans tile i, publishes its bit total (aggregate) and ORs its bit strings
-//     into an LDS window at tile-local offsets; the descriptor window of the tile is requested in iteration i+1 (its
-//     predecessors hold earlier tickets and have had a whole tile time to publish) and consumed in iteration i+2
-//     (a whole tile time to arrive), when the tile's LDS window - one of three - is stored.
-//
-// Per tile (8 KiB of symbols = four rows of 256 lanes x 8 bytes): every lane turns the 8 symbols of a row into an "oct"
-// (<= 128 bits, right-aligned in four dwords) with a tree of shift-or steps on {code, len} pairs read
-// from a 2 KiB LDS table with ds_read_b64 (no unpacking); oct bit totals are scanned lane -> wave -> tile (DPP);
-// an oct that ENDS at window bit e is ORed into the LDS window with one v_alignbit_b32 + one ds_or_b32 per dword
-// (alignbit by e mod 32 needs no special case for 0).  On the way out every output dword is one more alignbit of
-// two neighbouring window dwords by (B mod 32), B = the tile's bit offset in the block: byte-swapped, 16-byte
-// aligned coalesced stores.  A tile owns the output dwords [B >> 5, E >> 5); the B mod 32 leading bits of its
-// first dword are re-encoded from the up to 31 symbols before the tile (each code has >= 1 bit) into the "lead
-// word" in front of the window, so every output dword is written exactly once: no global atomics, no pre-zeroed
-// output.
+//   * a three-stage software pipeline, one LDS window per stage: iteration i looks up, groups and scans tile i, publishes
+//     its bit total (aggregate) and places its bit strings in a window at TILE-LOCAL offsets (plain stores with carries,
+//     sfe_dev.hpp: emit_oct); the descriptor window of the tile is requested in iteration i+1 (its predecessors hold
+//     earlier tickets and have had a whole tile time to publish) and consumed in iteration i+2 (a whole tile time to
+//     arrive), when the tile's window is funnel-shifted by (B mod 32) on its way out: byte-swapped, 16-byte aligned
+//     non-temporal stores.  Wave 0 runs the chain and consumes every chain value BEFORE it issues new memory operations
+//     (s_waitcnt vmcnt counts in order); one barrier per tile (the hand-over words exist twice, by iteration parity).
+//   * A tile owns the output dwords [B >> 5, E >> 5); the B mod 32 leading bits of its first dword are re-encoded from the
+//     up to 31 symbols before the tile into the "lead word" in front of the window, so every output dword is written
+//     exactly once: no global atomics, no pre-zeroed output.  A block's ragged remainder is sfe4_tail_kernel's.
+//   * 1024 lanes and 32 KiB tiles where three windows fit a CU's LDS (codes <= 12 bits; 13..16-bit and, as quads, 17..32-bit
+//     codes with windows sized for 12 bits per symbol and a flag-and-encode-again pass for tiles that do not fit).
 #include "common.hpp"
 #include "internal.hpp"
 #include "sfe_dev.hpp"
@@ -37,184 +34,8 @@
 int g_sfe4_wide = 1;                                   // 0: always the 256-lane form (A/B and tests)
 int g_sfe_window_bits = 0;                             // test knob: bits per symbol of the wide form's windows (0: min(Lmax, 12))
 int g_sfe_lanes = 0;                                   // 0: widest form that fits; 256 / 512: that workgroup width (A/B and tests)
-int g_sfe_variant = 5;                                 // 5: plain-store windows (sfe5_kernel); 4: atomic-OR windows (sfe4_kernel)
 
 namespace {
-
-#ifdef E4_STAMPS
-// diagnostic build only (tools/dbg): per-wave cycle totals of the phases of an iteration
-__device__ unsigned long long e4_stamp_buf[2048 * 16 * 8];
-#define E4_T0() unsigned long long _t_prev = __builtin_amdgcn_s_memtime(), _t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define E4_T(ph) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); _t_acc[ph] += _t - _t_prev; _t_prev = _t; } while (0)
-#define E4_TEND() do { if (lane == 0) for (int _q = 0; _q < 8; ++_q) e4_stamp_buf[((blockIdx.x & 2047) * 16 + wv) * 8 + _q] = _t_acc[_q]; } while (0)
-#else
-#define E4_T0()
-#define E4_T(ph)
-#define E4_TEND()
-#endif
-
-// NW: dwords an oct can touch (3: Lmax <= 8, 4: <= 12, 5: <= 16); L16: Lmax == 16
-//
-// The FULL tiles of every block.  A three-stage software pipeline per workgroup, one LDS window buffer per stage:
-//   iteration i, all waves: tile i is looked up, grouped, scanned and ORed into its window at TILE-LOCAL bit offsets (the
-//     output position is not needed for that); tile i-2, whose prefix B is known by now, is funnel-shifted by (B mod 32)
-//     on the way out of LDS and stored.
-//   wave 0 also runs the chain, and never waits for a round trip doing so: at the top of iteration i it hands over the
-//     ticket that was requested in iteration i-1 and requests the next; it resolves the prefix of tile i-2 from the
-//     descriptor window it requested in iteration i-1 — a full iteration after that tile's aggregate went out, so its
-//     predecessors (earlier tickets) have published theirs unless they lag a whole tile time behind; after barrier A it
-//     publishes tile i's aggregate and requests the window of tile i-1.
-// Two barriers per tile.  A block's ragged remainder (< 8192 symbols) is left to sfe4_tail_kernel.
-template <int NW, bool L16, int NT>
-__global__ __launch_bounds__(NT, E4_WPS) void sfe4_kernel(const EncBlk *__restrict__ blks, int nblk, int nconc,
-                                                             u64 *__restrict__ desc, u32 *__restrict__ tickets, u32 win_stride)
-{
-    __shared__ E4Static sh;
-    extern __shared__ __attribute__((aligned(16))) u32 dynwin[];     // three buffers of [E4_GUARD][window dwords]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NWV = NT / 64;                       // waves
-    constexpr u32 TILE = 32u * NT, TSHIFT = NT == 256 ? 13 : NT == 512 ? 14 : 15;        // symbols per tile
-    E4_T0();
-
-    for (int b = (int)(blockIdx.x % (u32)nconc); b < nblk; b += nconc) {
-        const EncBlk *bp = blks + b;
-        const u8 *in = bp->in;
-        const u32 nfull = (u32)(bp->n >> TSHIFT);      // full tiles of this kernel's size
-        const bool ragged = (bp->n & (TILE - 1)) != 0;
-        u64 *bdesc = desc + bp->desc_base;
-        u32 *tick = tickets + bp->ticket;
-        __syncthreads();                               // the previous block's table and windows are no longer in use
-        if (tid < 256) sh.lut[tid] = gload<u64>((const u64 *)bp->lut + tid);
-        if (tid == 0) sh.tick = atomicAdd(tick, 3u);
-        __syncthreads();
-        // tickets are four deep so that no atomic's round trip is ever waited for: `cur` is processed, `nxt` is being
-        // loaded, `nn` is known, and thread 0 holds the request issued one iteration ago (req)
-        u32 cur = sh.tick, nxt = cur + 1, nn = cur + 2;
-        if (cur >= nfull) continue;
-        u32 req = E4_NONE;
-        if (tid == 0) req = atomicAdd(tick, 1u);
-        TileIn cin, nin, nin2;                         // inputs are requested two tiles ahead
-        load_tile<NT>(in, cur, tid, cin);
-        if (nxt < nfull) load_tile<NT>(in, nxt, tid, nin);
-        // wave 0: the descriptor window and the 32 symbols in front of the tile computed one iteration ago (q) are requested
-        // after barrier A and used at the top of the next iteration, when that tile is p: one variable each, never copied
-        // (a copy of a loaded register is a wait for the load)
-        u64 first_w = 0;
-        u32 pv_w = 0;
-
-        u32 q_tile = E4_NONE, q_T = 0;                 // computed in the previous iteration: aggregate out, window requested now
-        u32 p_tile = E4_NONE, p_T = 0;                 // computed two iterations ago: resolved and stored now
-        u32 dirty[3] = {win_stride - E4_GUARD, win_stride - E4_GUARD, win_stride - E4_GUARD};   // dwords that may be non-zero
-        u32 buf = 0;                                   // window buffer of `cur`; q: buf - 1, p: buf - 2 (mod 3)
-        bool rotate_in = false;
-
-        for (;;) {
-            const bool cur_ok = cur < nfull;
-            const bool have_q = q_tile != E4_NONE, have_p = p_tile != E4_NONE;
-            if (!cur_ok && !have_q && !have_p) break;
-            const u32 pbuf = buf >= 2 ? buf - 2 : buf + 1;
-            u32 *win = dynwin + buf * win_stride + E4_GUARD;               // this tile's window
-            u32 *pwin = dynwin + pbuf * win_stride + E4_GUARD;             // the window that is stored in this iteration
-            Oct c_oct[4];
-            u32 incl[2] = {0, 0};                      // rows (0,1) and (2,3): two 16-bit running sums per dword, one DPP scan each
-
-            E4_T(7);
-            // ---- wave 0, before it issues anything new: everything it consumes here was requested at least half an
-            //      iteration ago (its youngest outstanding memory operation is the descriptor request after barrier A; it
-            //      takes no part in the window stores below), so these waits are short --------------------------------
-            if (wv == 0) {
-                if (lane == 0) sh.tick = req;          // last iteration's ticket request
-                E4_T(2);
-                if (have_p) {                          // prefix and lead bits of the tile that is stored in this iteration
-                    u64 B = 0;
-                    if (p_tile > 0) {
-                        B = lookback_sum_dpp(bdesc, (int)p_tile, bp->err, first_w);
-                        E4_T(0);
-                        if (lane == 0) {
-                            desc_store(bdesc + p_tile, DESC_PREFIX, B + p_T);
-                            if (!ragged && p_tile == nfull - 1) gstore<u64>(bp->out_n, (B + p_T + 7) >> 3);
-                        }
-                        const u32 r = (u32)B & 31u;
-                        if (r) lead_bits(sh.lut, pwin, pv_w, r, lane);
-                    }
-                    if (lane == 0) sh.prefix = B;
-                }
-            }
-            E4_T(7);
-
-            // ---- this tile: zero its window, look up, group, scan ------------------------------------------------
-            if (cur_ok) {
-                for (u32 i = (u32)tid; i < ((dirty[buf] + 3u) >> 2) + 1u; i += NT)
-                    ((uint4 *)win)[(int)i - 1] = make_uint4(0, 0, 0, 0);              // from dword -4: the lead word is win[-1]
-            }
-            // the input registers move up one place here, not at the end of the iteration: a wave that loads and stores
-            // has to drain its whole memory queue before it may touch a loaded register (loads and stores complete out of
-            // order with respect to each other), and here the window stores of the previous iteration are oldest
-            if (rotate_in) { cin = nin; nin = nin2; }
-            rotate_in = true;
-            if (cur_ok && nn < nfull) load_tile<NT>(in, nn, tid, nin2);
-            // the next ticket: unconditional (a few tickets past the block's end are harmless), and issued only now, after
-            // the wave's one drain of the iteration: the returned value is not touched before the next iteration's top
-            if (tid == 0) req = atomicAdd(tick, 1u);
-            if (cur_ok) {
-                u32 absent = 0;
-                tile_octs<false, NW, L16, NT>(sh.lut, cin, 0u, tid, c_oct, incl, absent);
-                if (absent) set_error(bp->err, SHAFA_FILE_UNRECOGNIZABLE);   // data symbol without a code (output undefined, in bounds)
-                if (lane == 63) {
-                    sh.wtot[wv] = incl[0] & 0xFFFFu;
-                    sh.wtot[NWV + wv] = incl[0] >> 16;
-                    sh.wtot[2 * NWV + wv] = incl[1] & 0xFFFFu;
-                    sh.wtot[3 * NWV + wv] = incl[1] >> 16;
-                }
-            }
-            E4_T(1);
-            lds_barrier();                                                             // A
-            E4_T(3);
-            const u32 n3 = sh.tick;
-            // waves 1..3 store the resolved tile's window FIRST: their next use of a loaded register (the input rotation in
-            // the next iteration) has to wait for these stores, so they go out as early as the iteration allows
-            if (wv != 0 && have_p)
-                store_window(pwin, bp->out, bp->out_cap, bp->err, sh.prefix, p_T, !ragged && p_tile == nfull - 1, tid - 64,
-                             NT - 64);
-            u32 c_T = 0;
-            if (cur_ok) {
-                u32 roff[4];
-                c_T = tile_offsets<NWV>(sh.wtot, lane, wv, roff);
-                if (tid == 0) {
-                    if (cur == 0) {
-                        desc_store(bdesc, DESC_PREFIX, c_T);
-                        if (!ragged && nfull == 1) gstore<u64>(bp->out_n, ((u64)c_T + 7) >> 3);
-                    } else desc_store(bdesc + cur, DESC_AGG, c_T);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k)            // the oct ends at: row offset of the wave + inclusive lane prefix
-                    place<NW>(win, c_oct[k], roff[k] + ((incl[k >> 1] >> (16 * (k & 1))) & 0xFFFFu));
-                dirty[buf] = (c_T >> 5) + 2u;
-            }
-            E4_T(4);
-            if (wv == 0) {
-                if (have_q && q_tile > 0) {            // descriptor window and leading symbols of the tile computed one iteration ago
-                    const int idx = (int)q_tile - 1 - lane;
-                    first_w = desc_load(bdesc + (idx > 0 ? idx : 0));
-                    if (lane < 32) pv_w = gload_off<u8>(in + (u64)q_tile * TILE - 32, 31u - (u32)lane);
-                }
-            }
-            E4_T(5);
-            lds_barrier();                                                             // B
-            E4_T(6);
-
-            // ---- rotate ------------------------------------------------------------------------------------------
-            p_tile = q_tile; p_T = q_T;
-            q_tile = cur_ok ? cur : E4_NONE; q_T = c_T;
-            buf = buf == 2 ? 0 : buf + 1;
-            cur = nxt;
-            nxt = nn;
-            nn = n3;
-        }
-    }
-    E4_TEND();
-}
 
 // cap_bits: what a window holds.  Launches whose longest code lets a tile outgrow the CU's LDS (13..16-bit codes in the
 // 1024-lane form) run with windows sized for 12 bits per symbol: a tile that does not fit (the block's rare symbols — every
@@ -245,7 +66,9 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restri
         if (tid < 256) sh.lut[tid] = gload<u64>((const u64 *)bp->lut + tid);
         if (tid == 0) sh.tick = atomicAdd(tick, 3u);
         __syncthreads();
-        u32 cur = sh.tick, nxt = cur + 1, nn = cur + 2;        // tickets four deep, as in sfe4_kernel
+        // tickets are four deep so that no atomic's round trip is ever waited for: `cur` is processed, `nxt` is being
+        // loaded, `nn` is known, and thread 0 holds the request issued one iteration ago (req)
+        u32 cur = sh.tick, nxt = cur + 1, nn = cur + 2;
         if (cur >= nfull) continue;
         u32 req = E4_NONE;
         if (tid == 0) req = atomicAdd(tick, 1u);
@@ -280,7 +103,8 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restri
             Oct c_oct[UNITS];
             u32 tot = 0, incl = 0, tail = 0;
 
-            // ---- wave 0, before it issues anything new (see sfe4_kernel) -----------------------------------------------
+            // ---- wave 0, before it issues anything new: everything it consumes here was requested at least half an
+            //      iteration ago (it takes no part in the window stores below), so these waits are short ---------------------
             if (wv == 0) {
                 if (lane == 0) sh.tick5[par] = req;    // last iteration's ticket request
                 if (have_p) {                          // prefix and lead bits of the tile that is stored in this iteration
@@ -390,7 +214,7 @@ int e5q_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u3
                   u32 *d_redo, int redo_only)
 {
     constexpr int MAXDEV = 64;
-    static int wgs_by_dev_lmax[MAXDEV][33], cus_by_dev[MAXDEV], tail_attr_by_dev[MAXDEV];
+    static int wgs_by_dev_lmax[MAXDEV][33], cus_by_dev[MAXDEV], tail_attr_by_dev[MAXDEV], main_attr_by_dev[MAXDEV];
     static std::mutex mu;
     const u32 win_stride = ((u32)E4_GUARD + (u32)(((size_t)(32 * NT) * lmax_win) >> 5) + 8u + 3u) & ~3u;   // dwords per buffer
     const u32 tail_stride = ((u32)E4_GUARD + (u32)(((size_t)(32 * NT) * lmax) >> 5) + 8u + 3u) & ~3u;
@@ -402,13 +226,17 @@ int e5q_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u3
     {
         std::lock_guard<std::mutex> lk(mu);
         int *wgs_by_lmax = wgs_by_dev_lmax[dev];
+        // the attribute only ever grows: a later launch with smaller windows must not lower the limit under an earlier,
+        // larger window size whose occupancy is cached
+        if (dyn > 65536 && (int)dyn > main_attr_by_dev[dev]) {
+            HIP_TRY(hipFuncSetAttribute((const void *)sfe5_kernel<5, false, NT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            main_attr_by_dev[dev] = (int)dyn;
+        }
         if (!wgs_by_lmax[lmax_win]) {
             int occ = 0;
             hipDeviceProp_t prop;
             HIP_TRY(hipGetDeviceProperties(&prop, dev));
             cus_by_dev[dev] = prop.multiProcessorCount;
-            if (dyn > 65536)
-                HIP_TRY(hipFuncSetAttribute((const void *)sfe5_kernel<5, false, NT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)sfe5_kernel<5, false, NT, 8>, NT, dyn));
             wgs_by_lmax[lmax_win] = occ < 1 ? 1 : (occ > 6 ? 6 : occ);
         }
@@ -430,6 +258,7 @@ int e5q_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u3
     if (any_ragged)
         hipLaunchKernelGGL((sfe5q_tail_kernel<NT>), dim3((u32)count), dim3(NT), (size_t)tail_stride * 4, st, dblk,
                            (const u64 *)d_desc, tail_stride, (const u32 *)(redo_only ? d_redo : nullptr));
+    HIP_TRY(hipGetLastError());
     return SHAFA_SUCCESS;
 }
 
@@ -442,7 +271,7 @@ int e4_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32
     // per device: the LDS attribute below belongs to the device's copy of the kernel, and devices may differ in CUs.
     // (Statics of a template: one set per instantiation.  Guarded: pipes on several host threads launch concurrently.)
     constexpr int MAXDEV = 64;
-    static int wgs_by_dev_lmax[MAXDEV][17], cus_by_dev[MAXDEV], tail_attr_by_dev[MAXDEV];
+    static int wgs_by_dev_lmax[MAXDEV][17], cus_by_dev[MAXDEV], tail_attr_by_dev[MAXDEV], main_attr_by_dev[MAXDEV];
     static std::mutex mu;
     const u32 win_stride = ((u32)E4_GUARD + (u32)(((size_t)(32 * NT) * lmax_win) >> 5) + 8u + 3u) & ~3u;   // dwords per buffer
     const u32 tail_stride = ((u32)E4_GUARD + (u32)(((size_t)(32 * NT) * lmax) >> 5) + 8u + 3u) & ~3u;
@@ -454,16 +283,18 @@ int e4_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32
     {
         std::lock_guard<std::mutex> lk(mu);
         int *wgs_by_lmax = wgs_by_dev_lmax[dev];
+        // more than the default 64 KiB of dynamic LDS per workgroup: the attribute only ever grows (a launch with smaller
+        // windows — sf_encode_window_bits, a launch of shorter codes — must not lower it under a cached larger size)
+        if (dyn > 65536 && (int)dyn > main_attr_by_dev[dev]) {
+            HIP_TRY(hipFuncSetAttribute((const void *)sfe5_kernel<NW, L16, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            main_attr_by_dev[dev] = (int)dyn;
+        }
         if (!wgs_by_lmax[lmax_win]) {
             int occ = 0;
             hipDeviceProp_t prop;
             HIP_TRY(hipGetDeviceProperties(&prop, dev));
             cus_by_dev[dev] = prop.multiProcessorCount;
-            if (dyn > 65536) {                         // more than the default 64 KiB of dynamic LDS per workgroup
-                HIP_TRY(hipFuncSetAttribute((const void *)sfe4_kernel<NW, L16, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-                HIP_TRY(hipFuncSetAttribute((const void *)sfe5_kernel<NW, L16, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-            }
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)sfe4_kernel<NW, L16, NT>, NT, dyn));
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)sfe5_kernel<NW, L16, NT>, NT, dyn));
             wgs_by_lmax[lmax_win] = occ < 1 ? 1 : (occ > 6 ? 6 : occ);   // residency is a matter of speed only (tickets), 6 = what the registers allow
         }
         if (any_ragged && (size_t)tail_stride * 4 > 65536 && tail_attr_by_dev[dev] < (int)tail_stride) {
@@ -481,15 +312,12 @@ int e4_launch_nt(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32
     int per = target / nconc;
     if (per < 1) per = 1;
     const u32 cap_bits = (u32)(32u * NT) * lmax_win;
-    if (g_sfe_variant == 5 || d_redo)
-        hipLaunchKernelGGL((sfe5_kernel<NW, L16, NT>), dim3((u32)(nconc * per)), dim3(NT), dyn, st, dblk, count, nconc, d_desc, d_tickets,
-                           win_stride, cap_bits, d_redo, redo_only);
-    else
-        hipLaunchKernelGGL((sfe4_kernel<NW, L16, NT>), dim3((u32)(nconc * per)), dim3(NT), dyn, st, dblk, count, nconc, d_desc, d_tickets,
-                           win_stride);
+    hipLaunchKernelGGL((sfe5_kernel<NW, L16, NT>), dim3((u32)(nconc * per)), dim3(NT), dyn, st, dblk, count, nconc, d_desc, d_tickets,
+                       win_stride, cap_bits, d_redo, redo_only);
     if (any_ragged)
         hipLaunchKernelGGL((sfe4_tail_kernel<NW, L16, NT>), dim3((u32)count), dim3(NT), (size_t)tail_stride * 4, st, dblk,
                            (const u64 *)d_desc, tail_stride, (const u32 *)(redo_only ? d_redo : nullptr), (const u64 *)nullptr);
+    HIP_TRY(hipGetLastError());
     return SHAFA_SUCCESS;
 }
 
@@ -509,13 +337,13 @@ template <int NW, bool L16>
 int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, u32 ragged, const SfeRedo &x)
 {
     const bool ragged8 = ragged & 1u, ragged16 = ragged & 2u, ragged32 = ragged & 4u;
-    if (g_sfe_lanes == 512 && g_sfe_variant == 5)
+    if (g_sfe_lanes == 512)
         return e4_launch_nt<NW, L16, 512>(st, dblk, count, d_desc, d_tickets, lmax, lmax, ragged16, nullptr, 0);
     if (g_sfe_lanes == 256 || !g_sfe4_wide)
         return e4_launch_nt<NW, L16, 256>(st, dblk, count, d_desc, d_tickets, lmax, lmax, ragged8, nullptr, 0);
     const u32 wbits = e5_window_bits(lmax);
     if (wbits == lmax) return e4_launch_nt<NW, L16, 1024>(st, dblk, count, d_desc, d_tickets, lmax, lmax, ragged32, nullptr, 0);
-    if (g_sfe_variant != 5 || !x.redo)                 // the atomic-OR form has no fall-back: its 256-lane form holds the worst case
+    if (!x.redo)                                       // no second chain at hand: the 256-lane form holds the worst case
         return e4_launch_nt<NW, L16, 256>(st, dblk, count, d_desc, d_tickets, lmax, lmax, ragged8, nullptr, 0);
     int rc = e4_launch_nt<NW, L16, 1024>(st, dblk, count, d_desc, d_tickets, wbits, lmax, ragged32, x.redo, 0);
     if (rc) return rc;
@@ -524,25 +352,18 @@ int e4_launch_t(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 
 
 }  // namespace
 
-#ifdef E4_STAMPS
-extern "C" int shafa_e4_read_stamps(unsigned long long *dst, int n)
-{
-    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(e4_stamp_buf), (size_t)n * 8) == hipSuccess ? 0 : 9;
-}
-#endif
-
 // launched from sfenc_launch (sf_encode.hip) for blocks whose codes are <= 16 bits when the launch holds enough blocks
 // to keep every chain short; desc (one u64 per tile) and tickets (one u32 per block) are zeroed by the caller;
 // tables are 256 x u64 {code, len}
 // does a launch with this longest code run the wide form with windows smaller than its worst case (then it needs `x`)?
 bool sfenc4_needs_redo(u32 lmax)
 {
-    return g_sfe_variant == 5 && g_sfe4_wide && g_sfe_lanes == 0 && e5_window_bits(lmax) < lmax;
+    return g_sfe4_wide && g_sfe_lanes == 0 && e5_window_bits(lmax) < lmax;
 }
 
 // can launches of codes of 17..32 bits take the one-pass encoder (quad form)?  It always runs with windows smaller than
 // its worst case, so it needs the second chain.
-bool sfenc4_long_ok() { return g_sfe_variant == 5 && g_sfe4_wide && g_sfe_lanes == 0; }
+bool sfenc4_long_ok() { return g_sfe4_wide && g_sfe_lanes == 0; }
 
 // blocks whose codes are 17..32 bits (tables 256 x u64 {code, len}, len = 1 << 16 for a symbol without a code)
 int sfenc4_launch_long(hipStream_t st, const EncBlk *dblk, int count, u64 *d_desc, u32 *d_tickets, u32 lmax, u32 ragged, const SfeRedo &x)

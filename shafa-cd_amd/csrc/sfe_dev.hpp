@@ -305,7 +305,7 @@ __device__ __forceinline__ void store_window5(const u32 *pwin, u8 *out, u64 out_
 }
 
 // =====================================================================================================================
-// sfe5: the same three-stage pipeline with a window that is filled by PLAIN LDS stores (no atomics, no zeroing).
+// Windows filled by PLAIN LDS stores (no atomics, no zeroing): sfe5_kernel (sf_encode4.hip) and sfe6_kernel (sf_encode6.hip).
 //
 // A lane owns 32 CONSECUTIVE symbols of the tile (four octs), so its bit string is ~6 dwords long and all but its two
 // end dwords belong to it alone.  An oct that covers window bits [s, e) stores every dword it has bits in EXCEPT the one
@@ -316,8 +316,9 @@ __device__ __forceinline__ void store_window5(const u32 *pwin, u8 *out, u64 out_
 // lane adds the final partial dword and a zero behind it (the padding of a block's last byte).  Model with the algebra
 // checked against a direct concatenation: tools/model/sfe5_model.py.
 //
-// Per lane and tile: 32 table look-ups and <= 12 exec-masked ds_write_b32 instead of 32 look-ups, 16 ds_or_b32 and the
-// window zeroing (sfe4: LDS pipe busy 60 % of the time, half of it bank conflicts of the atomics and look-ups).
+// Per lane and tile: 32 table look-ups and <= 12 ds_write_b32 (a store that is not due goes to the lane's dump word)
+// where round 2's atomic-OR windows took 32 look-ups, 16 ds_or_b32 and a zeroing pass (`place`, kept for the ragged-tail
+// kernels, whose strings may be shorter than a dword).
 // =====================================================================================================================
 #ifndef E5_STORE_W0
 #define E5_STORE_W0 1                                  // the waves E5_STORE_W0 .. NWV-1 store the resolved window

@@ -47,7 +47,7 @@ def test_library_exports_nothing_but_the_declared_symbols(shafa):
     assert shafa.lib().shafa_hip_set_option(b"sf_encode_one_pass_min_blocks", 0) == shafa.SUCCESS
     for v in (0, 2, 1):
         assert shafa.lib().shafa_hip_set_option(b"sf_decode_speculate", v) == shafa.SUCCESS
-    for name, good, bad in ((b"sf_encode_variant", (4, 5), 6), (b"sf_encode_lanes", (256, 512, 0), 100),
+    for name, good, bad in ((b"sf_encode_lanes", (256, 512, 0), 100),
                             (b"sf_encode_window_bits", (4, 16, 0), 17), (b"sf_decode_path", (1, 2, 0), 3), (b"rle_encode_general", (1, 0), None)):
         for v in good:
             assert shafa.lib().shafa_hip_set_option(name, v) == shafa.SUCCESS, (name, v)

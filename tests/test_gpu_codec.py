@@ -360,14 +360,13 @@ def test_sf_decode_codes_of_17_to_32_bits_fast_path(oracle, shafa):
         assert rc == shafa.FILE_UNRECOGNIZABLE
 
 
-DEFAULT_OPTIONS = {"sf_encode_one_pass_min_blocks": 0, "sf_encode_variant": 5, "sf_encode_lanes": 0, "sf_encode_window_bits": 0,
+DEFAULT_OPTIONS = {"sf_encode_one_pass_min_blocks": 0, "sf_encode_lanes": 0, "sf_encode_window_bits": 0,
                    "sf_decode_speculate": 1, "sf_decode_path": 0, "rle_encode_general": 0}
 
 
 @pytest.mark.parametrize("options", [
     {"sf_encode_one_pass_min_blocks": 1 << 30},                            # count / scan / pack kernels (sfe3_*) for every launch
     {"sf_encode_one_pass_min_blocks": 1},                                  # the one-pass kernel even for one block
-    {"sf_encode_one_pass_min_blocks": 1, "sf_encode_variant": 4},          # ... with atomic-OR windows (sfe4_kernel)
     {"sf_encode_one_pass_min_blocks": 1, "sf_encode_lanes": 256},          # ... 256-lane workgroups, 8 KiB tiles
     {"sf_encode_one_pass_min_blocks": 1, "sf_encode_lanes": 512},          # ... 512-lane workgroups, 16 KiB tiles
     {"sf_encode_one_pass_min_blocks": 1, "sf_encode_window_bits": 4},      # ... windows too small: flagged, encoded again (256 lanes)

@@ -9,15 +9,13 @@ from test_gpu_parity import first_diff, long_code_case, to_shafa_table
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[5, 4], ids=["plain_store_windows", "atomic_or_windows"])
-def one_pass(shafa, request):
-    """Every test runs on both window forms of the one-pass kernel (sfe5_kernel, the default, and sfe4_kernel)."""
+@pytest.fixture
+def one_pass(shafa):
+    """The chained one-pass kernel (sfe5_kernel) whatever the number of blocks in the launch."""
     shafa.lib().shafa_hip_init(0)
     shafa.set_option("sf_encode_one_pass_min_blocks", 1)
-    shafa.set_option("sf_encode_variant", request.param)
     yield
     shafa.set_option("sf_encode_one_pass_min_blocks", 0)
-    shafa.set_option("sf_encode_variant", 5)
 
 
 def run_batch(shafa, oracle, blocks, tables, caps=None, expect_err=None):

@@ -14,7 +14,7 @@ import pkgload
 pkg = pkgload.load()
 pkg.lib().shafa_hip_init(0)
 if len(sys.argv) > 1:
-    pkg.set_option("sf_encode_variant", int(sys.argv[1]))
+    pass  # (the atomic-OR window form this switch selected was removed in round 4)
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(device=dev)
 nb, bs = 64, 64 << 20
