@@ -100,6 +100,46 @@ void *batch_stage(Batch *b, hipStream_t st, size_t bytes)
     return b->h_stage + off;
 }
 
+u8 *batch_params_begin(Batch *b, size_t bytes)
+{
+    if (!b->copy_st) {
+        if (hipStreamCreateWithFlags(&b->copy_st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (int i = 0; i < 2; ++i)
+            if (hipEventCreateWithFlags(&b->par_ready[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&b->par_free[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    const int i = b->par_turn;
+    b->par_turn ^= 1;
+    b->par_cur = i;
+    if (bytes > b->par_bytes[i]) {                     // grow: the kernels that read the old buffer must be through
+        if (b->par_used[i] && hipEventSynchronize(b->par_free[i]) != hipSuccess) return nullptr;
+        if (b->d_par[i]) (void)hipFree(b->d_par[i]);
+        b->d_par[i] = nullptr;
+        b->par_bytes[i] = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipMalloc(&b->d_par[i], want) != hipSuccess) return nullptr;
+        b->par_bytes[i] = want;
+    }
+    return (u8 *)b->d_par[i];
+}
+
+int batch_params_commit(Batch *b, hipStream_t st, const void *hs, size_t bytes)
+{
+    const int i = b->par_cur;
+    if (b->par_used[i]) HIP_TRY(hipStreamWaitEvent(b->copy_st, b->par_free[i], 0));
+    HIP_TRY(hipMemcpyAsync(b->d_par[i], hs, bytes, hipMemcpyHostToDevice, b->copy_st));
+    HIP_TRY(hipEventRecord(b->par_ready[i], b->copy_st));
+    HIP_TRY(hipStreamWaitEvent(st, b->par_ready[i], 0));
+    return SHAFA_SUCCESS;
+}
+
+int batch_params_done(Batch *b, hipStream_t st)
+{
+    HIP_TRY(hipEventRecord(b->par_free[b->par_cur], st));
+    b->par_used[b->par_cur] = true;
+    return SHAFA_SUCCESS;
+}
+
 void batch_stage_retire(Batch *b, hipStream_t st)
 {
     if (!b->segs) return;
@@ -190,6 +230,12 @@ void shafa_hipd_batch_destroy(shafa_hipd_batch *hb)
     DeviceGuard dg(b->device);                     // the batch's device, whatever the caller's current device is
     if (b->has_last) (void)hipStreamSynchronize(b->last_st);
     hipDeviceSynchronize();
+    if (b->copy_st) {
+        (void)hipStreamDestroy(b->copy_st);
+        for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(b->par_ready[i]); (void)hipEventDestroy(b->par_free[i]); }
+    }
+    for (int i = 0; i < 2; ++i)
+        if (b->d_par[i]) hipFree(b->d_par[i]);
     if (b->d_ws) hipFree(b->d_ws);
     if (b->segs) {
         for (StageSeg &sg : *b->segs) seg_release(sg, false);
@@ -296,6 +342,7 @@ int shafa_hipd_finish(shafa_hipd_batch *hb, void *stream, int nblocks, int *h_bl
     }
     HIP_TRY(hipStreamSynchronize(st));
     batch_stage_retire(b, st);
+    if (b->copy_st) batch_stage_retire(b, b->copy_st);  // `st` waited for every parameter copy: they are through as well
     int first = SHAFA_SUCCESS;
     for (int i = 0; i < nblocks; ++i) {
         const int e = b->h_hosterr[i] ? b->h_hosterr[i] : b->h_err[i];

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(HIST_THREADS) void hist256_kernel(const HistBlk *__
 // read before the next tile's counts arrive.
 __global__ __launch_bounds__(HIST_THREADS) void hist256_tiles_kernel(const HistBlk *__restrict__ blks)
 {
-    __shared__ u32 h[256 * HIST_REP];
+    __shared__ __attribute__((aligned(16))) u32 h[256 * HIST_REP];
     const int tid = threadIdx.x;
     const HistBlk blk = blks[blockIdx.y];
     const u64 n = blk.n_dev ? *blk.n_dev : blk.n;
@@ -109,9 +109,13 @@ __global__ __launch_bounds__(HIST_THREADS) void hist256_tiles_kernel(const HistB
             else for (u64 q = p; q < te; ++q) atomicAdd(&h[(u32)blk.in[q] * HIST_REP + rep], 1u);
         }
         __syncthreads();
-        u32 c = 0;
+        u32 c = 0;                                     // the lane's 32 replicas as eight 16-byte reads, rotated by tid / 2: the
+        const uint4 *row = (const uint4 *)(h + tid * HIST_REP);          //   sixteen lanes of an LDS pass hit sixteen bank quads
 #pragma unroll
-        for (int r = 0; r < HIST_REP; ++r) c += h[tid * HIST_REP + ((r + tid) & (HIST_REP - 1))];
+        for (int j = 0; j < HIST_REP / 4; ++j) {
+            const uint4 v = row[(j + (tid >> 1)) & (HIST_REP / 4 - 1)];
+            c += v.x + v.y + v.z + v.w;
+        }
         th[tid] = (u16)(c - prev);
         prev = c;
         __syncthreads();

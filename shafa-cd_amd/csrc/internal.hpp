@@ -33,6 +33,15 @@ struct Batch {
     int *d_err;            // one error code per block (first error wins)
     int *h_err;            // pinned mirror
     int *h_hosterr;        // errors found on the host while preparing a launch (malformed tables)
+    // Parameter records and code tables of a launch travel on a SIDE stream into one of two device buffers, so that the
+    // copy (and its hand-over between the copy engine and the compute queue, ~50-100 us either way) overlaps the kernels of
+    // the launch before instead of sitting between two launches: batch_params_begin / _commit / _done.
+    hipStream_t copy_st;
+    void *d_par[2];
+    size_t par_bytes[2];
+    hipEvent_t par_ready[2], par_free[2];
+    bool par_used[2];
+    int par_turn, par_cur;
 };
 
 // Every layer-2 entry point starts with this: checks that the calling thread's current device is the batch's, and
@@ -61,6 +70,16 @@ int batch_reserve(Batch *b, hipStream_t st, size_t bytes);
 void *batch_stage(Batch *b, hipStream_t st, size_t bytes);
 // every copy enqueued on `st` so far has completed (the caller synchronised `st`): release its regions
 void batch_stage_retire(Batch *b, hipStream_t st);
+
+// Parameters of a launch (records + tables), uploaded off the launch stream:
+//   d = batch_params_begin(b, bytes)          the device buffer the launch's parameters will live in (records may point into it)
+//   hs = batch_stage(b, b->copy_st, bytes)    pinned staging, filled by the caller
+//   batch_params_commit(b, st, hs, bytes)     copy on the side stream (after the kernels that last read this buffer); `st` waits for it
+//   ... kernels on `st` ...
+//   batch_params_done(b, st)                  the buffer is free again once these kernels have run
+u8 *batch_params_begin(Batch *b, size_t bytes);
+int batch_params_commit(Batch *b, hipStream_t st, const void *hs, size_t bytes);
+int batch_params_done(Batch *b, hipStream_t st);
 
 // ---- per-op parameter records (device arrays) --------------------------------------------------
 struct EncBlk {

@@ -2285,7 +2285,11 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     if (rc) return rc;
     u8 *ws = (u8 *)bt->d_ws;
 
-    u8 *hs = (u8 *)batch_stage(bt, st, stage_bytes);
+    // the records, the blocks' run_dp words and the tables travel on the side stream into a parameter buffer of their own
+    // (batch_params_*): the copy overlaps the launch before this one instead of sitting in front of sfd_tables
+    u8 *dpar = batch_params_begin(bt, stage_bytes);
+    if (!dpar) return SHAFA_LACK_OF_MEMORY;
+    u8 *hs = (u8 *)batch_stage(bt, bt->copy_st, stage_bytes);
     if (!hs) return SHAFA_LACK_OF_MEMORY;
     DecBlk *hb = (DecBlk *)hs;
     size_t tpos = o_tab;
@@ -2300,7 +2304,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         e.err = bt->d_err + b;
         e.n_tiles = ntiles[b];
         e.tile_base = tbase;
-        e.run_dp = any_spec ? (u32 *)(ws + o_rundp) + b : nullptr;
+        e.run_dp = any_spec ? (u32 *)(dpar + o_rundp) + b : nullptr;
         ((u32 *)(hs + o_rundp))[b] = spec_blk[b] ? 0u : 1u;               // 1: straight to the exact kernels
         e.pairlut = pair_all ? ws + o_pair + (size_t)b * (2u << LEN_MAXK) : nullptr;
         e.cnt3 = need_tabs ? (u16 *)(ws + o_cnt3 + (size_t)b * (2u << LEN_MAXK)) : nullptr;
@@ -2315,42 +2319,42 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         e.KW = hblk_kw[b];
         e.lmax = h.lmax;
         e.n_states = (u32)(h.trie.size() / 2);
-        e.lut2 = (const u16 *)(ws + tpos);
+        e.lut2 = (const u16 *)(dpar + tpos);
         e.n_l2 = (u32)h.lut2.size();
         if (h.lut2.size()) memcpy(hs + tpos, h.lut2.data(), h.lut2.size() * 2);
         tpos += (h.lut2.size() * 2 + 16 + 15) & ~(size_t)15;
-        e.lut13 = (const u16 *)(ws + tpos);
+        e.lut13 = (const u16 *)(dpar + tpos);
         memcpy(hs + tpos, h.lut13.data(), h.lut13.size() * 2);
         tpos += (h.lut13.size() * 2 + 15) & ~(size_t)15;
         if (!h.longtab.empty()) {
-            e.longtab = (const u16 *)(ws + tpos);
+            e.longtab = (const u16 *)(dpar + tpos);
             memcpy(hs + tpos, h.longtab.data(), LONG_BYTES);
             tpos += LONG_BYTES;
         }
         if (!h.long32.empty()) {
-            e.long32 = (const u16 *)(ws + tpos);
+            e.long32 = (const u16 *)(dpar + tpos);
             memcpy(hs + tpos, h.long32.data(), LONG32_BYTES);
             tpos += (LONG32_BYTES + 15) & ~15;
         }
         if (!h.lenlut32.empty()) {
-            e.lenlut32 = ws + tpos;
+            e.lenlut32 = dpar + tpos;
             memcpy(hs + tpos, h.lenlut32.data(), h.lenlut32.size());
             tpos += (h.lenlut32.size() + 15) & ~(size_t)15;
         }
-        e.lenlut = ws + tpos;
+        e.lenlut = dpar + tpos;
         if (!e.lenlut32) e.lenlut32 = e.lenlut;            // no code longer than 13 bits: the plain table
         memcpy(hs + tpos, h.lenlut.data(), h.lenlut.size());
         tpos += (h.lenlut.size() + 15) & ~(size_t)15;
-        e.lut = (const u16 *)(ws + tpos);
+        e.lut = (const u16 *)(dpar + tpos);
         memcpy(hs + tpos, h.lut.data(), h.lut.size() * 2);
         tpos += (h.lut.size() * 2 + 15) & ~(size_t)15;
-        e.trie = (const u32 *)(ws + tpos);
+        e.trie = (const u32 *)(dpar + tpos);
         memcpy(hs + tpos, h.trie.data(), h.trie.size() * 4);
         tpos += (h.trie.size() * 4 + 15) & ~(size_t)15;
     }
-    HIP_TRY(hipMemcpyAsync(ws, hs, stage_bytes, hipMemcpyHostToDevice, st));
+    if ((rc = batch_params_commit(bt, st, hs, stage_bytes))) return rc;
 
-    const DecBlk *dblk = (const DecBlk *)(ws + o_blk);
+    const DecBlk *dblk = (const DecBlk *)(dpar + o_blk);
     const size_t lds_data = (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
     const size_t lds_lut = (size_t)(1u << LUT_MAXK) * 2 + (size_t)((max_l2 + 8) & ~7u) * 2;
     const size_t lds_sync = lds_data + (size_t)R * DEC_THREADS + lds_lut + 4 * R + 64;
@@ -2525,5 +2529,5 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
                            (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff));
     }
     HIP_TRY(hipGetLastError());
-    return SHAFA_SUCCESS;
+    return batch_params_done(bt, st);
 }

@@ -280,7 +280,8 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const u64 ndesc = total_tiles[1] + total_tiles[2] + total_tiles[3];
     if (ndesc >= 0xFFFFFFFFull) return SHAFA_LACK_OF_MEMORY;
 
-    // device workspace: [desc u64 * ndesc][tickets u32 * nblocks] (zeroed) [tile bits u32 * ndesc][EncBlk * nblocks][tables]
+    // device workspace: [desc u64 * ndesc][tickets u32 * nblocks] (zeroed) [tile bits u32 * ndesc]; the parameter buffer
+    // (uploaded on the side stream, batch_params_*): [EncBlk * nblocks][tables]
     const size_t tab1 = one_pass ? 2048 : 1024;
     size_t off = 0;
     const size_t o_desc = off; off += ndesc * 8;
@@ -290,19 +291,22 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const size_t o_redo = off; off += redo ? (size_t)nblocks * 4 : 0; off = (off + 15) & ~(size_t)15;
     const size_t o_zero_end = off;
     const size_t o_tbits = off; off += ndesc * 4; off = (off + 15) & ~(size_t)15;
+    const size_t ws_bytes = off;
     const size_t o_blk = off; off += (size_t)nblocks * sizeof(EncBlk); off = (off + 15) & ~(size_t)15;
     const size_t o_tab = off;
     size_t tab_bytes = 0;
     for (int b = 0; b < nblocks; ++b)
         tab_bytes += cls[b] == 1 ? tab1 : cls[b] == 2 ? 2048 : cls[b] == 3 ? ((sizeof(shafa_code_table) + 15) & ~15ul) : 0;
     off += tab_bytes;
-    int rc = batch_reserve(bt, st, off);
+    int rc = batch_reserve(bt, st, ws_bytes);
     if (rc) return rc;
     u8 *ws = (u8 *)bt->d_ws;
 
-    // host staging: EncBlk array + tables, one H2D copy
+    // host staging: EncBlk array + tables, one H2D copy on the side stream
     const size_t stage_bytes = off - o_blk;
-    u8 *hs = (u8 *)batch_stage(bt, st, stage_bytes);
+    u8 *dpar = batch_params_begin(bt, stage_bytes);
+    if (!dpar) return SHAFA_LACK_OF_MEMORY;
+    u8 *hs = (u8 *)batch_stage(bt, bt->copy_st, stage_bytes);
     if (!hs) return SHAFA_LACK_OF_MEMORY;
     EncBlk *hb = (EncBlk *)hs;
     u8 *htab = hs + (o_tab - o_blk);
@@ -329,7 +333,7 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
             e.pad = 0;
             e.thist = (c == 1 && tiles) ? d_thist + h_thist_off[b] : nullptr;
             dbase += e.n_tiles + (c == 1 && tiles ? 1 : 0);
-            e.lut = ws + o_tab + tpos;
+            e.lut = dpar + (o_tab - o_blk) + tpos;
             const shafa_code_table &t = h_tables[b];
             if (c == 1 && one_pass) {                 // {code, len}; a symbol without a code: len = 1 << 16
                 u64 *l = (u64 *)(htab + tpos);
@@ -356,11 +360,11 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     }
     const bool need_desc = cls_count[3] || (cls_count[1] && one_pass && !tiles) || one_pass2;
     if (o_zero_end && need_desc) HIP_TRY(hipMemsetAsync(ws, 0, o_zero_end, st));
-    HIP_TRY(hipMemcpyAsync(ws + o_blk, hs, stage_bytes, hipMemcpyHostToDevice, st));
+    if ((rc = batch_params_commit(bt, st, hs, stage_bytes))) return rc;
     for (int b = 0; b < nblocks; ++b)
         if (cls[b] == 0) HIP_TRY(hipMemsetAsync(d_out_n + b, 0, 8, st));
 
-    const EncBlk *dblk = (const EncBlk *)(ws + o_blk);
+    const EncBlk *dblk = (const EncBlk *)dpar;
     u64 *ddesc = (u64 *)(ws + o_desc);
     u32 *dtick = (u32 *)(ws + o_tick);
     if (cls_count[1] && tiles) {                       // tile offsets from the histograms: u64 per entry in the descriptor area,
@@ -389,5 +393,5 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         hipLaunchKernelGGL(sf_encode_generic, dim3(max_tiles[3] * cls_count[3]), dim3(ENC_THREADS), 0, st,
                            dblk + cls_first[3], cls_count[3], ddesc, dtick);
     HIP_TRY(hipGetLastError());
-    return SHAFA_SUCCESS;
+    return batch_params_done(bt, st);
 }
