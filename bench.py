@@ -83,7 +83,10 @@ def parse_args(argv=None):
     ap.add_argument("--pipeline-blocks", type=int, default=32,
                     help="blocks of the pipeline leg (`pipeline` object: per-family times and roofline fractions of K1, K2, K5 "
                          "on run-heavy data at this block size; bounded, a fraction of a second of GPU time)")
-    ap.add_argument("--no-pipeline", action="store_true", help="skip the pipeline leg")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the pipeline legs")
+    ap.add_argument("--pipeline-only", action="store_true",
+                    help="run one pipeline leg and nothing else (for profiles of the leg alone: tools/gpu_prof.sh <tag> --pipeline-only --pipeline-kind K)")
+    ap.add_argument("--pipeline-kind", default=None, choices=["runs", "mixed"], help="the leg's data (default: both legs)")
     ap.add_argument("--no-host-path", action="store_true",
                     help="skip the `host_path` object (layer-3 pipe PCIe-inclusive rates and the CLI end to end on a tmpfs file)")
     ap.add_argument("--host-path-blocks", type=int, default=32)
@@ -296,13 +299,13 @@ def host_path_leg(args, pkg, torch, dev, d_in):
     return out
 
 
-def pipeline_key(args, nb):
-    return f"pipeline:{args.block_mib}:{nb}"
+def pipeline_key(args, nb, kind):
+    return f"pipeline:{kind}:{args.block_mib}:{nb}"
 
 
 def measured_pipeline_traffic(pkey):
-    """per-kernel HBM bytes per launch of the pipeline leg from the newest profiles/*_traffic.json with this csrc hash
-    and pipeline key (tools/gpu_prof.sh); None otherwise."""
+    """per-kernel HBM bytes per launch of a pipeline leg from the newest profiles/*_traffic.json with this csrc hash
+    and pipeline key (tools/gpu_prof.sh <tag> --pipeline-only --pipeline-kind <kind>); None otherwise."""
     pdir = os.path.join(ROOT, "profiles")
     best = None
     for fn in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -317,15 +320,40 @@ def measured_pipeline_traffic(pkey):
     return best
 
 
-def pipeline_leg(args, pkg, torch, dev, st, steps, nb):
-    """F (RLE + histogram of the RLE bytes) -> T (host) -> C (SF encode of the RLE bytes), then D (SF decode + RLE
-    decode) on run-heavy data (Zipf symbols in geometric runs, cfg-2 shape); per-family HIP-event times and
-    algorithmic-byte rooflines."""
+PIPELINE_KINDS = {
+    "runs": "Zipf(1.2) symbols in geometric runs (p = 0.35): RLE has work on every block (cfg-0 shape at -b M)",
+    "mixed": "cfg[2] stand-in, the statistics of tests/golden/full_mixed_M: block 0 a binary section (records, zero / 0xFF "
+             "padding runs), the other blocks dictionary text; block 0 accepts RLE for the whole file (f.c:250-258), so the "
+             "text blocks are RLE-coded although they gain nothing",
+}
+
+
+def pipeline_blocks(kind, synth, torch, dev, bs, nb):
+    """the leg's input, resident: nb blocks of bs bytes"""
+    import numpy as np
+    if kind == "runs":
+        blk = torch.from_numpy(synth.runs_stream(11, bs, synth.zipf_table(1.2))).to(dev)
+        return blk.repeat(nb)
+    # generated in 8 MiB units on the host (the generators are numpy, seconds per 8 MiB) and tiled to the block size: the codec
+    # has no memory beyond a run of bytes, so a block's RLE and Shannon-Fano statistics are its unit's
+    unit = min(bs, 8 << 20)
+    binu = torch.from_numpy(synth.binary_stream(21, unit)).to(dev)
+    txtu = torch.from_numpy(synth.text_stream(22, unit)).to(dev)
+    out = torch.empty(nb * bs, dtype=torch.uint8, device=dev)
+    for b in range(nb):
+        u = binu if b == 0 else torch.roll(txtu, 4099 * b)
+        out[b * bs:(b + 1) * bs] = u.repeat(bs // unit)
+    return out
+
+
+def pipeline_leg(args, pkg, torch, dev, st, steps, nb, kind):
+    """F (RLE + histogram of the RLE bytes + their tile histograms) -> T (host) -> C (SF encode of the RLE bytes), then D (SF
+    decode + RLE decode); per-family HIP-event times and algorithmic-byte rooflines; per-family HBM
+    traffic from the PMC passes of a profile of THIS code and THIS leg alone, else null."""
     import numpy as np
     synth = load_pkg("synth")
     bs = args.block_mib << 20
-    blk = torch.from_numpy(synth.runs_stream(11, bs, synth.zipf_table(1.2))).to(dev)
-    d_in = blk.repeat(nb)
+    d_in = pipeline_blocks(kind, synth, torch, dev, bs, nb)
     bt = pkg.Batch(nb, 2 * bs + 64)
     off, n = [b * bs for b in range(nb)], [bs] * nb
     rcap = 2 * bs + 64
@@ -333,6 +361,9 @@ def pipeline_leg(args, pkg, torch, dev, st, steps, nb):
     d_rle = torch.empty(nb * rcap, dtype=torch.uint8, device=dev)
     d_rle_n = torch.zeros(nb, dtype=torch.int64, device=dev)
     d_freq = torch.zeros(nb * 256, dtype=torch.int64, device=dev)
+    thb = pkg.tile_hist_bytes(rcap)
+    thoff = [b * thb for b in range(nb)]
+    d_th = torch.zeros(nb * thb, dtype=torch.uint8, device=dev)
 
     def timed(fn):
         torch.cuda.synchronize()
@@ -346,9 +377,10 @@ def pipeline_leg(args, pkg, torch, dev, st, steps, nb):
         bt.finish(st, nb)
         return e0.elapsed_time(e1) / steps * 1e-3
 
-    out = {"workload": f"{nb} x {args.block_mib} MiB blocks of Zipf(1.2) symbols in geometric runs (p=0.35)"}
-    t_h = timed(lambda: bt.hist256(st, d_in, off, n, d_freq))
-    t_f = timed(lambda: bt.rle_encode(st, d_in, off, n, d_rle, roff, [rcap] * nb, d_rle_n, d_freq))
+    out = {"workload": f"{nb} x {args.block_mib} MiB blocks: " + PIPELINE_KINDS[kind]}
+    # K1: make_freq of the input with its tile histograms (what Module F leaves when RLE is declined, f.c:325)
+    t_h = timed(lambda: bt.hist256_tiles(st, d_in, off, n, d_freq, d_th, [b * pkg.tile_hist_bytes(bs) for b in range(nb)]))
+    t_f = timed(lambda: bt.rle_encode_tiles(st, d_in, off, n, d_rle, roff, [rcap] * nb, d_rle_n, d_freq, d_th, thoff))
     rle_n = [int(x) for x in d_rle_n.cpu().numpy()]
     freq = d_freq.cpu().numpy().astype(np.uint64).reshape(nb, 256)
     t0 = time.perf_counter()
@@ -360,7 +392,7 @@ def pipeline_leg(args, pkg, torch, dev, st, steps, nb):
     eoff = [b * cap for b in range(nb)]
     d_enc = torch.empty(nb * cap, dtype=torch.uint8, device=dev)
     d_enc_n = torch.zeros(nb, dtype=torch.int64, device=dev)
-    t_c = timed(lambda: bt.sf_encode(st, d_rle, roff, rle_n, tables, d_enc, eoff, [cap] * nb, d_enc_n))
+    t_c = timed(lambda: bt.sf_encode_tiles(st, d_rle, roff, rle_n, tables, d_th, thoff, d_enc, eoff, [cap] * nb, d_enc_n))
     assert [int(x) for x in d_enc_n.cpu().numpy()] == enc_bytes
     d_sym = torch.empty(nb * rcap, dtype=torch.uint8, device=dev)
     t_ds = timed(lambda: bt.sf_decode(st, d_enc, eoff, enc_bytes, tables, rle_n, d_sym, roff))
@@ -369,34 +401,39 @@ def pipeline_leg(args, pkg, torch, dev, st, steps, nb):
     d_dec = torch.empty(nb * dcap, dtype=torch.uint8, device=dev)
     d_dec_n = torch.zeros(nb, dtype=torch.int64, device=dev)
     t_dr = timed(lambda: bt.rle_decode(st, d_sym, roff, rle_n, d_dec, doff, [bs + 1024] * nb, d_dec_n))
-    assert [int(x) for x in d_dec_n.cpu().numpy()] == n and torch.equal(d_dec[:bs], blk), "pipeline round trip differs"
+    assert [int(x) for x in d_dec_n.cpu().numpy()] == n, "pipeline round trip: sizes differ"
+    for b in range(nb):
+        assert torch.equal(d_dec[doff[b]:doff[b] + bs], d_in[off[b]:off[b] + bs]), f"pipeline round trip differs in block {b}"
     tot, rle_tot, enc_tot = float(nb * bs), float(sum(rle_n)), float(sum(enc_bytes))
 
-    def fam(alg, t, name=None):
-        d = {"ms": t * 1e3, "algorithmic_bytes": alg, "achieved_GBs": alg / t / 1e9, "frac": alg / t / 1e9 / HBM_PEAK_GBS,
-             "GiBs_of_original": tot / GIB / t}
-        if name in traffic:
-            d["traffic"] = traffic[name]
-        return d
-
-    # HBM traffic of the RLE kernels from the PMC passes of a profile of THIS code and leg (else null)
-    traffic = {"K1_hist256": None, "K2_rle_encode_hist": None, "K5_rle_decode": None}
+    # HBM traffic per family: the PMC passes (FETCH_SIZE x 2, WRITE_SIZE; separate runs) of a profile of this tree taken with
+    # `--pipeline-only --pipeline-kind <kind>`, every kernel of the family summed; null without such a profile
+    fams = {"K1_hist256": lambda k: k.startswith("hist256") and "<false>" in k,
+            "K2_rle_encode_hist": lambda k: k.startswith("rle3_") or (k.startswith("hist256") and "<true>" in k),
+            "K3_sf_encode": lambda k: k.startswith("sfe"),
+            "K4_sf_decode": lambda k: k.startswith("sfd_"),
+            "K5_rle_decode": lambda k: k.startswith("rle_decode")}
+    traffic = {k: None for k in fams}
     tsrc = None
-    m = measured_pipeline_traffic(pipeline_key(args, nb))
+    m = measured_pipeline_traffic(pipeline_key(args, nb, kind))
     if m:
         pk = m[1]["per_kernel_bytes"]
-        tot_of = lambda pred: sum(v["read"] + v["written"] for k, v in pk.items() if pred(k))      # noqa: E731
-        rle3 = tot_of(lambda k: k.startswith("rle3_"))
-        if rle3:
-            traffic["K2_rle_encode_hist"] = rle3 + rle_tot     # + the fused histogram's one read of the RLE bytes
-        traffic["K5_rle_decode"] = tot_of(lambda k: k.startswith("rle_decode")) or None
-        traffic["K1_hist256"] = tot                             # hist256 reads its input once (PMC: 1.00 B/B)
+        for fam, pred in fams.items():
+            v = sum(x["read"] + x["written"] for k, x in pk.items() if pred(k))
+            traffic[fam] = v or None
         tsrc = f"profiles/{m[0]}"
+
+    def fam(alg, t, name):
+        return {"ms": t * 1e3, "algorithmic_bytes": alg, "achieved_GBs": alg / t / 1e9, "frac": alg / t / 1e9 / HBM_PEAK_GBS,
+                "GiBs_of_original": tot / GIB / t, "traffic": traffic[name]}
+
     out.update({"rle_ratio": rle_tot / tot, "sf_ratio_of_rle": enc_tot / rle_tot, "traffic_source": tsrc,
                 "K1_hist256": fam(tot, t_h, "K1_hist256"), "K2_rle_encode_hist": fam(tot + rle_tot, t_f, "K2_rle_encode_hist"),
-                "T_host_ms": t_t * 1e3, "K3_sf_encode": fam(rle_tot + enc_tot, t_c),
-                "K4_sf_decode": fam(enc_tot + rle_tot, t_ds), "K5_rle_decode": fam(rle_tot + tot, t_dr, "K5_rle_decode"),
-                "F_T_C_GiBs": tot / GIB / (t_f + t_t + t_c), "D_GiBs": tot / GIB / (t_ds + t_dr)})
+                "T_host_ms": t_t * 1e3, "K3_sf_encode": fam(rle_tot + enc_tot, t_c, "K3_sf_encode"),
+                "K4_sf_decode": fam(enc_tot + rle_tot, t_ds, "K4_sf_decode"), "K5_rle_decode": fam(rle_tot + tot, t_dr, "K5_rle_decode"),
+                "F_T_C_GiBs": tot / GIB / (t_f + t_t + t_c), "D_GiBs": tot / GIB / (t_ds + t_dr),
+                "tile_histograms": "K1 and K2 also write the 256 x u16 histogram of every 32 KiB tile (1.6 % of the bytes "
+                                   "they count), which lets K3 run as a one-shot grid (sf_encode6)"})
     bt.close()
     return out
 
@@ -427,6 +464,15 @@ def main():
     shard = nb * bs
     zt = dist_table(pkg, args)
     st = torch.cuda.Stream(device=dev)
+
+    if args.pipeline_only:                     # a profile of one leg alone (its kernels are not mixed with the headline's)
+        pnb = max(1, min(args.blocks, args.pipeline_blocks))
+        kind = args.pipeline_kind or "runs"
+        leg = pipeline_leg(args, pkg, torch, dev, st, args.steps, pnb, kind)
+        print(json.dumps({"metric": METRIC, "invalid": "--pipeline-only: no headline measurement", "pipeline_kind": kind,
+                          "config": {"blocks_per_gpu": pnb, "block_bytes": bs}, "pipeline": leg}), flush=True)
+        comm.close()
+        return
 
     # ---- resident inputs: this rank's shard of the global synthetic stream -----------------------
     d_in = torch.empty(shard, dtype=torch.uint8, device=dev)
@@ -627,15 +673,18 @@ def main():
         encode()                                           # restore d_enc for anything that follows
         bt.finish(st, nb)
 
-    pipe = None
+    pipe, pipe_mixed = None, None
     if not args.no_pipeline and rank == 0:
-        try:
-            pipe = pipeline_leg(args, pkg, torch, dev, st, 3,
-                                max(1, min(args.blocks, args.pipeline_blocks)))
-        except AssertionError:
-            raise                                      # a parity failure is never swallowed
-        except Exception as e:                         # (memory on a small device: the headline line must still come out)
-            pipe = {"error": f"{type(e).__name__}: {e}"[:300]}
+        pnb = max(1, min(args.blocks, args.pipeline_blocks))
+        legs = {}
+        for kind in ([args.pipeline_kind] if args.pipeline_kind else ["runs", "mixed"]):
+            try:
+                legs[kind] = pipeline_leg(args, pkg, torch, dev, st, 3, pnb, kind)
+            except AssertionError:
+                raise                                  # a parity failure is never swallowed
+            except Exception as e:                     # (memory on a small device: the headline line must still come out)
+                legs[kind] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        pipe, pipe_mixed = legs.get("runs"), legs.get("mixed")
 
     host_path = None
     profiled = any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
@@ -688,6 +737,8 @@ def main():
             out["scatter_gather"] = sg
         if pipe:
             out["pipeline"] = pipe
+        if pipe_mixed:
+            out["pipeline_mixed"] = pipe_mixed
         if host_path:
             out["host_path"] = host_path
         if world == 1 and not args.no_cpu:

@@ -20,6 +20,9 @@ constexpr int HIST_REP = 32;
 struct HistBlk { const u8 *in; u64 n; u64 *freq; const u64 *n_dev; u16 *thist; };
 constexpr u64 HIST_TILE = 32768;                       // SHAFA_TILE_BYTES: a tile of the sidecar (sf_encode6.hip)
 
+// OF_RLE: the launch that follows rle_encode on its output (f.c:310), sizes on the device — the same code under a name of its
+// own, so that a profile tells the two histograms of Module F apart
+template <bool OF_RLE>
 __global__ __launch_bounds__(HIST_THREADS) void hist256_kernel(const HistBlk *__restrict__ blks)
 {
     __shared__ u32 h[256 * HIST_REP];
@@ -67,7 +70,8 @@ __global__ __launch_bounds__(HIST_THREADS) void hist256_kernel(const HistBlk *__
 // 256 x u16 (a tile holds at most 32768 of one byte), at thist + 256 * tile.  The LDS replicas keep RUNNING totals over the
 // workgroup's eight tiles — nothing is zeroed between tiles; behind each tile every lane sums the 32 replicas of its symbol
 // and stores the difference to the previous sum.  Two barriers per tile: counts complete before they are summed, sums
-// read before the next tile's counts arrive.
+// read before the next tile's counts arrive; the next tile's loads are in flight meanwhile.
+template <bool OF_RLE>
 __global__ __launch_bounds__(HIST_THREADS) void hist256_tiles_kernel(const HistBlk *__restrict__ blks)
 {
     __shared__ __attribute__((aligned(16))) u32 h[256 * HIST_REP];
@@ -91,23 +95,10 @@ __global__ __launch_bounds__(HIST_THREADS) void hist256_tiles_kernel(const HistB
         }
     };
     constexpr u64 STEP = (u64)HIST_THREADS * 16;
+    constexpr int TL = (int)(HIST_TILE / STEP);        // 16-byte loads per lane and tile: 8
     u16 *th = blk.thist + (start / HIST_TILE) * 256;
     u32 prev = 0;
-    for (u64 ts = start; ts < end; ts += HIST_TILE, th += 256) {
-        const u64 te = ts + HIST_TILE < end ? ts + HIST_TILE : end;
-        u64 p = ts + (u64)tid * 16;
-        for (; p + 3 * STEP + 16 <= te; p += 4 * STEP) {   // four loads in flight per lane
-            const uint4 v0 = gload_nt<uint4>(blk.in + p), v1 = gload_nt<uint4>(blk.in + p + STEP);
-            const uint4 v2 = gload_nt<uint4>(blk.in + p + 2 * STEP), v3 = gload_nt<uint4>(blk.in + p + 3 * STEP);
-            count16(v0);
-            count16(v1);
-            count16(v2);
-            count16(v3);
-        }
-        for (; p < te; p += STEP) {
-            if (p + 16 <= te) count16(*(const uint4 *)(blk.in + p));
-            else for (u64 q = p; q < te; ++q) atomicAdd(&h[(u32)blk.in[q] * HIST_REP + rep], 1u);
-        }
+    auto sum_tile = [&]() {                            // behind the counts of a tile: its histogram = sums - previous sums
         __syncthreads();
         u32 c = 0;                                     // the lane's 32 replicas as eight 16-byte reads, rotated by tid / 2: the
         const uint4 *row = (const uint4 *)(h + tid * HIST_REP);          //   sixteen lanes of an LDS pass hit sixteen bank quads
@@ -118,7 +109,37 @@ __global__ __launch_bounds__(HIST_THREADS) void hist256_tiles_kernel(const HistB
         }
         th[tid] = (u16)(c - prev);
         prev = c;
+        th += 256;
         __syncthreads();
+    };
+    // full tiles: all eight loads of a tile in flight, and the NEXT tile's requested before this tile's barriers, so that the
+    // two barriers and the sums of a tile boundary do not leave the memory pipe idle
+    const u64 nfull = (end - start) / HIST_TILE;
+    uint4 cur[TL], nxt[TL];
+    if (nfull) {
+#pragma unroll
+        for (int k = 0; k < TL; ++k) cur[k] = gload_nt<uint4>(blk.in + start + (u64)k * STEP + (u64)tid * 16);
+    }
+    for (u64 t = 0; t < nfull; ++t) {
+        if (t + 1 < nfull) {
+            const u8 *nb = blk.in + start + (t + 1) * HIST_TILE + (u64)tid * 16;
+#pragma unroll
+            for (int k = 0; k < TL; ++k) nxt[k] = gload_nt<uint4>(nb + (u64)k * STEP);
+        }
+#pragma unroll
+        for (int k = 0; k < TL; ++k) count16(cur[k]);
+        sum_tile();
+#pragma unroll
+        for (int k = 0; k < TL; ++k) cur[k] = nxt[k];
+    }
+    const u64 ts = start + nfull * HIST_TILE;          // the block's ragged last tile
+    if (ts < end) {
+        u64 p = ts + (u64)tid * 16;
+        for (; p < end; p += STEP) {
+            if (p + 16 <= end) count16(*(const uint4 *)(blk.in + p));
+            else for (u64 q = p; q < end; ++q) atomicAdd(&h[(u32)blk.in[q] * HIST_REP + rep], 1u);
+        }
+        sum_tile();
     }
     if (prev) atomicAdd((unsigned long long *)(blk.freq + tid), (unsigned long long)prev);
 }
@@ -149,8 +170,11 @@ int hist_launch_dev(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, cons
     if (max_n == 0) return SHAFA_SUCCESS;
     HIP_TRY(hipMemcpyAsync(bt->d_par_hist, hp, pbytes, hipMemcpyHostToDevice, st));
     const dim3 grid((u32)ceil_div_u64(max_n, HIST_CHUNK), (u32)nblocks);
-    if (d_thist) hipLaunchKernelGGL(hist256_tiles_kernel, grid, dim3(HIST_THREADS), 0, st, (const HistBlk *)bt->d_par_hist);
-    else hipLaunchKernelGGL(hist256_kernel, grid, dim3(HIST_THREADS), 0, st, (const HistBlk *)bt->d_par_hist);
+    const HistBlk *dp = (const HistBlk *)bt->d_par_hist;
+    if (d_thist && d_n) hipLaunchKernelGGL(hist256_tiles_kernel<true>, grid, dim3(HIST_THREADS), 0, st, dp);
+    else if (d_thist) hipLaunchKernelGGL(hist256_tiles_kernel<false>, grid, dim3(HIST_THREADS), 0, st, dp);
+    else if (d_n) hipLaunchKernelGGL(hist256_kernel<true>, grid, dim3(HIST_THREADS), 0, st, dp);
+    else hipLaunchKernelGGL(hist256_kernel<false>, grid, dim3(HIST_THREADS), 0, st, dp);
     HIP_TRY(hipGetLastError());
     return SHAFA_SUCCESS;
 }

@@ -115,6 +115,7 @@ __device__ __forceinline__ u32 lookback_state(const u64 *desc, int k, int *err)
 }
 
 struct RldShared {
+    u8 pad0[16];                   // in front of `in`: a tile without zero bytes is stored straight from `in` (a piece may start before it)
     u8 in[RLD_TILE + 32];          // the tile, two look-ahead bytes, zeros
     u8 img[RLD_IMG + 48];          // 16 bytes in front (a piece may start before the image), slack for the last piece
     union {
@@ -123,6 +124,7 @@ struct RldShared {
     };
     u32 wfn[4];
     u32 wlen[4];
+    u32 wplain[4];                 // per wave: 32 valid bytes in every lane and not one zero among them
     u32 tile;
     u32 state_in;
     u32 next;
@@ -191,8 +193,15 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
     const u32 z = zmask32(w) & vm;
 
     // ---- this lane's transition map and token starts for each entry state, ordered scan over lanes and waves --------
+    // A wave without a zero byte (text-like data: nearly every wave): every byte is a literal once the state is S0, which
+    // it is after two bytes whatever it was — no table look-ups.  A TILE of such waves that is entered in S0 emits exactly
+    // its input: no per-byte lengths, no image, it is stored straight from `in` (below).
+    const bool wave_plain = __all(z == 0u && nvalid == RLD_BPL) != 0;
     u32 st3[3], ex3[3];
-    {
+    if (wave_plain) {
+        st3[0] = 0xFFFFFFFFu; st3[1] = 0xFFFFFFFCu; st3[2] = 0xFFFFFFFEu;
+        ex3[0] = ex3[1] = ex3[2] = 0;
+    } else {
         const u32 e0 = sh.fsm[z & 255u], e1 = sh.fsm[(z >> 8) & 255u], e2 = sh.fsm[(z >> 16) & 255u], e3 = sh.fsm[z >> 24];
 #pragma unroll
         for (int s0 = 0; s0 < 3; ++s0) {
@@ -210,14 +219,14 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
     if (__all(fn_const(f))) {                   // the usual wave: every lane's bytes settle the state whatever it was,
         fex = (u32)__shfl_up((int)f, 1, 64);    // so the map of all bytes before a lane is its neighbour's (constant) map
         if (lane == 0) fex = FN_IDENT;
-        if (lane == 63) sh.wfn[wv] = f;
+        if (lane == 63) { sh.wfn[wv] = f; sh.wplain[wv] = wave_plain ? 1u : 0u; }
     } else {
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const u32 y = (u32)__shfl_up((int)f, d, 64);
             if (lane >= d) f = fn_compose(y, f);
         }
-        if (lane == 63) sh.wfn[wv] = f;
+        if (lane == 63) { sh.wfn[wv] = f; sh.wplain[wv] = 0u; }
         fex = (u32)__shfl_up((int)f, 1, 64);
         if (lane == 0) fex = FN_IDENT;
     }
@@ -247,36 +256,48 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
     lds_barrier();
 
     // ---- literal / escape masks, per-byte output lengths ------------------------------------------------------------
-    const u32 s_in = fn_apply(fpre, sh.state_in);
-    const u32 S = (s_in == 0 ? st3[0] : s_in == 1 ? st3[1] : st3[2]) & vm;
-    const u32 Lm = S & ~z;
-    u32 E = S & z;
-    {   // a triple cut by the end of the block: error, no output
-        const long long lim = (long long)n - (long long)pos - 2;           // escapes at j < lim have their count byte
-        const u32 ok = lim >= 32 ? 0xFFFFFFFFu : lim <= 0 ? 0u : ((1u << (int)lim) - 1u);
-        if (E & ~ok) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
-        E &= ok;
-    }
-    w[8] = *(const u32 *)(sh.in + (tid + 1) * RLD_BPL);                    // the next lane's first bytes / the look-ahead
-    u32 lenw[8], len = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const u32 fe = nib_flags(E, i);
-        const u32 cnt2 = __builtin_amdgcn_alignbit(w[i + 1], w[i], 16);    // the bytes two places on
-        lenw[i] = nib_flags(Lm, i) | (cnt2 & ((fe << 8) - fe));
-    }
-    {   // count byte 0 behaves as 1 (d.c:179-184)
-        const u32 t = ((w[8] & 0x7F7Fu) + 0x7F7Fu) | w[8];
-        const u32 zn = (~t >> 7) & 0x0101u;
-        const u64 z34 = (u64)z | ((u64)((zn & 1u) | ((zn >> 7) & 2u)) << 32);
-        const u32 ez = E & (u32)(z34 >> 2);
-        if (ez) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) lenw[i] |= nib_flags(ez, i);
+    // (uniform) a tile of waves without zero bytes that is entered at a token start: its output is its input
+#ifndef RLD_NOPLAIN
+    const bool plain = sh.state_in == 0u && (sh.wplain[0] & sh.wplain[1] & sh.wplain[2] & sh.wplain[3]) != 0u;
+#else                                                  // A/B builds (tools/dbg)
+    const bool plain = false;
+#endif
+    u32 Lm = 0xFFFFFFFFu, E = 0u, lenw[8], len = RLD_BPL;
+    if (!plain) {
+        const u32 s_in = fn_apply(fpre, sh.state_in);
+        const u32 S = (s_in == 0 ? st3[0] : s_in == 1 ? st3[1] : st3[2]) & vm;
+        Lm = S & ~z;
+        E = S & z;
+        {   // a triple cut by the end of the block: error, no output
+            const long long lim = (long long)n - (long long)pos - 2;           // escapes at j < lim have their count byte
+            const u32 ok = lim >= 32 ? 0xFFFFFFFFu : lim <= 0 ? 0u : ((1u << (int)lim) - 1u);
+            if (E & ~ok) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
+            E &= ok;
         }
-    }
+        w[8] = *(const u32 *)(sh.in + (tid + 1) * RLD_BPL);                    // the next lane's first bytes / the look-ahead
+        len = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) len = __builtin_amdgcn_sad_u8(lenw[i], 0u, len);
+        for (int i = 0; i < 8; ++i) {
+            const u32 fe = nib_flags(E, i);
+            const u32 cnt2 = __builtin_amdgcn_alignbit(w[i + 1], w[i], 16);    // the bytes two places on
+            lenw[i] = nib_flags(Lm, i) | (cnt2 & ((fe << 8) - fe));
+        }
+        {   // count byte 0 behaves as 1 (d.c:179-184)
+            const u32 t = ((w[8] & 0x7F7Fu) + 0x7F7Fu) | w[8];
+            const u32 zn = (~t >> 7) & 0x0101u;
+            const u64 z34 = (u64)z | ((u64)((zn & 1u) | ((zn >> 7) & 2u)) << 32);
+            const u32 ez = E & (u32)(z34 >> 2);
+            if (ez) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) lenw[i] |= nib_flags(ez, i);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) len = __builtin_amdgcn_sad_u8(lenw[i], 0u, len);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lenw[i] = 0x01010101u;
+    }
 
     // ---- output offsets: wave 0 publishes the tile's total and looks back while the other waves build the image ------
     const u32 ilen = wave_incl_scan_add<u32>(len);
@@ -303,6 +324,7 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
     // ---- the output, in rounds of what the image holds: image byte i = output byte O + done + i ----------------------
     u8 *smem = (u8 *)&sh;
     const u32 img_off = (u32)offsetof(RldShared, img) + 16u, in_off = (u32)offsetof(RldShared, in) + (u32)tid * RLD_BPL;
+    const u32 src_off = plain ? (u32)offsetof(RldShared, in) : img_off;       // where output byte O + done + i sits in LDS
     const u64 limit = blk.out_cap < (u64)SHAFA_RLE_DECODE_MAX ? blk.out_cap : (u64)SHAFA_RLE_DECODE_MAX;
     u64 O = 0;
     for (u32 done = 0;;) {
@@ -315,7 +337,7 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
             nxt = sh.next;
             lds_barrier();
         }
-        if (len && lbase >= done && lbase + len <= nxt) {
+        if (!plain && len && lbase >= done && lbase + len <= nxt) {
             const u32 p0 = img_off + (lbase - done);
             {   // literals: one byte write each at the running position p, no branches.  The bytes of a triple are written
                 // at p as well: p is then the start of a run (filled below, later in program order) or the place of
@@ -354,7 +376,7 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
         const u32 mis = (u32)((uintptr_t)gout & 15u), nbytes = nxt - done;
         const u64 gidx = O + done;                      // index of image byte 0 in the block's output
         for (u32 u = tid; 16 * u < mis + nbytes; u += RLD_THREADS) {
-            const u32 s0 = img_off + 16 * u - mis, sb = s0 & ~3u, sf = s0 & 3u;
+            const u32 s0 = src_off + 16 * u - mis, sb = s0 & ~3u, sf = s0 & 3u;
             const u32 d0 = *(const u32 *)__builtin_assume_aligned(smem + sb, 4), d1 = *(const u32 *)__builtin_assume_aligned(smem + sb + 4, 4),
                       d2 = *(const u32 *)__builtin_assume_aligned(smem + sb + 8, 4), d3 = *(const u32 *)__builtin_assume_aligned(smem + sb + 12, 4),
                       d4 = *(const u32 *)__builtin_assume_aligned(smem + sb + 16, 4);

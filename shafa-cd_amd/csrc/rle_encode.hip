@@ -371,7 +371,8 @@ __device__ __forceinline__ void rle3_summary_tile(RleShared &sh, const RleBlk &b
 // run that enters it — only WHETHER the mask code may be used does (entering run >= 60 bytes) — so the size is computed
 // here, before the carries exist, and flagged: bit 31 = the tile needs the general code whatever enters (ragged, long
 // runs inside), bit 30 = a run enters (rle3_fix recomputes the size once the carry says it is long).
-constexpr u32 T_GENERAL = 0x80000000u, T_ENTERS = 0x40000000u, T_SIZE = 0xFFFFu;
+// bit 29 (pairs only): every byte of the pair is a literal — no zero byte, no run of four reaches into it: the emit pass copies
+constexpr u32 T_GENERAL = 0x80000000u, T_ENTERS = 0x40000000u, T_LITERAL = 0x20000000u, T_SIZE = 0xFFFFu;
 
 __device__ __forceinline__ void rle3_first_tile(RleShared &sh, const RleBlk &blk, const int k, const Rle3Pre &pre,
                                                 u32 *__restrict__ tsum, u32 *__restrict__ Tarr)
@@ -655,6 +656,7 @@ struct R8Fast {
     u32 wsum[4];
     u32 wfirst[4];                 // bytes from the start of a wave to its first run head
     u32 wlast[4];                  // last byte of each wave
+    u32 wpure[4];                  // first pass: every byte of the wave is a literal
     u32 slow;
     u32 H;                         // bytes after the pair equal to its last byte (<= 255)
 };
@@ -815,6 +817,44 @@ __device__ __forceinline__ bool rle3_emit8k(R8Fast &sh, const RleBlk &blk, const
     return true;
 }
 
+// A pair whose every byte is a literal (T_LITERAL of the first pass: text-like data) leaves as it came: 32 bytes per lane
+// into LDS at their own alignment, out again as 16-byte pieces aligned like the OUTPUT address (five dwords funnel-shifted
+// by the misalignment of G) — no masks, no classification, no token loop.
+__device__ __forceinline__ void rle3_copy8k(R8Fast &sh, const RleBlk &blk, const int kp, const u64 G)
+{
+    const u32 tid = threadIdx.x;
+    const u64 pos = (u64)kp * R8_TILE + (u64)tid * R8_BPL;
+    const uint4 v0 = gload_nt<uint4>(blk.in + pos), v1 = gload_nt<uint4>(blk.in + pos + 16);
+    u8 *smem = (u8 *)&sh;
+    constexpr u32 base = (u32)offsetof(R8Fast, img) + 16u;             // 16 bytes in front: a piece may start before the pair
+    *(uint4 *)(smem + base + 32u * tid) = v0;
+    *(uint4 *)(smem + base + 32u * tid + 16u) = v1;
+    lds_barrier();
+    if (G + R8_TILE > blk.out_cap) {
+        if (tid == 0) set_error(blk.err, SHAFA_LACK_OF_MEMORY);
+        return;
+    }
+    u8 *gout = blk.out + G;
+    const u32 mis = (u32)((uintptr_t)gout & 15u);
+    for (u32 u = tid; 16 * u < mis + (u32)R8_TILE; u += RLE_THREADS) {
+        const u32 s0 = base + 16 * u - mis, sb = s0 & ~3u, sf = s0 & 3u;
+        const u32 d0 = *(const u32 *)__builtin_assume_aligned(smem + sb, 4), d1 = *(const u32 *)__builtin_assume_aligned(smem + sb + 4, 4),
+                  d2 = *(const u32 *)__builtin_assume_aligned(smem + sb + 8, 4), d3 = *(const u32 *)__builtin_assume_aligned(smem + sb + 12, 4),
+                  d4 = *(const u32 *)__builtin_assume_aligned(smem + sb + 16, 4);
+        const u32 wds[4] = {__builtin_amdgcn_alignbyte(d1, d0, sf), __builtin_amdgcn_alignbyte(d2, d1, sf),
+                            __builtin_amdgcn_alignbyte(d3, d2, sf), __builtin_amdgcn_alignbyte(d4, d3, sf)};
+        u8 *ga = gout - mis + 16 * u;
+        const u32 lo = 16 * u;                          // the piece is bytes [lo - mis, lo - mis + 16) of the pair
+        if (lo >= mis && lo + 16 <= mis + (u32)R8_TILE) {
+            gstore_nt<uint4>(ga, make_uint4(wds[0], wds[1], wds[2], wds[3]));
+        } else {
+#pragma unroll
+            for (u32 q = 0; q < 16; ++q)
+                if (lo + q >= mis && lo + q < mis + (u32)R8_TILE) ga[q] = (u8)(wds[q >> 2] >> (8 * (q & 3)));
+        }
+    }
+}
+
 __global__ __launch_bounds__(RLE_THREADS) void rle3_emit(const RleBlk *__restrict__ blks, const u32 *__restrict__ Rarr,
                                                          u32 *__restrict__ Tarr, const u64 *__restrict__ Garr)
 {
@@ -825,6 +865,10 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_emit(const RleBlk *__restric
     const bool two = (u32)(k0 + 1) < blk.n_tiles;
     const u32 R0 = Rarr[blk.desc_base + k0];
     const u64 G0 = Garr[blk.desc_base + k0];
+    if (!blk.force_general && (Tarr[blk.desc_base + k0] & T_LITERAL)) {    // (uniform) set for full pairs only
+        rle3_copy8k(sh.f, blk, (int)blockIdx.x, G0);
+        return;
+    }
     if (rle3_emit8k(sh.f, blk, (int)blockIdx.x, R0, G0)) return;
     // the pair needs the 16-byte code (or the general code): tile by tile
     lds_barrier();
@@ -920,14 +964,16 @@ __device__ __forceinline__ bool rle3_first8k(R8Fast &sh, const RleBlk &blk, cons
     const u32 Lit = ~Z & ~LC;
     const u32 T3 = H & (Z | LC);
     const u32 wtot = wave_reduce_add<u32>((u32)__builtin_popcount(Lit) + 3u * (u32)__builtin_popcount(T3));
-    if (lane == 0) sh.wsum[wv] = wtot;
+    const bool wpure = __ballot(Lit != 0xFFFFFFFFu) == 0ull;          // text-like data: nearly every pair
+    if (lane == 0) { sh.wsum[wv] = wtot; sh.wpure[wv] = wpure ? 1u : 0u; }
     const bool ent0 = (sh.E[1] & 1u) != 0, ent1 = (sh.E[129] & 1u) != 0;
     lds_barrier();
     if (tid < 2) {                                      // thread t writes the summary and the size of tile 2 kp + t
         const int k = 2 * kp + tid;
         const int lp = (int)sh.wfirst[2 * tid + 1] >= 0 ? (int)sh.wfirst[2 * tid + 1] : (int)sh.wfirst[2 * tid];
-        tsum[blk.desc_base + k] = lp < 0 ? (0x80000000u | (u32)RLE_TILE) : (u32)(RLE_TILE - lp);
-        Tarr[blk.desc_base + k] = (sh.wsum[2 * tid] + sh.wsum[2 * tid + 1]) | ((tid ? ent1 : ent0) ? T_ENTERS : 0u);
+        const u32 pure = (sh.wpure[0] & sh.wpure[1] & sh.wpure[2] & sh.wpure[3]) ? T_LITERAL : 0u;   // (a run of >= 60 that enters
+        tsum[blk.desc_base + k] = lp < 0 ? (0x80000000u | (u32)RLE_TILE) : (u32)(RLE_TILE - lp);     //  would cover byte 0: not pure)
+        Tarr[blk.desc_base + k] = (sh.wsum[2 * tid] + sh.wsum[2 * tid + 1]) | ((tid ? ent1 : ent0) ? T_ENTERS : 0u) | pure;
     }
     return true;
 }

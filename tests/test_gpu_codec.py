@@ -37,6 +37,32 @@ def rle_inputs(oracle, shafa):
     b[4095] = 4
     b[4096 + 254] = 4
     cases["run_cut_near_tile_edge"] = b
+    # text-like data: pairs / tiles whose every byte is a literal take the copy paths of rle3_emit and rle_decode_kernel;
+    # sparse tokens in between move the output off the input's alignment and switch between the paths, also right at the
+    # edges of a pair (8 KiB) and with the tokens that only exist because of the bytes AROUND a pair
+    rng = np.random.default_rng(77)
+    for n in [8192, 8192 * 3, 8192 * 5 + 4096, 100000, (1 << 20) + 777]:
+        t = (rng.integers(1, 255, size=n) | 1).astype(np.uint8)              # odd bytes: no zeros
+        t[1:] = np.where(t[1:] == t[:-1], t[1:] ^ 2, t[1:])                   # and no two equal neighbours
+        cases[f"literal_{n}"] = t.copy()
+        u = t.copy()
+        for pos_ in range(5000, n - 300, 20011):
+            kind = (pos_ // 20011) % 4
+            if kind == 0:
+                u[pos_] = 0                                                   # a single zero: {0,0,1}
+            elif kind == 1:
+                u[pos_:pos_ + 4] = 0x41                                       # a run of four
+            elif kind == 2:
+                u[pos_:pos_ + 300] = 0x42                                     # a run over the 255 cap
+            else:
+                u[pos_:pos_ + 3] = 0x43                                       # a run of three stays literals
+        cases[f"literal_sparse_tokens_{n}"] = u
+        if n > 8192 * 2:
+            e = t.copy()
+            e[8190:8194] = 0x51                                               # a run of four across the first pair's end
+            e[8192 * 2 - 1] = 0                                               # a zero as the last byte of the second pair
+            e[8192 * 2 + 1:8192 * 2 + 4] = e[8192 * 2]                        # a run of four that starts on a pair's first byte
+            cases[f"literal_pair_edges_{n}"] = e
     return cases
 
 

@@ -99,7 +99,7 @@ total_in = bench.get("config", {}).get("blocks_per_gpu", 0) * bench.get("config"
 if total_in:
     enc = sum(r + w for k, (r, w) in per.items() if k.startswith("sfe"))
     dec = sum(r + w for k, (r, w) in per.items() if k.startswith("sfd"))
-    ratio = bench["config"]["compressed_ratio"]
+    ratio = bench["config"].get("compressed_ratio") or 0.0
     print(f"\n## bytes per input byte: sf_encode {enc / total_in:.3f}  sf_decode {dec / total_in:.3f}  (algorithmic {1 + ratio:.3f})")
     a = {"--dist": "zipfmod", "--zipf-s": "1.2", "--block-mib": "64", "--blocks": "128"}
     for i, x in enumerate(args):
@@ -108,8 +108,11 @@ if total_in:
     j = {"what": "HBM traffic from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, tools/gpu_prof.sh); "
                  "FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes",
          "workload_key": f"{a['--dist']}:{float(a['--zipf-s']):g}:{a['--block-mib']}:{a['--blocks']}",
-         "pipeline_key": (None if "--no-pipeline" in args else
-                          "pipeline:%s:%s" % (a["--block-mib"], min(int(a["--blocks"]), int(next((args[i + 1] for i, x in enumerate(args) if x == "--pipeline-blocks"), 32))))),
+         # a profile of one pipeline leg alone (--pipeline-only --pipeline-kind K): what bench.py's `pipeline` objects take
+         # their per-family traffic from; a headline profile carries null
+         "pipeline_key": ("pipeline:%s:%s:%s" % (next((args[i + 1] for i, x in enumerate(args) if x == "--pipeline-kind"), "runs"), a["--block-mib"],
+                                                 min(int(a["--blocks"]), int(next((args[i + 1] for i, x in enumerate(args) if x == "--pipeline-blocks"), 32))))
+                          if "--pipeline-only" in args else None),
          "bench_args": args, "csrc_sha256": csrc_hash(),
          "bytes_per_input_byte": {"sf_encode": enc / total_in if enc else None, "sf_decode": dec / total_in if dec else None},
          "algorithmic_bytes_per_input_byte": 1 + ratio,
