@@ -127,6 +127,19 @@ def make_input(gen):
     raise ValueError(kind)
 
 
+def corrupt_cod_block(path, k):
+    """Replace the first '0' / '1' of block k's codes in a .cod file by '2' (c.c:127-131: not a code character)."""
+    with open(path, "rb") as f:
+        fields = f.read().split(b"@")          # ['', 'R', '<n>', '<size>', '<codes>', '<size>', '<codes>', ..., '0']
+    i = 4 + 2 * k
+    codes = bytearray(fields[i])
+    j = next(q for q, ch in enumerate(codes) if ch in b"01")
+    codes[j] = ord("2")
+    fields[i] = bytes(codes)
+    with open(path, "wb") as f:
+        f.write(b"@".join(fields))
+
+
 def run_case(name, files_in, cmds, note="", store_inputs=True, expect_rc=None, generators=None):
     """files_in: {fname: bytes}; cmds: list of argv lists (without the binary), run in order in a
     scratch dir; files whose name starts with 'decoded__' are produced by copying after -m d."""
@@ -149,6 +162,10 @@ def run_case(name, files_in, cmds, note="", store_inputs=True, expect_rc=None, g
                 continue
             if step[0] == "__rm__":
                 os.remove(os.path.join(tmp, step[1]))
+                man["cmds"].append(step)
+                continue
+            if step[0] == "__corrupt_cod__":   # ["__corrupt_cod__", file, block]
+                corrupt_cod_block(os.path.join(tmp, step[1]), step[2])
                 man["cmds"].append(step)
                 continue
             r = subprocess.run([REF] + step, cwd=tmp, capture_output=True, timeout=1800)
@@ -315,6 +332,27 @@ def main():
         ["s", "-b", "M"], ["__copy__", "s", "orig__s"], ["__rm__", "s"],
         ["s.rle.shaf"], ["__copy__", "s", "decoded__sf_rle"],
     ], "3 x 64 MiB at -b M: binary section then dictionary text; RLE verdict of block 0 applied to the text blocks")
+
+    # 11. block-split edges through the drivers (file.c:78-85 last-block size, f.c:231-236 block loop)
+    big_case("edge_exact_K", "q", {"kind": "runs", "seed": 21, "n": 2 * 655360}, [
+        ["q", "-b", "K"], ["__copy__", "q", "orig__q"], ["__rm__", "q"],
+        ["q.rle.shaf"], ["__copy__", "q", "decoded__sf_rle"],
+    ], "a file of exactly two 640 KiB blocks at -b K: no short last block")
+    for tail in (1, 7, 15):
+        d = runs_stream(30 + tail, 3 * 65536 + tail, zt).tobytes()
+        run_case(f"edge_tail_{tail}", {"p": d}, [
+            ["p"], ["__copy__", "p", "orig__p"], ["__rm__", "p"],
+            ["p.rle.shaf"], ["__copy__", "p", "decoded__sf_rle"],
+            ["__copy__", "p.rle", "keep__p.rle"], ["__rm__", "p"],
+            ["p.rle", "-m", "d"], ["__copy__", "p", "decoded__rle_only"],
+        ], note=f"three 64 KiB blocks and a last block of {tail} byte(s), default block size")
+    # more blocks than the drivers keep in flight (three slots per device), a malformed .cod block in the middle: the blocks
+    # in front of it are on disk when the error surfaces (ordered write chain, c.c:254-267, multithread.c:75-86)
+    big_case("edge_bad_cod_mid", "g", {"kind": "runs", "seed": 41, "n": 12 * 65536}, [
+        ["g", "-m", "f"], ["g.rle.freq", "-m", "t"],
+        ["__corrupt_cod__", "g.rle.cod", 6],
+        ["g.rle", "-m", "c"],
+    ], "12 blocks of 64 KiB, block 6 of the .cod file malformed: Module C fails, what it wrote before stays")
 
     # 9. CLI behaviour samples (exit codes + stderr text)
     run_case("cli_errors", {"z": runs_stream(11, 5000, zt).tobytes()}, [

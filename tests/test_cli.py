@@ -80,7 +80,9 @@ def test_cli_module_t_alone_on_cpu(tmp_path):
 
 
 GPU_CASES = ["runs_default", "edges_forced_rle", "uniform_no_rle", "uniform_forced_both", "runs_force_freq",
-             "textlike_m", "tiny_1024", "tiny_1023", "cli_errors", "cfg0_K_runs", "cfg0_K_uniform"]
+             "textlike_m", "tiny_1024", "tiny_1023", "cli_errors", "cfg0_K_runs", "cfg0_K_uniform",
+             # block-split edges (file.c:78-85, f.c:231-236) and an error in the middle of the ordered write chain (c.c:254-267)
+             "edge_exact_K", "edge_tail_1", "edge_tail_7", "edge_tail_15", "edge_bad_cod_mid"]
 # full-size blocks (8 MiB / 64 MiB; inputs rebuilt from the manifest's generators, outputs pinned by SHA-256)
 FULL_CASES = ["full_uniform_m", "full_zipf_M", "full_zipfmod_M_forced_rle", "full_single_run_M", "full_alt01_M",
               "full_longtail_M", "full_mixed_M"]
@@ -92,6 +94,19 @@ def scratch_dir(tmp_path, case):
         import tempfile
         return tempfile.mkdtemp(prefix="shafa_" + case + "_", dir="/dev/shm")
     return str(tmp_path)
+
+
+# Where our host deliberately does NOT do what the reference does: the files on disk are
+# still compared with the reference's byte for byte.
+DIVERGENCES = {
+    # a last block of ONE byte is a single-symbol block: all codes empty, `@0@` in the .shaf, and the reference's decoder
+    # dereferences NULL (d.c:533, rc -11 here).  Ours: _FILE_UNRECOGNIZABLE for that block, the blocks before it written.
+    ("edge_tail_1", ("p.rle.shaf",)): {"rc": 1, "stderr_has": "Module d"},
+    # the reference drops the thread chain's error in Module C (c.c:421 ignores multithread_wait()'s result; with
+    # --no-multithread the same file fails with rc 1): it prints a summary and exits 0 with a truncated .shaf.  Ours
+    # reports the malformed block; what was written before it is the same.
+    ("edge_bad_cod_mid", ("g.rle", "-m", "c")): {"rc": 1, "stderr_has": "Module c"},
+}
 
 
 def replay(case, work):
@@ -118,8 +133,14 @@ def replay(case, work):
                 shutil.copyfile(os.path.join(work, cmd[1]), os.path.join(work, cmd[2]))
             elif cmd[0] == "__rm__":
                 os.remove(os.path.join(work, cmd[1]))
+            elif cmd[0] == "__corrupt_cod__":
+                mg.corrupt_cod_block(os.path.join(work, cmd[1]), cmd[2])
             continue
         rc, err, out = run(cmd["argv"], work)
+        div = DIVERGENCES.get((case, tuple(cmd["argv"])))
+        if div:
+            assert rc == div["rc"] and div["stderr_has"] in err, f"{case} {cmd['argv']}: rc {rc} stderr {err!r}"
+            continue
         assert rc == cmd["rc"], f"{case} {cmd['argv']}: rc {rc} stderr {err!r}"
         assert err == cmd["stderr"], f"{case} {cmd['argv']}"
         # stdout summaries (f.c:132-177, t.c:219-243, c.c:282-303, d.c:44-65): identical except the measured

@@ -27,16 +27,11 @@ def _manifest(case):
 
 
 def _blocks(n, bs):
-    """fsize block split with Module F's merge of a last block below 1 KiB (f.c:220-229)."""
+    """fsize block split (file.c:52-117): ceil(n / bs) blocks, the last one holds what is left — however little (the 1 KiB
+    rule of f.c:220,366 is about the FILE: a last block of one byte is a block, tests/golden/edge_tail_1)."""
     nb = n // bs
     rem = n - nb * bs
-    sizes = [bs] * nb
-    if rem:
-        if rem < 1024 and sizes:
-            sizes[-1] += rem
-        else:
-            sizes.append(rem)
-    return sizes
+    return [bs] * nb + ([rem] if rem else [])
 
 
 def _al(x, a=256):
