@@ -393,9 +393,10 @@ def host():
     if _host is not None:
         return _host
     lib()   # libshafa_host.so links against libshafa_hip.so
-    if not os.path.exists(HOST_LIB_PATH):
-        raise ImportError(f"{HOST_LIB_PATH} not built: run __graft_entry__.build()")
-    H = C.CDLL(HOST_LIB_PATH)
+    path = os.environ.get("SHAFA_HOST_LIB") or HOST_LIB_PATH        # (the sanitizer build of tools/san/run_san.sh)
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not built: run __graft_entry__.build()")
+    H = C.CDLL(path)
     u64p, tp = C.POINTER(C.c_uint64), C.POINTER(CodeTable)
     H.shafa_sf_build_codes.argtypes = [u64p, tp]
     H.shafa_sf_build_codes.restype = None

@@ -35,8 +35,9 @@ void shafa_sf_build_codes(const uint64_t freq[256], shafa_code_table *out)
     }
     qsort(r, 256, sizeof(ranked), by_count_desc);
 
-    /* cum[i] = sum of the first i ranked counts: range totals in O(1) */
-    uint64_t cum[257];
+    /* cum[i] = sum of the first i ranked counts: range totals in O(1).  128-bit sums: a hand-made .freq file may carry
+     * any 64-bit counts (the reference's `int total` overflows there, t.c:133: undefined; here the same rule on exact sums) */
+    unsigned __int128 cum[257];
     cum[0] = 0;
     for (int i = 0; i < 256; ++i) cum[i + 1] = cum[i] + r[i].count;
 
@@ -51,12 +52,12 @@ void shafa_sf_build_codes(const uint64_t freq[256], shafa_code_table *out)
         --top;
         const int a = stack[top].a, b = stack[top].b;
         if (a == b) continue;
-        const int64_t total = (int64_t)(cum[b + 1] - cum[a]);
+        const unsigned __int128 total = cum[b + 1] - cum[a];
         int cut = a;
-        int64_t best = total;
+        unsigned __int128 best = total;
         for (int i = a; i <= b; ++i) {
-            int64_t d = 2 * (int64_t)(cum[i + 1] - cum[a]) - total;
-            if (d < 0) d = -d;
+            const unsigned __int128 left = cum[i + 1] - cum[a], rest = total - left;
+            const unsigned __int128 d = left > rest ? left - rest : rest - left;        /* |2 left - total| */
             if (d >= best) break;
             best = d;
             cut = i;

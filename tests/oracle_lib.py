@@ -154,6 +154,8 @@ _cached = None
 
 def load():
     global _cached
+    if _cached is None and os.environ.get("SHAFA_ORACLE_LIB"):      # tools/san/run_san.sh: the build under ASan + UBSan
+        _cached = Oracle(C.CDLL(os.environ["SHAFA_ORACLE_LIB"]))
     if _cached is None:
         if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(
                 os.path.join(ORACLE_DIR, "shafa_oracle.c")):

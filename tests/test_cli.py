@@ -13,7 +13,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
-CLI = os.path.join(ROOT, "shafa-cd_amd", "bin", "shafa")
+CLI = os.environ.get("SHAFA_CLI") or os.path.join(ROOT, "shafa-cd_amd", "bin", "shafa")    # (SHAFA_CLI: tools/san/run_san.sh)
 
 
 def sha(path):
