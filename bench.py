@@ -184,11 +184,31 @@ def cpu_baseline(args, pkg, zt):
             subprocess.run([ref, stem + ".shaf", "-m", "d", "-d", "s"], cwd=tmp, capture_output=True, check=True)
             t2 = time.perf_counter()
             in_bytes = os.path.getsize(os.path.join(tmp, stem))
+        # the same two modules with --no-multithread (multithread.c:130-137: process and write inline, one core) on a prefix
+        # of the sample — SURVEY.md §8(d) / BASELINE.md §3 ask for both figures
+        st_blocks = min(nblk, 2)
+        with tempfile.TemporaryDirectory(dir=shm) as tmp:
+            p = os.path.join(tmp, "s")
+            data[:st_blocks * bs].tofile(p)
+            subprocess.run([ref, "s", "-m", "f", "-b", flag], cwd=tmp, capture_output=True, check=True)
+            stem = "s.rle" if os.path.exists(p + ".rle") else "s"
+            subprocess.run([ref, stem + ".freq", "-m", "t"], cwd=tmp, capture_output=True, check=True)
+            u0 = time.perf_counter()
+            subprocess.run([ref, stem, "-m", "c", "--no-multithread"], cwd=tmp, capture_output=True, check=True)
+            u1 = time.perf_counter()
+            if stem == "s":
+                os.remove(p)
+            subprocess.run([ref, stem + ".shaf", "-m", "d", "-d", "s", "--no-multithread"], cwd=tmp, capture_output=True, check=True)
+            u2 = time.perf_counter()
+            st_bytes = os.path.getsize(os.path.join(tmp, stem))
         return {"value": in_bytes / GIB / (t2 - t0), "unit": "GiB/s", "cores": min(nblk, cores),
                 "kind": "reference",
                 "sample": f"{nblk} x {args.block_mib} MiB {args.dist} blocks; reference -m c then -m d -d s, "
                           f"one thread per block ({nblk} threads on {cores} cores), wall incl. tmpfs I/O",
-                "encode_GiBs": in_bytes / GIB / (t1 - t0), "decode_GiBs": in_bytes / GIB / (t2 - t1)}
+                "encode_GiBs": in_bytes / GIB / (t1 - t0), "decode_GiBs": in_bytes / GIB / (t2 - t1),
+                "no_multithread": {"value": st_bytes / GIB / (u2 - u0), "cores": 1,
+                                   "sample": f"{st_blocks} x {args.block_mib} MiB blocks, --no-multithread",
+                                   "encode_GiBs": st_bytes / GIB / (u1 - u0), "decode_GiBs": st_bytes / GIB / (u2 - u1)}}
     # oracle port, single thread, smaller sample
     n = min(n, 32 << 20)
     d = data[:n]

@@ -25,7 +25,7 @@
  * previous stream.  The calling thread's current HIP device must be the batch's device (the one current at
  * shafa_hipd_batch_create) for layer-2 calls; layer 1 and layer 3 select their devices themselves and NO entry point
  * leaves the calling thread's current device changed.  shafa_hip_set_option() and shafa_hip_init*() are configuration:
- * call them while no other call is in flight.  shafa_hip_last_error() is per calling thread.  A decode call of 32 blocks
+ * call them while no other call is in flight.  shafa_hip_last_error() is per calling thread.  A decode call of 16 blocks
  * or more prepares its tables on up to seven short-lived helper threads of its own (joined before the call returns).
  * No entry point throws or exits.
  */

@@ -32,7 +32,8 @@ int batch_enter(Batch *b, hipStream_t st)
         snprintf(g_last_error, sizeof(g_last_error), "batch of device %d used while device %d is current", b->device, dev);
         return SHAFA_DEVICE_ERROR;
     }
-    if (b->has_last && b->last_st != st) HIP_TRY(hipStreamSynchronize(b->last_st));
+    if (b->has_last && b->last_st != st && hipStreamSynchronize(b->last_st) != hipSuccess)
+        (void)hipGetLastError();           // the previous stream was destroyed by its owner (legal once its work is done): nothing to wait for
     b->last_st = st;
     b->has_last = true;
     return SHAFA_SUCCESS;

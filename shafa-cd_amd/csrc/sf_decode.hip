@@ -2171,11 +2171,12 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         // kernels' time for 8 MiB blocks of compressible data.  Blocks are handed out by a counter, so the launch does
         // not depend on how many helpers could be started.
         std::atomic<int> next{0};
-        auto work = [&]() {
+        std::atomic<bool> nomem{false};
+        auto work = [&]() {                                // no exception leaves a thread (the entry points never throw)
             for (;;) {
                 const int b = next.fetch_add(1, std::memory_order_relaxed);
                 if (b >= nblocks) break;
-                build_host_tab(h_tables[b], tabs[b]);
+                try { build_host_tab(h_tables[b], tabs[b]); } catch (...) { nomem.store(true); }
             }
         };
         int helpers = nblocks / 16;                        // a helper is worth starting for sixteen tables or more
@@ -2188,6 +2189,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         }
         work();
         for (auto &t : th) t.join();
+        if (nomem.load()) return SHAFA_LACK_OF_MEMORY;
     }
     for (int b = 0; b < nblocks; ++b) {
         HostTab &h = tabs[b];

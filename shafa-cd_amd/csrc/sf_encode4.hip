@@ -116,7 +116,7 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restri
                             if (!ragged && p_tile == nfull - 1) gstore<u64>(bp->out_n, (B + p_T + 7) >> 3);
                         }
                         const u32 r = (u32)B & 31u;
-                        if (r) lead_bits(sh.lut, pwin, pv_w, r, lane);
+                        if (r && p_T <= cap_bits) lead_bits(sh.lut, pwin, pv_w, r, lane);     // (a tile that did not fit its window was not placed)
                     }
                     if (lane == 0) sh.prefix5[par] = B;
                 }
@@ -148,7 +148,9 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restri
             lds_barrier();
             const u32 n3 = sh.tick5[par];
 #ifndef E5_ABL_NOSTORE                                 // timing ablations (tools/dbg): wrong output
-            if (wv >= E5_STORE_W0 && have_p)
+            // (a tile that did not fit its window was never placed and its block is encoded again: nothing to store, and
+            // reading p_T bits of a window that holds cap_bits would run past the workgroup's LDS)
+            if (wv >= E5_STORE_W0 && have_p && p_T <= cap_bits)
 #else
             if (wv >= E5_STORE_W0 && have_p && bp->n == 12345)
 #endif

@@ -63,8 +63,11 @@ static int pipe_depth(uint64_t n_blocks)
  * tmpfs reads scale with threads (tools/iobench/tmpfs_rw.c on the GPU box: 6.6 GiB/s with one thread, 15 with eight,
  * 21-23 with sixteen).  WRITES of a new file do not: 5.5 GiB/s with one thread and LESS with more (2.8 with eight: the
  * page allocations of one inode serialise) — so a block is written by one thread.  That write path is what bounds the
- * CLI end to end.  --no-multithread: everything inline. */
-enum { IO_THREADS = 12, IO_MIN_SLICE = 2 << 20 };
+ * CLI end to end.  --no-multithread: everything inline.  Inputs must be seekable (regular files): a FIFO or
+ * /dev/stdin, which the reference's fread loop accepts, is SHAFA_FILE_STREAM_FAILED here (pread: ESPIPE). */
+/* (helper threads only for slices of 8 MiB: a block of -b m or less is read inline — eleven thread starts per small block
+ * were pure overhead) */
+enum { IO_THREADS = 12, IO_MIN_SLICE = 8 << 20 };
 typedef struct { int fd; uint8_t *buf; size_t n; off_t off; bool write; bool ok; } io_slice;
 
 static bool io_all(int fd, uint8_t *buf, size_t n, off_t off, bool write)

@@ -29,9 +29,10 @@ def block_sizes(total_bytes, block_size):
     return [block_size] * (n - 1) + [total_bytes - (n - 1) * block_size] if n else []
 
 
-def scatter_blocks(src, total_bytes, block_size, device, root=0, group=None):
+def scatter_blocks(src, total_bytes, block_size, device, root=0, group=None, stats=None):
     """X1.  `src` (root only) holds the whole input; every rank gets a tensor with its own blocks,
-    back to back.  Returns (local_tensor, first_block, sizes_of_local_blocks)."""
+    back to back.  Returns (local_tensor, first_block, sizes_of_local_blocks).  `stats` (a dict, optional) counts the
+    point-to-point operations this rank posted ("p2p_ops"): a test that means to exercise them can tell."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     sizes = block_sizes(total_bytes, block_size)
     first, count = block_range(len(sizes), world, rank)
@@ -46,17 +47,23 @@ def scatter_blocks(src, total_bytes, block_size, device, root=0, group=None):
                 local.copy_(src[lo:lo + nb])
             elif nb:
                 ops.append(dist.P2POp(dist.isend, src[lo:lo + nb], r, group))
+        if stats is not None:
+            stats["p2p_ops"] = stats.get("p2p_ops", 0) + len(ops)
         for w in (dist.batch_isend_irecv(ops) if ops else []):
             w.wait()
     elif my_bytes:
+        if stats is not None:
+            stats["p2p_ops"] = stats.get("p2p_ops", 0) + 1
         for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, local, root, group)]):
             w.wait()
     return local, first, sizes[first:first + count]
 
 
-def gather_payloads(local_out, local_offsets, local_sizes, n_blocks, device, root=0, group=None):
+def gather_payloads(local_out, local_offsets, local_sizes, n_blocks, device, root=0, group=None, stats=None):
     """X2.  Block j of this rank is local_out[local_offsets[j] : local_offsets[j] + local_sizes[j]].
-    Root returns the list of all payload tensors in global block order; other ranks return None."""
+    Root returns the list of all payload tensors in global block order; other ranks return None.
+    Every payload travels as its own view of local_out in ONE batch of point-to-point operations per rank (no packing
+    copy on the sender; operations between two ranks match in the order they were posted)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     max_cnt = (n_blocks + world - 1) // world
     mine = torch.zeros(max_cnt, dtype=torch.int64, device=device)
@@ -64,29 +71,31 @@ def gather_payloads(local_out, local_offsets, local_sizes, n_blocks, device, roo
         mine[:len(local_sizes)] = torch.tensor([int(s) for s in local_sizes], dtype=torch.int64, device=device)
     every = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(every, mine, group=group)
-    packed = (torch.cat([local_out[int(o):int(o) + int(s)] for o, s in zip(local_offsets, local_sizes)])
-              if local_sizes else torch.empty(0, dtype=torch.uint8, device=device))
+    views = [local_out[int(o):int(o) + int(s)] for o, s in zip(local_offsets, local_sizes)]
     if rank != root:
-        if packed.numel():
-            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, packed, root, group)]):
-                w.wait()
+        ops = [dist.P2POp(dist.isend, v, root, group) for v in views if v.numel()]
+        if stats is not None:
+            stats["p2p_ops"] = stats.get("p2p_ops", 0) + len(ops)
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
         return None
-    out, bufs, ops = [None] * n_blocks, {}, []
+    out, ops = [None] * n_blocks, []
     for r in range(world):
         f, c = block_range(n_blocks, world, r)
         sz = [int(x) for x in every[r][:c].tolist()]
         if r == root:
-            bufs[r] = packed
-        else:
-            bufs[r] = torch.empty(sum(sz), dtype=torch.uint8, device=device)
-            if sum(sz):
-                ops.append(dist.P2POp(dist.irecv, bufs[r], r, group))
+            for j in range(c):
+                out[f + j] = views[j]
+            continue
+        buf = torch.empty(max(sum(sz), 1), dtype=torch.uint8, device=device)
+        pos = 0
+        for j, s_ in enumerate(sz):
+            out[f + j] = buf[pos:pos + s_]
+            if s_:
+                ops.append(dist.P2POp(dist.irecv, out[f + j], r, group))
+            pos += s_
+    if stats is not None:
+        stats["p2p_ops"] = stats.get("p2p_ops", 0) + len(ops)
     for w in (dist.batch_isend_irecv(ops) if ops else []):
         w.wait()
-    for r in range(world):
-        f, c = block_range(n_blocks, world, r)
-        pos = 0
-        for j, s in enumerate(int(x) for x in every[r][:c].tolist()):
-            out[f + j] = bufs[r][pos:pos + s]
-            pos += s
     return out

@@ -32,7 +32,8 @@ def _worker(rank, world, port, total, bs, q):
     zt = pkg.zipf_table(1.2)
     data = orc.gen_bytes(424242, total, zt)
     src = torch.from_numpy(data).to(dev) if rank == 0 else None
-    local, first, sizes = sh.scatter_blocks(src, total, bs, dev)                      # X1
+    stats = {}
+    local, first, sizes = sh.scatter_blocks(src, total, bs, dev, stats=stats)         # X1
     nb = len(sizes)
     st = torch.cuda.Stream(device=dev)
     bt = pkg.Batch(max(nb, 1), bs)
@@ -57,10 +58,10 @@ def _worker(rank, world, port, total, bs, q):
         bt.finish(st, nb)
         assert [int(x) for x in d_enc_n.cpu().numpy()[:nb]] == enc_n
     n_blocks = (total + bs - 1) // bs
-    got = sh.gather_payloads(d_enc, eoff, enc_n, n_blocks, dev)                        # X2
+    got = sh.gather_payloads(d_enc, eoff, enc_n, n_blocks, dev, stats=stats)           # X2
     ok = True
     if rank == 0:
-        ok = len(got) == n_blocks
+        ok = len(got) == n_blocks and stats.get("p2p_ops", 0) > 0       # blocks really went over RCCL (world >= 2)
         for b in range(n_blocks):
             blk = data[b * bs:(b + 1) * bs]
             rc, enc = orc.sf_encode(blk, orc.sf_build(orc.hist256(blk)))
@@ -79,6 +80,10 @@ def _gpu_count():
 def test_scatter_hip_encode_gather_over_rccl(total, bs):
     import torch.multiprocessing as mp
     world = max(1, _gpu_count())                   # one rank per visible GPU (8 on a full node)
+    if world < 2:
+        # at world 1 every point-to-point list is empty: nothing of X1 / X2 would be exercised, so say so instead of passing;
+        # the movement itself is covered at world 2 and 8 over gloo (tests/test_sharding_gloo.py), the HIP kernels everywhere else
+        pytest.skip("one GPU on this box: X1 scatter / X2 gatherv over RCCL need two ranks (no send or receive happens at world 1)")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29600 + (os.getpid() + total) % 1500
@@ -116,6 +121,23 @@ def test_bench_self_launches_ranks():
     assert ("invalid" in j) == (n < 2)
     if n >= 2:
         assert "scatter_gather" in j and j["scatter_gather"]["backend"] == "nccl"
+
+
+def test_bench_at_world_size_8():
+    """`bench.py --gpus 8` with tiny blocks: the rank plumbing of the node the scaling bench runs on (rendezvous of eight
+    ranks, shard offsets, barrier, max-reduce, per-rank gather, rank-0 line) is not first exercised by the driver.  On a box
+    with fewer than eight GPUs the ranks share devices (--oversubscribe: gloo for the collectives, line marked invalid)."""
+    n = _gpu_count()
+    argv = ["--gpus", "8", "--steps", "1", "--warmup", "1", "--blocks", "2", "--block-mib", "8", "--no-cpu", "--no-pipeline",
+            "--no-host-path"]
+    if n < 8:
+        argv.append("--oversubscribe")
+    j = _bench(argv, timeout=900)
+    assert j["n_gpus"] == 8 and j["value"] > 0 and j["scaling"] == "weak"
+    assert ("invalid" in j) == (n < 8)
+    pr = j["per_rank"]
+    assert len(pr["encode_ms"]) == 8 and len(pr["decode_ms"]) == 8 and all(x > 0 for x in pr["encode_ms"] + pr["decode_ms"])
+    assert j["config"]["blocks_per_gpu"] == 2
 
 
 def test_bench_on_every_visible_gpu_over_rccl():

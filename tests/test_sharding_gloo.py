@@ -24,7 +24,8 @@ def _worker(rank, world, port, total, bs, q):
     orc = oracle_lib.load()
     dev = torch.device("cpu")
     src = torch.from_numpy(orc.gen_bytes(99, total)) if rank == 0 else None
-    local, first, sizes = sh.scatter_blocks(src, total, bs, dev)
+    stats = {}
+    local, first, sizes = sh.scatter_blocks(src, total, bs, dev, stats=stats)
     outs, offs, lens, pos = [], [], [], 0
     for s in sizes:
         blk = local[pos:pos + s].numpy()
@@ -37,10 +38,14 @@ def _worker(rank, world, port, total, bs, q):
         outs.append(enc)
     packed = torch.from_numpy(np.concatenate(outs)) if outs else torch.empty(0, dtype=torch.uint8)
     n_blocks = (total + bs - 1) // bs
-    got = sh.gather_payloads(packed, offs, lens, n_blocks, dev)
+    got = sh.gather_payloads(packed, offs, lens, n_blocks, dev, stats=stats)
     if rank == 0:
         data = orc.gen_bytes(99, total)
         ok = len(got) == n_blocks
+        # the root really talked to the others: one send per rank that holds blocks (X1) and one receive per remote block (X2)
+        remote = sum(sh.block_range(n_blocks, world, r)[1] for r in range(1, world))
+        holders = sum(1 for r in range(1, world) if sh.block_range(n_blocks, world, r)[1])
+        ok = ok and stats.get("p2p_ops", 0) == holders + remote
         for b in range(n_blocks):
             blk = data[b * bs:(b + 1) * bs]
             rc, enc = orc.sf_encode(blk, orc.sf_build(orc.hist256(blk)))
