@@ -31,6 +31,7 @@ struct Slot {
     int op;
     bool busy, want_in_hist;
     size_t in_n, out_cap, n_symbols;
+    size_t copied;             // bytes of the result fetched speculatively at submit (pipe_prefetch)
     int rc;                    // error found while submitting
 };
 
@@ -39,9 +40,29 @@ struct Slot {
 struct shafa_pipe {
     int n_slots;
     Slot *slots;
+    size_t last_out[8];        // per op: result size of the block retired last (what the next submit fetches ahead)
 };
 
 namespace {
+
+// A result whose size only the device knows (RLE / SF encode, RLE decodes) is fetched SPECULATIVELY when the op is
+// submitted: as many bytes as the pipe's previous block of that op produced, plus 3 % — consecutive blocks of a file differ
+// little — by one asynchronous copy behind the op's kernels, so that it overlaps the next block's H2D on the other
+// direction of the link; shafa_pipe_wait fetches what is missing (the first block of a pipe: everything).  (Fetching the
+// whole payload from shafa_pipe_wait, after the host has seen the size, put every D2H behind a host round trip: 28 GiB/s
+// where the link does two directions.  A copy KERNEL that reads the size on the device — exact, no host — was measured
+// too: its 1-2 ms on a hardware queue hold back the barrier packets of the other slots' copies, 28-34 GiB/s.)
+int pipe_prefetch(Slot &s, size_t pred, size_t cap)
+{
+    s.copied = 0;
+    if (!pred) return SHAFA_SUCCESS;
+    size_t nbytes = pred + pred / 32 + 4096;
+    if (nbytes > cap) nbytes = cap;
+    if (nbytes > s.h_out_cap) nbytes = s.h_out_cap;
+    HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, nbytes, hipMemcpyDeviceToHost, s.st));
+    s.copied = nbytes;
+    return SHAFA_SUCCESS;
+}
 
 int grow_pinned(u8 **p, size_t *cap, size_t need)
 {
@@ -63,7 +84,7 @@ int grow_dev(u8 **p, size_t *cap, size_t need)
     return SHAFA_SUCCESS;
 }
 
-int slot_submit(Slot &s, const shafa_code_table *table)
+int slot_submit(Slot &s, const shafa_code_table *table, const size_t pred)
 {
     int rc;
     DeviceGuard dg(s.device);                      // the caller's current device is restored on return
@@ -85,6 +106,7 @@ int slot_submit(Slot &s, const shafa_code_table *table)
         const u64 ocap[1] = {cap};
         if ((rc = rleenc_launch(s.batch, s.st, 1, s.d_in, off0, in_n, s.d_out, off0, ocap, d_size, s.d_small))) return rc;
         HIP_TRY(hipMemcpyAsync(s.h_small, s.d_small, 514 * sizeof(u64), hipMemcpyDeviceToHost, s.st));
+        if ((rc = pipe_prefetch(s, pred, cap))) return rc;
         break;
     }
     case SHAFA_OP_SF_ENCODE: {
@@ -94,6 +116,7 @@ int slot_submit(Slot &s, const shafa_code_table *table)
         const u64 ocap[1] = {s.out_cap};
         if ((rc = sfenc_launch(s.batch, s.st, 1, s.d_in, off0, in_n, table, s.d_out, off0, ocap, d_size))) return rc;
         HIP_TRY(hipMemcpyAsync(s.h_small + 512, d_size, sizeof(u64), hipMemcpyDeviceToHost, s.st));
+        if ((rc = pipe_prefetch(s, pred, s.out_cap))) return rc;
         break;
     }
     case SHAFA_OP_SF_DECODE: {
@@ -123,6 +146,7 @@ int slot_submit(Slot &s, const shafa_code_table *table)
         const u64 ocap[1] = {cap};
         if ((rc = rledec_launch(s.batch, s.st, 1, rle_in, off0, rle_n, s.d_out, off0, ocap, d_size))) return rc;
         HIP_TRY(hipMemcpyAsync(s.h_small + 512, d_size, sizeof(u64), hipMemcpyDeviceToHost, s.st));
+        if ((rc = pipe_prefetch(s, pred, cap))) return rc;
         break;
     }
     default:
@@ -205,7 +229,8 @@ int shafa_pipe_submit(shafa_pipe *p, int slot, int op, size_t in_n, const shafa_
     s.out_cap = out_cap;
     s.want_in_hist = (flags & SHAFA_PIPE_INPUT_HIST) != 0;
     s.busy = true;
-    s.rc = slot_submit(s, table);            // errors are reported by shafa_pipe_wait, in block order
+    s.copied = 0;
+    s.rc = slot_submit(s, table, (op >= 0 && op < 8) ? p->last_out[op] : 0);            // errors are reported by shafa_pipe_wait, in block order
     return SHAFA_SUCCESS;
 }
 
@@ -241,13 +266,14 @@ int shafa_pipe_wait(shafa_pipe *p, int slot, shafa_pipe_result *res)
     default:
         break;
     }
-    // the result's size is only known now: fetch exactly that many bytes (other slots keep the GPU busy)
+    // the size is known now: fetch what the speculative copy at submit did not bring (usually nothing)
     const size_t sz = (size_t)s.h_small[512];
     if (sz > s.h_out_cap) return SHAFA_LACK_OF_MEMORY;
-    if (sz) {
-        HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, sz, hipMemcpyDeviceToHost, s.st));
+    if (sz > s.copied) {
+        HIP_TRY(hipMemcpyAsync(s.h_out + s.copied, s.d_out + s.copied, sz - s.copied, hipMemcpyDeviceToHost, s.st));
         HIP_TRY(hipStreamSynchronize(s.st));
     }
+    if (s.op >= 0 && s.op < 8) p->last_out[s.op] = sz;
     res->out_n = sz;
     return SHAFA_SUCCESS;
 }

@@ -45,6 +45,27 @@ static void trace(const char *what, double t0)
 enum { PIPE_SLOTS_PER_DEVICE = 3, PIPE_SLOTS = 64 };        /* PIPE_SLOTS: upper bound (ticket arrays) */
 /* three blocks in flight per selected GPU (shafa_hip_init_devices): slot i works on device i mod n, results are retired
  * in submission order by the one writer thread as before */
+/* One pipe is kept between the modules of a process (the default `shafa file` runs F, T and C one after the other, each
+ * with the same three slots): its streams, pinned and device buffers are what a module's first blocks paid 150 ms for.
+ * A module that fails destroys its pipe (slots may still be busy); shafa_host_release() drops the kept one. */
+static shafa_pipe *g_kept_pipe = NULL;
+static int pipe_get(int depth, shafa_pipe **out)
+{
+    if (g_kept_pipe && shafa_pipe_slots(g_kept_pipe) == depth) { *out = g_kept_pipe; g_kept_pipe = NULL; return SHAFA_SUCCESS; }
+    if (g_kept_pipe) { shafa_pipe_destroy(g_kept_pipe); g_kept_pipe = NULL; }
+    return shafa_pipe_create(depth, out);
+}
+static void pipe_put(shafa_pipe *p, int err)
+{
+    if (!p) return;
+    if (err || g_kept_pipe) shafa_pipe_destroy(p);
+    else g_kept_pipe = p;
+}
+void shafa_host_release(void)
+{
+    if (g_kept_pipe) { shafa_pipe_destroy(g_kept_pipe); g_kept_pipe = NULL; }
+}
+
 static int pipe_depth(uint64_t n_blocks)
 {
     if (NO_MULTITHREAD) return 1;
@@ -375,7 +396,7 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
     shafa_pipe *pipe = NULL;
     shafa_pipe_result *res = malloc(sizeof(*res));
     if (!p_rle || !p_rle_freq || !p_freq || !sizes || !rle_sizes || !res) err = SHAFA_LACK_OF_MEMORY;
-    if (!err) err = shafa_pipe_create(pipe_depth(n_blocks), &pipe);
+    if (!err) err = pipe_get(pipe_depth(n_blocks), &pipe);
     const uint64_t depth = pipe ? (uint64_t)shafa_pipe_slots(pipe) : 1;
 
     /* submit block `sub`, retire block `ret`; block 0 is retired alone because it decides use_rle (f.c:250-258) */
@@ -433,7 +454,7 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
         const int werr = writer_stop(&wr);
         if (!err) err = werr;
     }
-    shafa_pipe_destroy(pipe);
+    pipe_put(pipe, err);
     free(res);
     if (f_rle >= 0) close(f_rle);
     if (f_rle_freq) fclose(f_rle_freq);
@@ -540,7 +561,7 @@ _modules_error shafa_compress(char **path)
     shafa_pipe_result *res = malloc(sizeof(*res));
     if (!err && !res) err = SHAFA_LACK_OF_MEMORY;
     trace("C: files open", t0);
-    if (!err) err = shafa_pipe_create(pipe_depth(n_blocks), &pipe);
+    if (!err) err = pipe_get(pipe_depth(n_blocks), &pipe);
     trace("C: pipe created", t0);
     const uint64_t depth = pipe ? (uint64_t)shafa_pipe_slots(pipe) : 1;
     uint64_t sub = 0, ret = 0, ticket[PIPE_SLOTS] = {0};
@@ -594,7 +615,7 @@ _modules_error shafa_compress(char **path)
         if (!err) err = werr;
     }
     trace("C: loop done", t0);
-    shafa_pipe_destroy(pipe);
+    pipe_put(pipe, err);
     trace("C: pipe destroyed", t0);
     free(res);
     if (out >= 0) close(out);
@@ -656,7 +677,7 @@ _modules_error rle_decompress(char **path)
     shafa_pipe *pipe = NULL;
     shafa_pipe_result *res = malloc(sizeof(*res));
     if (!err && !res) err = SHAFA_LACK_OF_MEMORY;
-    if (!err) err = shafa_pipe_create(pipe_depth(n_blocks), &pipe);
+    if (!err) err = pipe_get(pipe_depth(n_blocks), &pipe);
     const uint64_t depth = pipe ? (uint64_t)shafa_pipe_slots(pipe) : 1;
     uint64_t sub = 0, ret = 0, ticket[PIPE_SLOTS] = {0};
     writer_t wr;
@@ -685,7 +706,7 @@ _modules_error rle_decompress(char **path)
         const int werr = writer_stop(&wr);
         if (!err) err = werr;
     }
-    shafa_pipe_destroy(pipe);
+    pipe_put(pipe, err);
     free(res);
     if (out >= 0) close(out);
     close(in);
@@ -748,7 +769,7 @@ _modules_error shafa_decompress(char **path, bool decompress_rle)
     shafa_pipe *pipe = NULL;
     shafa_pipe_result *res = malloc(sizeof(*res));
     if (!err && !res) err = SHAFA_LACK_OF_MEMORY;
-    if (!err) err = shafa_pipe_create(pipe_depth(n_blocks), &pipe);
+    if (!err) err = pipe_get(pipe_depth(n_blocks), &pipe);
     const uint64_t depth = pipe ? (uint64_t)shafa_pipe_slots(pipe) : 1;
     uint64_t sub = 0, ret = 0, ticket[PIPE_SLOTS] = {0};
     writer_t wr;
@@ -799,7 +820,7 @@ _modules_error shafa_decompress(char **path, bool decompress_rle)
         if (!err) err = werr;
     }
     trace("D: loop done", t0);
-    shafa_pipe_destroy(pipe);
+    pipe_put(pipe, err);
     trace("D: pipe destroyed", t0);
     free(res);
     if (out >= 0) close(out);

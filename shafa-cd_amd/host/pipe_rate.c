@@ -48,13 +48,17 @@ int main(int argc, char **argv)
     for (int pass = 0; pass < 2; ++pass) {               /* pass 0 warms up (allocations), pass 1 is timed */
         const double t0 = now_ms();
         int sub = 0, ret = 0;
+        const int trace = pass && getenv("SHAFA_PIPE_TRACE") != NULL;      /* host time of every call of the timed pass */
         while (ret < nb) {
+            const double c0 = now_ms();
             if (sub < nb && sub - ret < slots) {
                 if (!shafa_pipe_in(p, sub % slots, n)) return 3;      /* input already there: only the H2D is paid */
                 if ((rc = shafa_pipe_submit(p, sub % slots, SHAFA_OP_SF_ENCODE, n, &tab, 0, cap, 0))) return 1;
+                if (trace) printf("  %8.3f ms submit %2d (slot %d) took %.3f ms\n", c0 - t0, sub, sub % slots, now_ms() - c0);
                 ++sub;
             } else {
                 if ((rc = shafa_pipe_wait(p, ret % slots, res))) { fprintf(stderr, "encode wait: %d\n", rc); return 1; }
+                if (trace) printf("  %8.3f ms wait   %2d (slot %d) took %.3f ms\n", c0 - t0, ret, ret % slots, now_ms() - c0);
                 enc_n = res->out_n;
                 if (!enc) { enc = malloc(enc_n); memcpy(enc, res->out, enc_n); }
                 ++ret;

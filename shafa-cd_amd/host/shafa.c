@@ -10,6 +10,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 typedef struct {
     unsigned long block_size;
@@ -168,10 +169,15 @@ int main(int argc, char *const argv[])
     }
     const int err = run_modules(&o, &file);
     free(file);
-    shafa_hip_shutdown();
-    if (err) {
-        if (err != SHAFA_OUTSIDE_MODULE) fputs(shafa_error_msg(err), stderr);
-        return 1;
+    if (err && err != SHAFA_OUTSIDE_MODULE) fputs(shafa_error_msg(err), stderr);
+    /* Every output file is written and closed by now.  Leave without tearing the GPU context down buffer by buffer (the
+     * kept pipe's pinned memory, the runtime's exit handlers: 0.1-0.15 s of a 0.7 s run on a 2 GiB file): the process ends
+     * here and the kernel driver reclaims all of it.  SHAFA_CLEAN_EXIT=1 takes the long way (leak checkers). */
+    fflush(NULL);
+    if (getenv("SHAFA_CLEAN_EXIT")) {
+        shafa_host_release();
+        shafa_hip_shutdown();
+        return err ? 1 : 0;
     }
-    return 0;
+    _exit(err ? 1 : 0);
 }

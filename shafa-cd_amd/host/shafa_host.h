@@ -65,6 +65,10 @@ bool shafa_rle_worthwhile(uint64_t n0, uint64_t rle0, bool force_rle);
 /* d.h:14 */ _modules_error shafa_decompress(char **path, bool decompress_rle);
 /* d.h:22 */ _modules_error rle_decompress(char **path);
 
+/* The module drivers keep one block pipeline (streams, pinned and device buffers) between calls of a process; this
+ * releases it (no reference counterpart: the reference allocates per block). */
+void shafa_host_release(void);
+
 /* multithread.h:19: kept for CLI compatibility; the GPU path has no per-block host threads, the flag
  * only selects one-block-at-a-time dispatch instead of batched dispatch. */
 extern bool NO_MULTITHREAD;

@@ -18,7 +18,7 @@ PY
 export LD_LIBRARY_PATH=$PWD/shafa-cd_amd:$LD_LIBRARY_PATH
 O=shafa-cd_amd/bin/shafa
 timeout 300 $O $D/z -m f -b M > /dev/null; timeout 60 $O $D/z.freq -m t > /dev/null
-s=$(date +%s%N); SHAFA_TRACE=1 timeout 300 $O $D/z -m c 2>&1 >/dev/null | tail -${2:-40}; e=$(date +%s%N); echo "total -m c $(( (e-s)/1000000 )) ms"
+s=$(date +%s%N); SHAFA_TRACE=1 timeout 300 $O $D/z -m c 2>$D/trace_c.txt >/dev/null; e=$(date +%s%N); head -${3:-30} $D/trace_c.txt; echo ...; tail -${2:-40} $D/trace_c.txt; echo "total -m c $(( (e-s)/1000000 )) ms"
 cp $D/z $D/z.orig
 s=$(date +%s%N); SHAFA_TRACE=1 timeout 300 $O $D/z.shaf -m d 2>&1 >/dev/null | tail -${2:-40}; e=$(date +%s%N); echo "total -m d $(( (e-s)/1000000 )) ms"
 cmp $D/z $D/z.orig && echo "round trip identical"
