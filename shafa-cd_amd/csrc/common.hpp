@@ -285,6 +285,7 @@ __device__ __forceinline__ void set_error(int *err, int code)
 // ---------------------------------------------------------------------------------------------
 // `first` (optional): the descriptors of tiles k-1-lane, loaded earlier by the caller so that the
 // round trip overlaps other work; used for the first window instead of a fresh load.
+template <int STRIDE = 1, int SLEEP = 1>
 __device__ __forceinline__ u64 lookback_sum(const u64 *desc, int k, int *err, bool have_first = false,
                                             u64 first = 0)
 {
@@ -297,7 +298,7 @@ __device__ __forceinline__ u64 lookback_sum(const u64 *desc, int k, int *err, bo
         SpinClock spin;
         for (;;) {
             if (have_first) d = first;
-            else d = (idx >= 0) ? desc_load(desc + idx) : (DESC_PREFIX << 62);
+            else d = (idx >= 0) ? desc_load(desc + (size_t)idx * STRIDE) : (DESC_PREFIX << 62);
             have_first = false;
             {   // entries behind the nearest inclusive prefix are not needed: do not wait for them
                 const u64 pm = __ballot((d >> 62) == DESC_PREFIX), em = __ballot((d >> 62) == DESC_EMPTY);
@@ -309,7 +310,7 @@ __device__ __forceinline__ u64 lookback_sum(const u64 *desc, int k, int *err, bo
                 if ((d >> 62) == DESC_EMPTY) d = (DESC_PREFIX << 62);
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(SLEEP);
         }
         const u64 val = d & DESC_VALUE_MASK;
         const u64 pmask = __ballot((d >> 62) == DESC_PREFIX);

@@ -23,8 +23,26 @@ namespace {
 constexpr int RLD_THREADS = 256;
 constexpr int RLD_BPL = 32;                        // bytes per lane
 constexpr int RLD_TILE = RLD_THREADS * RLD_BPL;
-constexpr int RLD_IMG = 16 * 1024;                 // bytes of the output image
+#ifndef RLD_IMG_KB
+#define RLD_IMG_KB 12
+#endif
+constexpr int RLD_IMG = RLD_IMG_KB * 1024;         // bytes of the output image
 constexpr u32 FN_IDENT = 0u | (1u << 2) | (2u << 4);
+#ifndef RLD_DSTRIDE
+#define RLD_DSTRIDE 4                              // u64 words between the descriptors of consecutive tiles
+#endif
+#ifndef RLD_SLEEP
+#define RLD_SLEEP 1
+#endif
+
+#ifdef RLD_STAMPS
+// diagnostic build only (tools/dbg/rld_stamps.py): per workgroup eight phase stamps in 100 MHz ticks
+constexpr u32 RLD_NSTAMP = 1u << 16;
+__device__ unsigned long long rld_stamp_buf[RLD_NSTAMP * 8];
+#define RLD_STAMP(slot) do { if (tid == 0 && blockIdx.x < RLD_NSTAMP) rld_stamp_buf[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RLD_STAMP(slot)
+#endif
 
 // per 8-bit zero mask (bit i = byte i is 0) and entry state s: bits [10 s, 10 s + 8) = token starts, [10 s + 8, 10 s + 10) = exit
 struct RldFsm {
@@ -83,7 +101,7 @@ __device__ __forceinline__ u32 lookback_state(const u64 *desc, int k, int *err)
         u64 d = 0;
         SpinClock spin;
         for (;;) {
-            d = (idx >= 0) ? desc_load(desc + idx) : (DESC_PREFIX << 62);
+            d = (idx >= 0) ? desc_load(desc + (size_t)idx * RLD_DSTRIDE) : (DESC_PREFIX << 62);
             {   // entries behind the nearest tile that settles the state are not needed: do not wait for them
                 const bool empty = (d >> 62) == DESC_EMPTY;
                 const u64 sm = __ballot(!empty && ((d >> 62) == DESC_PREFIX || fn_const((u32)d & 63u))), em = __ballot(empty);
@@ -95,7 +113,7 @@ __device__ __forceinline__ u32 lookback_state(const u64 *desc, int k, int *err)
                 if ((d >> 62) == DESC_EMPTY) d = (DESC_PREFIX << 62);
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(RLD_SLEEP);
         }
         const u32 val = (u32)d & 63u;
         const bool isP = (d >> 62) == DESC_PREFIX;
@@ -131,6 +149,21 @@ struct RldShared {
     u64 O;
 };
 
+// zero mask of 32 bytes -> token-start mask and exit state for each of the three entry states
+__device__ __forceinline__ void fsm32(const u32 *fsm, u32 z, u32 (&st3)[3], u32 (&ex3)[3])
+{
+    const u32 e0 = fsm[z & 255u], e1 = fsm[(z >> 8) & 255u], e2 = fsm[(z >> 16) & 255u], e3 = fsm[z >> 24];
+#pragma unroll
+    for (int s0 = 0; s0 < 3; ++s0) {
+        u32 x = (e0 >> (10 * s0)) & 1023u, starts = x & 255u;
+        x = (e1 >> (10 * (x >> 8))) & 1023u; starts |= (x & 255u) << 8;
+        x = (e2 >> (10 * (x >> 8))) & 1023u; starts |= (x & 255u) << 16;
+        x = (e3 >> (10 * (x >> 8))) & 1023u; starts |= (x & 255u) << 24;
+        st3[s0] = starts;
+        ex3[s0] = x >> 8;
+    }
+}
+
 // bit i of a nibble -> 0x01 in byte i
 __device__ __forceinline__ u32 nib_flags(u32 mask, int i) { return __umul24((mask >> (4 * i)) & 15u, 0x00204081u) & 0x01010101u; }
 
@@ -151,7 +184,10 @@ __device__ __forceinline__ void rld_fill(u8 *smem, u32 p, u32 sym, u32 c)
         if (q < (c & 3u)) smem[p + q] = (u8)sym;
 }
 
-__global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *__restrict__ blks, int nblk,
+#ifndef RLD_WAVES
+#define RLD_WAVES 7
+#endif
+__global__ __launch_bounds__(RLD_THREADS) __attribute__((amdgpu_waves_per_eu(RLD_WAVES, RLD_WAVES))) void rle_decode_kernel(const RldBlk *__restrict__ blks, int nblk,
                                                                  u64 *desc_state, u64 *desc_sum, u32 *tickets)
 {
     __shared__ __attribute__((aligned(16))) RldShared sh;
@@ -159,18 +195,30 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
     const int b = blockIdx.x % nblk;
     const RldBlk blk = blks[b];
     if ((u32)(blockIdx.x / nblk) >= blk.n_tiles) return;
+    RLD_STAMP(0);
+#ifdef RLD_NOTICKET                                     // A/B build: the tile index from the grid position (relies on in-order dispatch)
+    if (tid == 0) sh.tile = blockIdx.x / nblk;
+#else
     if (tid == 0) sh.tile = atomicAdd(tickets + blk.ticket, 1u);
+#endif
     sh.fsm[tid] = g_rld_fsm.v[tid];
     if (tid < 2) *(uint4 *)(sh.in + RLD_TILE + 16 * tid) = make_uint4(0, 0, 0, 0);
     lds_barrier();
+    RLD_STAMP(1);
     const int k = (int)sh.tile;
     const u64 n = blk.n;
     const u64 pos = (u64)k * RLD_TILE + (u64)tid * RLD_BPL;
-    u64 *dst = desc_state + blk.desc_base, *dsum = desc_sum + blk.desc_base;
+    u64 *dst = desc_state + (size_t)blk.desc_base * RLD_DSTRIDE, *dsum = desc_sum + (size_t)blk.desc_base * RLD_DSTRIDE;
 
     // ---- the lane's 32 bytes -> registers and LDS; zero mask ---------------------------------------------------
     u32 w[9];
     int nvalid = 0;
+    uint4 pv0 = make_uint4(0, 0, 0, 0), pv1 = pv0;             // wave 0: the 32 bytes in front of the tile (one address for all lanes)
+    if (wv == 0 && k > 0) {
+        const u8 *q = blk.in + (u64)k * RLD_TILE - 32;
+        pv0 = *(const uint4 *)q;
+        pv1 = *(const uint4 *)(q + 16);
+    }
     if (pos + RLD_BPL <= n) {
         const uint4 v0 = gload_nt<uint4>(blk.in + pos), v1 = gload_nt<uint4>(blk.in + pos + 16);
         w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
@@ -191,6 +239,10 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
     }
     const u32 vm = nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
     const u32 z = zmask32(w) & vm;
+#ifdef RLD_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RLD_STAMP(2);
+#endif
 
     // ---- this lane's transition map and token starts for each entry state, ordered scan over lanes and waves --------
     // A wave without a zero byte (text-like data: nearly every wave): every byte is a literal once the state is S0, which
@@ -202,16 +254,17 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
         st3[0] = 0xFFFFFFFFu; st3[1] = 0xFFFFFFFCu; st3[2] = 0xFFFFFFFEu;
         ex3[0] = ex3[1] = ex3[2] = 0;
     } else {
-        const u32 e0 = sh.fsm[z & 255u], e1 = sh.fsm[(z >> 8) & 255u], e2 = sh.fsm[(z >> 16) & 255u], e3 = sh.fsm[z >> 24];
-#pragma unroll
-        for (int s0 = 0; s0 < 3; ++s0) {
-            u32 x = (e0 >> (10 * s0)) & 1023u, starts = x & 255u;
-            x = (e1 >> (10 * (x >> 8))) & 1023u; starts |= (x & 255u) << 8;
-            x = (e2 >> (10 * (x >> 8))) & 1023u; starts |= (x & 255u) << 16;
-            x = (e3 >> (10 * (x >> 8))) & 1023u; starts |= (x & 255u) << 24;
-            st3[s0] = starts;
-            ex3[s0] = x >> 8;
-        }
+        fsm32(sh.fsm, z, st3, ex3);
+    }
+    // The state the tile is entered in, without waiting for anybody: two non-zero bytes in a row end in S0 whatever the state
+    // before them (literal literal / symbol count / count literal), so the map of the 32 bytes in front of the tile is
+    // almost always constant, and then it IS the entry state.  Only a tile behind 32 bytes of zero-heavy triples looks back.
+    u32 fprev = FN_IDENT;
+    if (wv == 0 && k > 0) {
+        const u32 pw[8] = {pv0.x, pv0.y, pv0.z, pv0.w, pv1.x, pv1.y, pv1.z, pv1.w};
+        u32 pst[3], pex[3];
+        fsm32(sh.fsm, zmask32(pw), pst, pex);
+        fprev = pex[0] | (pex[1] << 2) | (pex[2] << 4);
     }
     // bytes past the end of the block do not move the state (vm clears them from every mask below)
     u32 f = ex3[0] | (ex3[1] << 2) | (ex3[2] << 4);
@@ -231,6 +284,7 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
         if (lane == 0) fex = FN_IDENT;
     }
     lds_barrier();
+    RLD_STAMP(3);
     u32 wcar = FN_IDENT, ftile = FN_IDENT;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -243,17 +297,20 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
         u32 sin = 0;
         if (k > 0) {
             if (tid == 0) {
-                if (fn_const(ftile)) desc_store(dst + k, DESC_PREFIX, ftile & 3);
-                else desc_store(dst + k, DESC_AGG, ftile);
+                if (fn_const(ftile)) desc_store(dst + (size_t)k * RLD_DSTRIDE, DESC_PREFIX, ftile & 3);
+                else desc_store(dst + (size_t)k * RLD_DSTRIDE, DESC_AGG, ftile);
             }
-            sin = lookback_state(dst, k, blk.err);
+#ifndef RLD_ABL_NOLB
+            sin = fn_const(fprev) ? (fprev & 3u) : lookback_state(dst, k, blk.err);
+#endif
         }
         if (tid == 0) {
-            desc_store(dst + k, DESC_PREFIX, fn_apply(ftile, sin));
+            desc_store(dst + (size_t)k * RLD_DSTRIDE, DESC_PREFIX, fn_apply(ftile, sin));
             sh.state_in = sin;
         }
     }
     lds_barrier();
+    RLD_STAMP(4);
 
     // ---- literal / escape masks, per-byte output lengths ------------------------------------------------------------
     // (uniform) a tile of waves without zero bytes that is entered at a token start: its output is its input
@@ -303,22 +360,20 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
     const u32 ilen = wave_incl_scan_add<u32>(len);
     if (lane == 63) sh.wlen[wv] = ilen;
     lds_barrier();
+    RLD_STAMP(5);
     u32 lbase = 0, ltot = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (q == wv) lbase = ltot + ilen - len;
         ltot += sh.wlen[q];
     }
-    if (wv == 0) {
-        u64 O = 0;
-        if (k > 0) {
-            if (tid == 0) desc_store(dsum + k, DESC_AGG, ltot);
-            O = lookback_sum(dsum, k, blk.err);
-        }
-        if (tid == 0) {
-            desc_store(dsum + k, DESC_PREFIX, O + ltot);
-            sh.O = O;
-        }
+    // wave 0 publishes the tile's total and asks for its predecessors' descriptors now; it reads the answer after its share of
+    // the image (first round below), so the round trip costs the tile nothing when the predecessors have published
+    u64 lb_first = 0;
+    if (wv == 0 && k > 0) {
+        if (tid == 0) desc_store(dsum + (size_t)k * RLD_DSTRIDE, DESC_AGG, ltot);
+        const int idx = k - 1 - lane;
+        lb_first = idx >= 0 ? desc_load(dsum + (size_t)idx * RLD_DSTRIDE) : (DESC_PREFIX << 62);
     }
 
     // ---- the output, in rounds of what the image holds: image byte i = output byte O + done + i ----------------------
@@ -346,6 +401,7 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
                 u32 p = p0;
                 const u32 p_end = p0 + len;
                 const u32 dump = (u32)offsetof(RldShared, dump) + 4u * (u32)tid;
+#ifndef RLD_ABL_NOLIT                                   // (A/B builds, wrong output: tools/dbg/rld_stamps.py)
 #pragma unroll
                 for (int i = 0; i < RLD_BPL / 4; ++i) {
                     smem[p < p_end ? p : dump] = (u8)w[i];          p = add_byte<0>(p, lenw[i]);
@@ -353,8 +409,12 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
                     smem[p < p_end ? p : dump] = (u8)(w[i] >> 16);  p = add_byte<2>(p, lenw[i]);
                     smem[p < p_end ? p : dump] = (u8)(w[i] >> 24);  p = add_byte<3>(p, lenw[i]);
                 }
+#endif
             }
             u32 g = 0;                                  // bytes of the runs so far
+#ifdef RLD_ABL_NOFILL
+            if (0)
+#endif
             for (u32 e = E; e; e &= e - 1) {            // runs: the lane's escapes in order
                 const u32 j = (u32)__builtin_ctz(e);
                 const u32 sym = smem[in_off + j + 1], c0 = smem[in_off + j + 2], c = c0 ? c0 : 1u;
@@ -362,8 +422,23 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
                 g += c;
             }
         }
+        if (done == 0 && wv == 0) {
+            u64 O0 = 0;
+            if (k > 0) {
+#ifndef RLD_ABL_NOLB
+                O0 = lookback_sum<RLD_DSTRIDE, RLD_SLEEP>(dsum, k, blk.err, true, lb_first);
+#else
+                O0 = (u64)k * 8192u;
+#endif
+            }
+            if (tid == 0) {
+                desc_store(dsum + (size_t)k * RLD_DSTRIDE, DESC_PREFIX, O0 + ltot);
+                sh.O = O0;
+            }
+        }
         lds_barrier();                                // the image is complete (and, the first time, O has arrived)
         if (done == 0) {
+            RLD_STAMP(6);
             O = sh.O;
             const u64 Oend = O + ltot;
             if (Oend > (u64)SHAFA_RLE_DECODE_MAX) { if (tid == 0) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE); }
@@ -375,6 +450,9 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
         u8 *gout = blk.out + O + done;
         const u32 mis = (u32)((uintptr_t)gout & 15u), nbytes = nxt - done;
         const u64 gidx = O + done;                      // index of image byte 0 in the block's output
+#ifdef RLD_ABL_NOSTORE
+        if (ltot == 0xFFFFFFFFu)
+#endif
         for (u32 u = tid; 16 * u < mis + nbytes; u += RLD_THREADS) {
             const u32 s0 = src_off + 16 * u - mis, sb = s0 & ~3u, sf = s0 & 3u;
             const u32 d0 = *(const u32 *)__builtin_assume_aligned(smem + sb, 4), d1 = *(const u32 *)__builtin_assume_aligned(smem + sb + 4, 4),
@@ -397,7 +475,19 @@ __global__ __launch_bounds__(RLD_THREADS) void rle_decode_kernel(const RldBlk *_
         if (done >= ltot) break;
         lds_barrier();                                // the image is read out before the next round writes it
     }
+#ifdef RLD_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RLD_STAMP(7);
+#endif
 }
+
+#ifdef RLD_STAMPS
+extern "C" int shafa_rld_read_stamps(unsigned long long *dst, int n)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(rld_stamp_buf), (size_t)n * 8) == hipSuccess ? 0 : 9;
+}
+#endif
+
 
 }  // namespace
 
@@ -415,8 +505,8 @@ int rledec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
         if (t > max_tiles) max_tiles = (u32)t;
     }
     size_t off = 0;
-    const size_t o_state = off; off += ndesc * 8;
-    const size_t o_sum = off; off += ndesc * 8;
+    const size_t o_state = off; off += ndesc * 8 * RLD_DSTRIDE;
+    const size_t o_sum = off; off += ndesc * 8 * RLD_DSTRIDE;
     const size_t o_tick = off; off += (size_t)nblocks * 4; off = (off + 15) & ~(size_t)15;
     const size_t o_zero_end = off;
     const size_t o_blk = off; off += (size_t)nblocks * sizeof(RldBlk);
