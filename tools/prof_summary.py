@@ -109,7 +109,7 @@ if total_in:
             a[x] = args[i + 1]
     j = {"what": "HBM traffic from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, tools/gpu_prof.sh); "
                  "FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes",
-         "workload_key": f"{a['--dist']}:{float(a['--zipf-s']):g}:{a['--block-mib']}:{a['--blocks']}",
+         "workload_key": f"{a['--dist']}:{float(a['--zipf-s']):g}:{a['--block-mib']}:{a['--blocks']}" + (":chained" if "--no-tiles" in args else ""),
          # a profile of one pipeline leg alone (--pipeline-only --pipeline-kind K): what bench.py's `pipeline` objects take
          # their per-family traffic from; a headline profile carries null
          "pipeline_key": ("pipeline:%s:%s:%s" % (next((args[i + 1] for i, x in enumerate(args) if x == "--pipeline-kind"), "runs"), a["--block-mib"],

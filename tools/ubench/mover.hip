@@ -76,7 +76,7 @@ int main()
         const u64 nwg = n / (256ull * 16 * U); \
         const u32 grid = PERSIST ? (u32)(GRID) : (u32)nwg; \
         float ms = time_ms([&] { hipLaunchKernelGGL((k_move<U, S32, NTL, NTS, LDSRT, PERSIST>), dim3(grid), dim3(256), 0, 0, d_a, d_b, nwg); }, 5); \
-        printf("%-64s %7.3f ms  %5.2f TB/s  (of 8 TB/s: %.3f)\n", NAME, ms, bytes / ms / 1e9, bytes / ms / 1e9 / 8000.0); }
+        printf("%-64s %7.3f ms  %5.2f TB/s  (of 8 TB/s: %.3f)\n", NAME, ms, bytes / ms / 1e9, bytes / ms / 1e9 / 8.0); }
     for (int rep = 0; rep < 2; ++rep) {
         RUN("one-shot 32 KiB/WG coalesced, plain ld, nt st", 8, false, false, true, false, false, 0)
         RUN("one-shot 32 KiB/WG coalesced, nt ld, nt st", 8, false, true, true, false, false, 0)
