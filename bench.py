@@ -702,7 +702,7 @@ def main():
         legs = {}
         for kind in ([args.pipeline_kind] if args.pipeline_kind else ["runs", "mixed"]):
             try:
-                legs[kind] = pipeline_leg(args, pkg, torch, dev, st, 3, pnb, kind)
+                legs[kind] = pipeline_leg(args, pkg, torch, dev, st, 8, pnb, kind)
             except AssertionError:
                 raise                                  # a parity failure is never swallowed
             except Exception as e:                     # (memory on a small device: the headline line must still come out)
