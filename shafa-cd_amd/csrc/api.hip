@@ -112,6 +112,11 @@ u8 *batch_params_begin(Batch *b, size_t bytes)
     const int i = b->par_turn;
     b->par_turn ^= 1;
     b->par_cur = i;
+#ifndef PARAMS_ALWAYS_SIDE
+    b->par_inline = !b->par_dma && bytes <= PARAMS_INLINE_BYTES;   // the caller stages on the stream that will read the staging arena
+#else
+    b->par_inline = false;
+#endif
     if (bytes > b->par_bytes[i]) {                     // grow: the kernels that read the old buffer must be through
         if (b->par_used[i] && hipEventSynchronize(b->par_free[i]) != hipSuccess) return nullptr;
         if (b->d_par[i]) (void)hipFree(b->d_par[i]);
@@ -124,11 +129,40 @@ u8 *batch_params_begin(Batch *b, size_t bytes)
     return (u8 *)b->d_par[i];
 }
 
+// The parameter upload as a kernel that reads the pinned staging arena (host memory the device can address): above 16 KB
+// hipMemcpyAsync hands a host-to-device copy to the SDMA engine, and a launch of 8..30 blocks then waited ~0.6 ms for its
+// 17..60 KB of parameters (tools/dbg/small_launch_encode.sh: 8 x 64 MiB encoded in 790 us, 7 x 64 MiB in 190 us).
+// Except in a pipe (layer 3): there the link is busy with the blocks themselves and a kernel's reads of host memory queue
+// behind 64 MiB transfers (decode 41 -> 34 GiB/s, tools/dbg/pipe_rate_ab.sh), while the engine's latency hides behind the
+// block's own transfer as long as the copy is NOT in the slot's stream (there it starts after the block has arrived: 33
+// GiB/s as well): a pipe slot's batch (par_dma) keeps hipMemcpyAsync on the side stream.
+__global__ __launch_bounds__(256) void param_copy_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 int batch_params_commit(Batch *b, hipStream_t st, const void *hs, size_t bytes)
 {
     const int i = b->par_cur;
+    const size_t n16 = (bytes + 15) / 16;              // the arena is handed out in 64-byte units, the device buffer has slack
+    const size_t wgs = (n16 + 255) / 256;
+    if (b->par_inline) {
+        // a few blocks' worth (layer 3 submits one block per launch): in the launch's own stream, in order — a pipe's slots
+        // already outnumber the hardware queues, and a side stream's kernel would wait behind another slot's kernels
+        if (n16) {
+            hipLaunchKernelGGL(param_copy_kernel, dim3((unsigned)wgs), dim3(256), 0, st, (uint4 *)b->d_par[i], (const uint4 *)hs, n16);
+            HIP_TRY(hipGetLastError());
+        }
+        return SHAFA_SUCCESS;
+    }
     if (b->par_used[i]) HIP_TRY(hipStreamWaitEvent(b->copy_st, b->par_free[i], 0));
-    HIP_TRY(hipMemcpyAsync(b->d_par[i], hs, bytes, hipMemcpyHostToDevice, b->copy_st));
+    if (b->par_dma) {
+        if (bytes) HIP_TRY(hipMemcpyAsync(b->d_par[i], hs, bytes, hipMemcpyHostToDevice, b->copy_st));
+    } else if (n16) {
+        hipLaunchKernelGGL(param_copy_kernel, dim3((unsigned)(wgs < 512 ? wgs : 512)), dim3(256), 0, b->copy_st,
+                           (uint4 *)b->d_par[i], (const uint4 *)hs, n16);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(b->par_ready[i], b->copy_st));
     HIP_TRY(hipStreamWaitEvent(st, b->par_ready[i], 0));
     return SHAFA_SUCCESS;

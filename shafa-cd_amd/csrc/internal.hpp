@@ -16,6 +16,9 @@ struct StageSeg {
 };
 
 // Reusable per-batch context behind the opaque shafa_hipd_batch handle.
+// parameter uploads of at most this many bytes go into the launch's stream (api.hip, batch_params_commit)
+constexpr size_t PARAMS_INLINE_BYTES = 64 * 1024;
+
 struct Batch {
     int device;            // the device the batch was created on: its workspace, error words and kernels live there
     hipStream_t last_st;   // the stream of the batch's last launch (a batch serves ONE stream at a time: a launch on a
@@ -42,6 +45,8 @@ struct Batch {
     hipEvent_t par_ready[2], par_free[2];
     bool par_used[2];
     int par_turn, par_cur;
+    bool par_inline;            // this launch's parameters are copied in the launch's own stream (few blocks), not on copy_st
+    bool par_dma;               // the batch belongs to a pipe slot: parameters by hipMemcpyAsync on the side stream (api.hip)
 };
 
 // Every layer-2 entry point starts with this: checks that the calling thread's current device is the batch's, and

@@ -180,6 +180,7 @@ int shafa_pipe_create(int n_slots, shafa_pipe **out)
         if (e != hipSuccess) { shafa_pipe_destroy(p); return shafa_set_hip_error(e, "shafa_pipe_create"); }
         if ((rc = shafa_hipd_batch_create(1, (size_t)1 << 27, &bh))) { shafa_pipe_destroy(p); return rc; }
         s.batch = (Batch *)bh;
+        s.batch->par_dma = true;                        // see batch_params_commit
     }
     *out = p;
     return SHAFA_SUCCESS;

@@ -2291,7 +2291,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     // (batch_params_*): the copy overlaps the launch before this one instead of sitting in front of sfd_tables
     u8 *dpar = batch_params_begin(bt, stage_bytes);
     if (!dpar) return SHAFA_LACK_OF_MEMORY;
-    u8 *hs = (u8 *)batch_stage(bt, bt->copy_st, stage_bytes);
+    u8 *hs = (u8 *)batch_stage(bt, bt->par_inline ? st : bt->copy_st, stage_bytes);
     if (!hs) return SHAFA_LACK_OF_MEMORY;
     DecBlk *hb = (DecBlk *)hs;
     size_t tpos = o_tab;

@@ -306,7 +306,7 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const size_t stage_bytes = off - o_blk;
     u8 *dpar = batch_params_begin(bt, stage_bytes);
     if (!dpar) return SHAFA_LACK_OF_MEMORY;
-    u8 *hs = (u8 *)batch_stage(bt, bt->copy_st, stage_bytes);
+    u8 *hs = (u8 *)batch_stage(bt, bt->par_inline ? st : bt->copy_st, stage_bytes);
     if (!hs) return SHAFA_LACK_OF_MEMORY;
     EncBlk *hb = (EncBlk *)hs;
     u8 *htab = hs + (o_tab - o_blk);
