@@ -141,6 +141,23 @@ __global__ __launch_bounds__(256) void param_copy_kernel(uint4 *__restrict__ dst
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
+// The small per-launch records of the other launchers (hist, rle_encode, rle_decode), in the launch's stream: the same
+// kernel once the runtime would take the SDMA engine for them (more than 16 KB: hundreds of blocks), hipMemcpyAsync below
+// that and in a pipe.  `src` is in the batch's pinned staging arena (64-byte units), `dst` 16-byte aligned with room for
+// the last piece.
+int batch_upload(Batch *b, hipStream_t st, void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return SHAFA_SUCCESS;
+    if (b->par_dma || bytes <= 16384 || (bytes & 15) || ((uintptr_t)dst & 15)) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+        return SHAFA_SUCCESS;
+    }
+    const size_t n16 = bytes / 16, wgs = (n16 + 255) / 256;
+    hipLaunchKernelGGL(param_copy_kernel, dim3((unsigned)(wgs < 512 ? wgs : 512)), dim3(256), 0, st, (uint4 *)dst, (const uint4 *)src, n16);
+    HIP_TRY(hipGetLastError());
+    return SHAFA_SUCCESS;
+}
+
 int batch_params_commit(Batch *b, hipStream_t st, const void *hs, size_t bytes)
 {
     const int i = b->par_cur;

@@ -168,7 +168,7 @@ int hist_launch_dev(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, cons
     }
     HIP_TRY(hipMemsetAsync(d_freq, 0, (size_t)nblocks * 256 * sizeof(u64), st));
     if (max_n == 0) return SHAFA_SUCCESS;
-    HIP_TRY(hipMemcpyAsync(bt->d_par_hist, hp, pbytes, hipMemcpyHostToDevice, st));
+    { const int urc = batch_upload(bt, st, bt->d_par_hist, hp, pbytes); if (urc) return urc; }
     const dim3 grid((u32)ceil_div_u64(max_n, HIST_CHUNK), (u32)nblocks);
     const HistBlk *dp = (const HistBlk *)bt->d_par_hist;
     if (d_thist && d_n) hipLaunchKernelGGL(hist256_tiles_kernel<true>, grid, dim3(HIST_THREADS), 0, st, dp);

@@ -83,6 +83,7 @@ void batch_stage_retire(Batch *b, hipStream_t st);
 //   ... kernels on `st` ...
 //   batch_params_done(b, st)                  the buffer is free again once these kernels have run
 u8 *batch_params_begin(Batch *b, size_t bytes);
+int batch_upload(Batch *b, hipStream_t st, void *dst, const void *src, size_t bytes);
 int batch_params_commit(Batch *b, hipStream_t st, const void *hs, size_t bytes);
 int batch_params_done(Batch *b, hipStream_t st);
 

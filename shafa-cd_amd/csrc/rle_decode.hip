@@ -532,7 +532,7 @@ int rledec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
     }
     HIP_TRY(hipMemsetAsync(ws, 0, o_zero_end, st));
     HIP_TRY(hipMemsetAsync(d_out_n, 0, (size_t)nblocks * 8, st));
-    HIP_TRY(hipMemcpyAsync(ws + o_blk, hb, (size_t)nblocks * sizeof(RldBlk), hipMemcpyHostToDevice, st));
+    if ((rc = batch_upload(bt, st, ws + o_blk, hb, (size_t)nblocks * sizeof(RldBlk)))) return rc;
     if (max_tiles) {
         hipLaunchKernelGGL(rle_decode_kernel, dim3(max_tiles * (u32)nblocks), dim3(RLD_THREADS), 0, st,
                            (const RldBlk *)(ws + o_blk), nblocks, (u64 *)(ws + o_state), (u64 *)(ws + o_sum),

@@ -1078,7 +1078,7 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
         dbase += e.n_tiles;
     }
     HIP_TRY(hipMemsetAsync(d_out_n, 0, (size_t)nblocks * 8, st));      // empty blocks: size 0
-    HIP_TRY(hipMemcpyAsync(ws + o_blk, hb, (size_t)nblocks * sizeof(RleBlk), hipMemcpyHostToDevice, st));
+    if ((rc = batch_upload(bt, st, ws + o_blk, hb, (size_t)nblocks * sizeof(RleBlk)))) return rc;
     if (max_tiles) {
         const RleBlk *dblk = (const RleBlk *)(ws + o_blk);
         const dim3 grid_t((max_tiles + 1) / 2, (u32)nblocks), grid_b((u32)nblocks);     // two tiles per workgroup
