@@ -6,6 +6,13 @@
 //     fread(block b+2)  ‖  H2D(block b+1)  ‖  kernels(block b)  ‖  D2H(block b-1)  ‖  fwrite(block b-2)
 // with at most n_slots blocks in flight.  The caller fills shafa_pipe_in(slot), submits, and retires
 // slots in submission order, which is the reference's ordered-write chain (multithread.c:75-86).
+//
+// Transfers (round 4): the blocks' H2D copies of all slots of a device go through ONE stream, chained to the slot's kernel
+// stream by an event; the payload D2H copies have a stream per slot.  With the H2D in its slot's own stream, two slots'
+// blocks crossed the link at the same time at half its rate each, both slots' kernels and D2H then started late together and
+// the host-to-device direction idled meanwhile (tools/dbg/pipe_trace.sh): 37-39 GiB/s encode.  In submission order every
+// block has the whole link: 49 GiB/s.  The other direction is the opposite: one D2H stream for all slots stops at 38-39
+// GiB/s (decode), two at 39.5, one per slot reaches 41-43 (tools/dbg/pipe_rate_ab.sh).
 #include "common.hpp"
 #include "internal.hpp"
 
@@ -33,6 +40,9 @@ struct Slot {
     size_t in_n, out_cap, n_symbols;
     size_t copied;             // bytes of the result fetched speculatively at submit (pipe_prefetch)
     int rc;                    // error found while submitting
+    hipStream_t st_h2d, st_d2h;   // the device's H2D stream (shared by its slots, owned by the pipe); the slot's D2H stream
+    hipEvent_t ev_in, ev_k, ev_out;   // block on the device / kernels done / payload on the host
+    bool out_queued;           // a payload copy was queued on st_d2h (ev_out recorded)
 };
 
 }  // namespace
@@ -41,6 +51,8 @@ struct shafa_pipe {
     int n_slots;
     Slot *slots;
     size_t last_out[8];        // per op: result size of the block retired last (what the next submit fetches ahead)
+    int n_xf;                  // H2D streams, one per device the slots live on
+    struct { int device; hipStream_t h2d; } xf[64];
 };
 
 namespace {
@@ -52,6 +64,18 @@ namespace {
 // whole payload from shafa_pipe_wait, after the host has seen the size, put every D2H behind a host round trip: 28 GiB/s
 // where the link does two directions.  A copy KERNEL that reads the size on the device — exact, no host — was measured
 // too: its 1-2 ms on a hardware queue hold back the barrier packets of the other slots' copies, 28-34 GiB/s.)
+// the first nbytes of the slot's result, behind the kernels queued so far, on the device's D2H stream
+int pipe_payload(Slot &s, size_t nbytes)
+{
+    if (!nbytes) return SHAFA_SUCCESS;
+    HIP_TRY(hipEventRecord(s.ev_k, s.st));
+    HIP_TRY(hipStreamWaitEvent(s.st_d2h, s.ev_k, 0));
+    HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, nbytes, hipMemcpyDeviceToHost, s.st_d2h));
+    HIP_TRY(hipEventRecord(s.ev_out, s.st_d2h));
+    s.out_queued = true;
+    return SHAFA_SUCCESS;
+}
+
 int pipe_prefetch(Slot &s, size_t pred, size_t cap)
 {
     s.copied = 0;
@@ -59,7 +83,8 @@ int pipe_prefetch(Slot &s, size_t pred, size_t cap)
     size_t nbytes = pred + pred / 32 + 4096;
     if (nbytes > cap) nbytes = cap;
     if (nbytes > s.h_out_cap) nbytes = s.h_out_cap;
-    HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, nbytes, hipMemcpyDeviceToHost, s.st));
+    const int rc = pipe_payload(s, nbytes);
+    if (rc) return rc;
     s.copied = nbytes;
     return SHAFA_SUCCESS;
 }
@@ -91,7 +116,11 @@ int slot_submit(Slot &s, const shafa_code_table *table, const size_t pred)
     if ((rc = batch_enter(s.batch, s.st))) return rc;
     const u64 off0[1] = {0}, in_n[1] = {s.in_n};
     if ((rc = grow_dev(&s.d_in, &s.d_in_cap, s.in_n))) return rc;
-    if (s.in_n) HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, s.in_n, hipMemcpyHostToDevice, s.st));
+    if (s.in_n) {                                  // the block: the device's H2D stream, in submission order
+        HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, s.in_n, hipMemcpyHostToDevice, s.st_h2d));
+        HIP_TRY(hipEventRecord(s.ev_in, s.st_h2d));
+        HIP_TRY(hipStreamWaitEvent(s.st, s.ev_in, 0));
+    }
     u64 *d_size = s.d_small + 512;
     switch (s.op) {
     case SHAFA_OP_HIST:
@@ -125,7 +154,7 @@ int slot_submit(Slot &s, const shafa_code_table *table, const size_t pred)
         if ((rc = grow_pinned(&s.h_out, &s.h_out_cap, s.n_symbols))) return rc;
         const u64 ns[1] = {s.n_symbols};
         if ((rc = sfdec_launch(s.batch, s.st, 1, s.d_in, off0, in_n, table, ns, s.d_out, off0))) return rc;
-        if (s.n_symbols) HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, s.n_symbols, hipMemcpyDeviceToHost, s.st));
+        if ((rc = pipe_payload(s, s.n_symbols))) return rc;
         break;
     }
     case SHAFA_OP_RLE_DECODE:
@@ -175,6 +204,20 @@ int shafa_pipe_create(int n_slots, shafa_pipe **out)
         s.device = api_pipe_device(i, n_slots);
         DeviceGuard dg(s.device);
         hipError_t e = hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking);
+        int x = 0;
+        while (x < p->n_xf && p->xf[x].device != s.device) ++x;
+        if (e == hipSuccess && x == p->n_xf) {          // the device's first slot: its H2D stream
+            p->xf[x].device = s.device;
+            e = hipStreamCreateWithFlags(&p->xf[x].h2d, hipStreamNonBlocking);
+            if (e == hipSuccess) p->n_xf = x + 1;
+        }
+        if (e == hipSuccess) {
+            s.st_h2d = p->xf[x].h2d;
+            e = hipStreamCreateWithFlags(&s.st_d2h, hipStreamNonBlocking);
+        }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_k, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming);
         if (e == hipSuccess) e = hipMalloc((void **)&s.d_small, 514 * sizeof(u64));
         if (e == hipSuccess) e = hipHostMalloc((void **)&s.h_small, 514 * sizeof(u64), hipHostMallocPortable);
         if (e != hipSuccess) { shafa_pipe_destroy(p); return shafa_set_hip_error(e, "shafa_pipe_create"); }
@@ -192,7 +235,12 @@ void shafa_pipe_destroy(shafa_pipe *p)
     for (int i = 0; i < p->n_slots; ++i) {
         Slot &s = p->slots[i];
         DeviceGuard dg(s.device);
+        if (s.st_h2d) (void)hipStreamSynchronize(s.st_h2d);
         if (s.st) (void)hipStreamSynchronize(s.st);
+        if (s.st_d2h) (void)hipStreamSynchronize(s.st_d2h);
+        if (s.ev_in) (void)hipEventDestroy(s.ev_in);
+        if (s.ev_k) (void)hipEventDestroy(s.ev_k);
+        if (s.ev_out) (void)hipEventDestroy(s.ev_out);
         if (s.batch) shafa_hipd_batch_destroy((shafa_hipd_batch *)s.batch);
         if (s.h_in) hipHostFree(s.h_in);
         if (s.h_out) hipHostFree(s.h_out);
@@ -202,6 +250,11 @@ void shafa_pipe_destroy(shafa_pipe *p)
         if (s.d_small) hipFree(s.d_small);
         if (s.h_small) hipHostFree(s.h_small);
         if (s.st) hipStreamDestroy(s.st);
+        if (s.st_d2h) hipStreamDestroy(s.st_d2h);
+    }
+    for (int x = 0; x < p->n_xf; ++x) {
+        DeviceGuard dg(p->xf[x].device);
+        if (p->xf[x].h2d) hipStreamDestroy(p->xf[x].h2d);
     }
     free(p->slots);
     free(p);
@@ -231,6 +284,7 @@ int shafa_pipe_submit(shafa_pipe *p, int slot, int op, size_t in_n, const shafa_
     s.want_in_hist = (flags & SHAFA_PIPE_INPUT_HIST) != 0;
     s.busy = true;
     s.copied = 0;
+    s.out_queued = false;
     s.rc = slot_submit(s, table, (op >= 0 && op < 8) ? p->last_out[op] : 0);            // errors are reported by shafa_pipe_wait, in block order
     return SHAFA_SUCCESS;
 }
@@ -244,6 +298,10 @@ int shafa_pipe_wait(shafa_pipe *p, int slot, shafa_pipe_result *res)
     memset(res, 0, sizeof(*res));
     DeviceGuard dg(s.device);
     int rc = shafa_hipd_finish((shafa_hipd_batch *)s.batch, s.st, 1, nullptr);   // synchronises the slot's stream
+    if (s.out_queued) {                              // and the payload copy behind it on the device's D2H stream
+        const hipError_t e = hipEventSynchronize(s.ev_out);
+        if (e != hipSuccess && !s.rc && !rc) rc = shafa_set_hip_error(e, "shafa_pipe_wait");
+    }
     if (s.rc) return s.rc;
     if (rc) return rc;
     res->out = s.h_out;

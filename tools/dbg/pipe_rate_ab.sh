@@ -8,7 +8,7 @@ cp shafa-cd_amd/libshafa_hip.so /tmp/orig.so
 for i in 1 2 3; do
   for L in "$@"; do
     cp "$L" shafa-cd_amd/libshafa_hip.so
-    echo "$(basename $L) $(timeout 120 shafa-cd_amd/bin/pipe_rate 32 64 3 2>&1 | tail -2 | tr '\n' ' ')"
+    echo "$(basename $L) $(timeout 120 shafa-cd_amd/bin/pipe_rate 32 64 ${SLOTS:-3} 2>&1 | grep -o "sf_[a-z]*\|[0-9.]* GiB/s\|round trip [a-z]*" | tr '\n' ' ')"
   done
 done
 cp /tmp/orig.so shafa-cd_amd/libshafa_hip.so
