@@ -108,3 +108,104 @@ def test_rle_encode_many_blocks_per_launch(oracle, shafa):
                 bad.append(f"launch {it} block {b}: histogram of the RLE bytes differs")
     bt.close()
     assert not bad, "\n".join(bad[:10])
+
+
+def test_hundreds_of_small_blocks_per_launch(oracle, shafa):
+    """600 blocks of 40-70 KB in one launch of each batch entry point (the reference's default block size is 64 KiB,
+    file.h): per-launch records of more than 16 KB travel through the upload kernel (api.hip batch_upload,
+    batch_params_commit), not the runtime's copy.  hist256_tiles, rle_encode, sf_encode (with and without tile histograms),
+    sf_decode, rle_decode — every block against the oracle."""
+    import ctypes as C
+    import torch
+    import golden.make_golden as mg
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    nb = 600
+    zt = shafa.zipf_table(1.2)
+    rng = np.random.default_rng(5)
+    sizes = [int(x) for x in rng.integers(40000, 70000, nb)]
+    base = [mg.runs_stream(300 + i, 70000, zt) for i in range(6)]
+    blocks = [base[b % 6][:sizes[b]] for b in range(nb)]
+    off, pos = [], 0
+    for n in sizes:
+        off.append(pos)
+        pos += (n + 15) // 16 * 16
+    host = np.zeros(pos + 16, dtype=np.uint8)
+    for o, b in zip(off, blocks):
+        host[o:o + b.size] = b
+    d_in = torch.from_numpy(host).to(dev)
+    bt = shafa.Batch(nb, 160000)
+    bad = []
+    # Module F: RLE bytes, their histogram and their tile histograms
+    rcap = 2 * 70000 + 64
+    roff = [b * rcap for b in range(nb)]
+    thb = shafa.tile_hist_bytes(rcap) + 16
+    thoff = [b * thb for b in range(nb)]
+    d_rle = torch.empty(nb * rcap, dtype=torch.uint8, device=dev)
+    d_rn = torch.zeros(nb, dtype=torch.int64, device=dev)
+    d_freq = torch.zeros(nb * 256, dtype=torch.int64, device=dev)
+    d_th = torch.zeros(nb * thb, dtype=torch.uint8, device=dev)
+    bt.rle_encode_tiles(st, d_in, off, sizes, d_rle, roff, [rcap] * nb, d_rn, d_freq, d_th, thoff)
+    bt.finish(st, nb)
+    rn = [int(x) for x in d_rn.cpu().numpy()]
+    fr = d_freq.cpu().numpy().astype(np.uint64).reshape(nb, 256)
+    rle = d_rle.cpu().numpy()
+    want_rle = {}
+    for b in range(nb):
+        key = (b % 6, sizes[b])
+        if key not in want_rle:
+            want_rle[key] = oracle.rle_encode(blocks[b])
+        w = want_rle[key]
+        got = rle[roff[b]:roff[b] + rn[b]]
+        if got.size != w.size or got.tobytes() != w.tobytes():
+            bad.append(f"rle_encode block {b}: {first_diff(got, w)}")
+        elif not (fr[b] == oracle.hist256(w)).all():
+            bad.append(f"rle_encode block {b}: histogram differs")
+    assert not bad, "\n".join(bad[:10])
+    # Module T on the host, Module C with the tile histograms and without: the same bytes as the oracle's
+    tabs, want_enc = [], []
+    for b in range(nb):
+        ot = oracle.sf_build(fr[b])
+        t = shafa.CodeTable()
+        C.memmove(C.byref(t), C.byref(ot), C.sizeof(t))
+        tabs.append(t)
+        rc, e = oracle.sf_encode(rle[roff[b]:roff[b] + rn[b]], ot)
+        assert rc == 0
+        want_enc.append(e)
+    ecap = 80000
+    eoff = [b * ecap for b in range(nb)]
+    d_n = torch.zeros(nb, dtype=torch.int64, device=dev)
+    for with_tiles in (True, False):
+        d_enc = torch.zeros(nb * ecap, dtype=torch.uint8, device=dev)
+        if with_tiles:
+            bt.sf_encode_tiles(st, d_rle, roff, rn, tabs, d_th, thoff, d_enc, eoff, [ecap] * nb, d_n)
+        else:
+            bt.sf_encode(st, d_rle, roff, rn, tabs, d_enc, eoff, [ecap] * nb, d_n)
+        bt.finish(st, nb)
+        en = d_n.cpu().numpy()
+        enc = d_enc.cpu().numpy()
+        for b in range(nb):
+            got = enc[eoff[b]:eoff[b] + int(en[b])]
+            if got.size != want_enc[b].size or got.tobytes() != want_enc[b].tobytes():
+                bad.append(f"sf_encode (tile histograms: {with_tiles}) block {b}: {first_diff(got, want_enc[b])}")
+        assert not bad, "\n".join(bad[:10])
+    # Module D: SF decode, then RLE decode, back to the input
+    d_sym = torch.zeros(nb * rcap, dtype=torch.uint8, device=dev)
+    bt.sf_decode(st, d_enc, eoff, [w.size for w in want_enc], tabs, rn, d_sym, roff)
+    bt.finish(st, nb)
+    assert torch.equal(d_sym, d_rle) or all(
+        torch.equal(d_sym[roff[b]:roff[b] + rn[b]], d_rle[roff[b]:roff[b] + rn[b]]) for b in range(nb)), "sf_decode differs"
+    dcap = 70000 + 1040
+    doff = [b * 71168 for b in range(nb)]
+    d_dec = torch.zeros(nb * 71168, dtype=torch.uint8, device=dev)
+    d_dn = torch.zeros(nb, dtype=torch.int64, device=dev)
+    bt.rle_decode(st, d_sym, roff, rn, d_dec, doff, [dcap] * nb, d_dn)
+    bt.finish(st, nb)
+    dn = d_dn.cpu().numpy()
+    dec = d_dec.cpu().numpy()
+    for b in range(nb):
+        got = dec[doff[b]:doff[b] + int(dn[b])]
+        if got.size != sizes[b] or got.tobytes() != blocks[b].tobytes():
+            bad.append(f"rle_decode block {b}: {first_diff(got, blocks[b])}")
+    bt.close()
+    assert not bad, "\n".join(bad[:10])
