@@ -2083,6 +2083,30 @@ void build_host_tab(const shafa_code_table &t, HostTab &h)
 }
 }  // namespace
 
+// fn(b) for every block of a launch, on the caller and up to seven helper threads (a helper is worth starting for sixteen
+// blocks or more; blocks are handed out by a counter, so the call does not depend on how many helpers could be started)
+template <class F> static void for_blocks_parallel(int nblocks, F fn)
+{
+    std::atomic<int> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int b = next.fetch_add(1, std::memory_order_relaxed);
+            if (b >= nblocks) break;
+            fn(b);
+        }
+    };
+    int helpers = nblocks / 16;
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (helpers > 7) helpers = 7;
+    if (hw > 0 && helpers > hw - 1) helpers = hw - 1;
+    std::vector<std::thread> th;
+    for (int i = 0; i < helpers; ++i) {
+        try { th.emplace_back(work); } catch (...) { break; }
+    }
+    work();
+    for (auto &t : th) t.join();
+}
+
 static int g_sfd_speculate = 1;                    // 0 never, 1 where spec_worthwhile() says so, 2 wherever the kernels apply
 void sfdec_configure(int speculate) { g_sfd_speculate = speculate; }
 // test knob ("sf_decode_path"): 0 = the fastest kernels the launch's tables allow; 1 = treat every table as if it were not
@@ -2170,25 +2194,10 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         // trie, four look-up tables) is 2 ms for 128 blocks — hidden behind the kernels of 64 MiB blocks, but twice the
         // kernels' time for 8 MiB blocks of compressible data.  Blocks are handed out by a counter, so the launch does
         // not depend on how many helpers could be started.
-        std::atomic<int> next{0};
         std::atomic<bool> nomem{false};
-        auto work = [&]() {                                // no exception leaves a thread (the entry points never throw)
-            for (;;) {
-                const int b = next.fetch_add(1, std::memory_order_relaxed);
-                if (b >= nblocks) break;
-                try { build_host_tab(h_tables[b], tabs[b]); } catch (...) { nomem.store(true); }
-            }
-        };
-        int helpers = nblocks / 16;                        // a helper is worth starting for sixteen tables or more
-        const int hw = (int)std::thread::hardware_concurrency();
-        if (helpers > 7) helpers = 7;
-        if (hw > 0 && helpers > hw - 1) helpers = hw - 1;
-        std::vector<std::thread> th;
-        for (int i = 0; i < helpers; ++i) {
-            try { th.emplace_back(work); } catch (...) { break; }
-        }
-        work();
-        for (auto &t : th) t.join();
+        for_blocks_parallel(nblocks, [&](int b) {
+            try { build_host_tab(h_tables[b], tabs[b]); } catch (...) { nomem.store(true); }   // no exception leaves a thread
+        });
         if (nomem.load()) return SHAFA_LACK_OF_MEMORY;
     }
     for (int b = 0; b < nblocks; ++b) {
@@ -2296,6 +2305,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     DecBlk *hb = (DecBlk *)hs;
     size_t tpos = o_tab;
     u32 tbase = 0;
+    std::vector<size_t> tab_pos(nblocks, 0);
     for (int b = 0; b < nblocks; ++b) {
         DecBlk &e = hb[b];
         memset(&e, 0, sizeof(e));
@@ -2321,39 +2331,51 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         e.KW = hblk_kw[b];
         e.lmax = h.lmax;
         e.n_states = (u32)(h.trie.size() / 2);
+        tab_pos[b] = tpos;                                  // where this block's tables start in the staging arena
         e.lut2 = (const u16 *)(dpar + tpos);
         e.n_l2 = (u32)h.lut2.size();
-        if (h.lut2.size()) memcpy(hs + tpos, h.lut2.data(), h.lut2.size() * 2);
         tpos += (h.lut2.size() * 2 + 16 + 15) & ~(size_t)15;
         e.lut13 = (const u16 *)(dpar + tpos);
-        memcpy(hs + tpos, h.lut13.data(), h.lut13.size() * 2);
         tpos += (h.lut13.size() * 2 + 15) & ~(size_t)15;
         if (!h.longtab.empty()) {
             e.longtab = (const u16 *)(dpar + tpos);
-            memcpy(hs + tpos, h.longtab.data(), LONG_BYTES);
             tpos += LONG_BYTES;
         }
         if (!h.long32.empty()) {
             e.long32 = (const u16 *)(dpar + tpos);
-            memcpy(hs + tpos, h.long32.data(), LONG32_BYTES);
             tpos += (LONG32_BYTES + 15) & ~15;
         }
         if (!h.lenlut32.empty()) {
             e.lenlut32 = dpar + tpos;
-            memcpy(hs + tpos, h.lenlut32.data(), h.lenlut32.size());
             tpos += (h.lenlut32.size() + 15) & ~(size_t)15;
         }
         e.lenlut = dpar + tpos;
         if (!e.lenlut32) e.lenlut32 = e.lenlut;            // no code longer than 13 bits: the plain table
-        memcpy(hs + tpos, h.lenlut.data(), h.lenlut.size());
         tpos += (h.lenlut.size() + 15) & ~(size_t)15;
         e.lut = (const u16 *)(dpar + tpos);
-        memcpy(hs + tpos, h.lut.data(), h.lut.size() * 2);
         tpos += (h.lut.size() * 2 + 15) & ~(size_t)15;
         e.trie = (const u32 *)(dpar + tpos);
-        memcpy(hs + tpos, h.trie.data(), h.trie.size() * 4);
         tpos += (h.trie.size() * 4 + 15) & ~(size_t)15;
     }
+    // the tables themselves (8-40 KB a block) are copied into the arena by the same helpers that built them: on the caller
+    // alone the copies of a launch of 512 small blocks took longer than its kernels
+    for_blocks_parallel(nblocks, [&](int b) {
+        if (!ntiles[b]) return;
+        const HostTab &h = tabs[b];
+        size_t q = tab_pos[b];
+        if (h.lut2.size()) memcpy(hs + q, h.lut2.data(), h.lut2.size() * 2);
+        q += (h.lut2.size() * 2 + 16 + 15) & ~(size_t)15;
+        memcpy(hs + q, h.lut13.data(), h.lut13.size() * 2);
+        q += (h.lut13.size() * 2 + 15) & ~(size_t)15;
+        if (!h.longtab.empty()) { memcpy(hs + q, h.longtab.data(), LONG_BYTES); q += LONG_BYTES; }
+        if (!h.long32.empty()) { memcpy(hs + q, h.long32.data(), LONG32_BYTES); q += (LONG32_BYTES + 15) & ~15; }
+        if (!h.lenlut32.empty()) { memcpy(hs + q, h.lenlut32.data(), h.lenlut32.size()); q += (h.lenlut32.size() + 15) & ~(size_t)15; }
+        memcpy(hs + q, h.lenlut.data(), h.lenlut.size());
+        q += (h.lenlut.size() + 15) & ~(size_t)15;
+        memcpy(hs + q, h.lut.data(), h.lut.size() * 2);
+        q += (h.lut.size() * 2 + 15) & ~(size_t)15;
+        memcpy(hs + q, h.trie.data(), h.trie.size() * 4);
+    });
     if ((rc = batch_params_commit(bt, st, hs, stage_bytes))) return rc;
 
     const DecBlk *dblk = (const DecBlk *)(dpar + o_blk);

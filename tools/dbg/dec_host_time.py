@@ -1,4 +1,5 @@
-"""Host time of one shafa_hipd_sf_decode call vs its GPU time (uniform 128 x 8 MiB): finds host work on the critical path."""
+"""Host time of one shafa_hipd_sf_decode call vs its GPU time (default uniform 128 x 8 MiB): finds host work on the critical
+path.  usage: dec_host_time.py [uniform|zipf|runs] [blocks] [block MiB]"""
 import sys, time, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
 import numpy as np, torch
@@ -7,10 +8,14 @@ pkg = pkgload.load()
 import oracle_lib
 dev = torch.device("cuda", 0)
 st = torch.cuda.Stream(device=dev)
-nb, bs = 128, 8 << 20
+nb = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+bs = (int(sys.argv[3]) if len(sys.argv) > 3 else 8) << 20
 dist = sys.argv[1] if len(sys.argv) > 1 else "uniform"
 d_in = torch.empty(nb * bs, dtype=torch.uint8, device=dev)
-if dist == "uniform":
+if dist == "runs":
+    synth = pkgload.load_submodule("synth")
+    d_in.copy_(torch.from_numpy(synth.runs_stream(11, bs, synth.zipf_table(1.2))).to(dev).repeat(nb))
+elif dist == "uniform":
     d_in.copy_(torch.randint(0, 256, (nb * bs,), dtype=torch.uint8, device=dev))
 else:
     zt = torch.from_numpy(pkg.zipf_table(1.2)).to(dev)
