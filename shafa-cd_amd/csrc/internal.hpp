@@ -17,10 +17,7 @@ struct StageSeg {
 
 // Reusable per-batch context behind the opaque shafa_hipd_batch handle.
 // parameter uploads of at most this many bytes go into the launch's stream (api.hip, batch_params_commit)
-#ifndef PARAMS_INLINE_KB
-#define PARAMS_INLINE_KB 64
-#endif
-constexpr size_t PARAMS_INLINE_BYTES = (size_t)PARAMS_INLINE_KB * 1024;
+constexpr size_t PARAMS_INLINE_BYTES = 64 * 1024;
 
 struct Batch {
     int device;            // the device the batch was created on: its workspace, error words and kernels live there
