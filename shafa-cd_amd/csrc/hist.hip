@@ -7,7 +7,11 @@
 // in ~25 % of the lanes).  The replicas are summed (rotated reads, conflict-free) and added to the
 // block's global bins with at most 256 atomics per workgroup.
 //
-// Algorithmic HBM bytes per block: n read (+ 2 KiB written).
+// hist256_tiles_kernel (round 4): the same pass also leaves the 256 x u16 histogram of every 32 KiB tile (the sidecar that
+// lets sf_encode6.hip run as a one-shot grid): running totals per replica, a tile's counts = the totals after it minus
+// the totals before it, summed over the replicas with eight rotated ds_read_b128 per lane while the next tile's loads fly.
+//
+// Algorithmic HBM bytes per block: n read (+ 2 KiB written; with tile histograms + n / 64 written).
 #include "common.hpp"
 #include "internal.hpp"
 

@@ -4,15 +4,24 @@
 //     S0 (token start): b == 0 -> S1, else literal -> S0      S1 (symbol) -> S2      S2 (count) -> S0
 // which only looks at "is the byte zero".  A lane takes 32 bytes: their zero mask indexes a 256-entry table (8 bytes
 // at a time: exit state and token-start mask for each of the three entry states), the lane's map {S0,S1,S2}->{S0,S1,S2}
-// (6 bits) is composed with an ordered scan lanes -> waves -> tiles (look-back over tile maps; a map that sends every
-// state to the same state ends the walk, which almost every tile's does).  With its entry state a lane has its
+// (6 bits) is composed with an ordered scan lanes -> waves.  The TILE's entry state needs nobody: two non-zero bytes in a
+// row end in S0 whatever the state before them, so the map of the 32 bytes in front of the tile is almost always constant
+// and then is the entry state; only a tile behind 32 zero-heavy bytes looks back over the tile maps (a map that sends
+// every state to the same state ends the walk, which almost every tile's does).  With its entry state a lane has its
 // token-start mask, hence its literal mask L and escape mask E as bits, and SWAR gives the per-byte output lengths
 // (1 at a literal, the count byte two places on at an escape — 1 when that is 0, d.c:179-184 — else 0): their sum is
 // scanned for output offsets (second look-back, 64-bit).  The tile's output is built in an LDS image
 // — literals as byte writes at running positions (one add per byte), runs as word writes with byte writes at both
 // ends — while wave 0 is still looking back for the tile's output offset, and leaves as aligned 16-byte stores (five
 // dwords of the image funnel-shifted by the offset's misalignment).  A tile whose output exceeds the image goes in
-// rounds of consecutive lanes.
+// rounds of consecutive lanes.  A tile without a zero byte that is entered at a token start is stored straight from its
+// input.
+//
+// What bounds it (profiles/r4_rld_*): a tile's 10-13 us are memory round trips in a row — ticket, load,
+// offset look-back, stores — at seven workgroups per CU (72 VGPRs, 12 KiB image).  The tile descriptors sit 32 bytes apart:
+// agent-scope atomics are served by the memory side, and sixteen descriptors in one cache line made every in-flight tile
+// of a block queue on the same three lines.  Neither fewer barriers, nor persistent workgroups with prefetch, nor a
+// speculative load ahead of the ticket paid (tools/experiments/).
 //
 // Algorithmic HBM bytes per block: rle_n read + orig_n written.
 #include "common.hpp"
