@@ -111,6 +111,13 @@ def test_rle_decode_hand_made_streams(oracle, shafa):
         "triples_only": bytes([0, 0, 255] * 5000),               # non-zero bytes never adjacent: chained maps
         "zero_count_zero_sym": bytes([0, 0, 0] * 3000 + [7]),
         "mixed": bytes(([0, 9, 200] + [1, 2, 3] + [0, 0, 1]) * 3000),
+        # many tiles whose 32 bytes in front never settle the state (every tile looks back over tile maps: the path that the
+        # local entry state, rle_decode.hip, leaves to zero-heavy data), in all three alignments against the 8 KiB tiles
+        "triples_many_tiles": bytes([0, 0, 3] * 200000),
+        "all_zero_many_tiles": bytes(300001 // 3 * 3),
+        "zeros_shifted_1": bytes([5]) + bytes([0, 0, 2] * 100000) + bytes([7, 8, 9] * 5000),
+        "zeros_shifted_2": bytes([5, 6]) + bytes([0, 0, 2] * 100000) + bytes([0, 7, 200] * 300),
+        "text_zeros_text": bytes([65 + (i * 7) % 26 for i in range(50000)]) + bytes([0, 0, 1] * 30000) + bytes([97 + (i * 5) % 26 for i in range(50000)]),
     }
     for name, raw in cases.items():
         rc, want = oracle.rle_decode(raw)
