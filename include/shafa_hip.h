@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SHAFA_HIP_ABI_VERSION 5
+#define SHAFA_HIP_ABI_VERSION 6
 
 /* utils/errors.h:5-16 (_modules_error), same numbers */
 enum shafa_error {
@@ -265,6 +265,27 @@ int shafa_pipe_submit(shafa_pipe *p, int slot, int op, size_t in_n, const shafa_
 /* Wait for the slot's block, fetch its result into the pinned output buffer, mark the slot idle.
  * Returns the block's _modules_error number. */
 int shafa_pipe_wait(shafa_pipe *p, int slot, shafa_pipe_result *res);
+
+/* ---- Groups: several consecutive blocks of a file in one slot -------------------------------------------------------------
+ * One launch per block costs the submitting thread ~0.1 ms whatever the block's size, which is all of a file's time at the
+ * reference's default block size (64 KiB, file.h).  A group puts up to SHAFA_PIPE_GROUP_MAX blocks into one slot: the caller
+ * lays their inputs out in shafa_pipe_in(slot, total) at offsets that are multiples of 16, every kernel is launched once for
+ * all of them, and the results come back together.  Same ops, same per-block results and error codes as the single-block
+ * calls; a slot holds either a single block or a group. */
+#define SHAFA_PIPE_GROUP_MAX 256
+
+typedef struct shafa_pipe_block {
+    size_t in_off, in_n;                 /* the block inside the slot's input buffer                               */
+    const shafa_code_table *table;       /* SF ops                                                                 */
+    size_t n_symbols;                    /* SF decodes                                                             */
+    size_t out_cap;                      /* SF_ENCODE result capacity                                              */
+} shafa_pipe_block;
+
+int shafa_pipe_submit_group(shafa_pipe *p, int slot, int op, int nblocks, const shafa_pipe_block *blocks, int flags);
+
+/* res[i] / block_rc[i]: block i's result and its _modules_error number (results of blocks behind a failed block are still
+ * valid: the caller decides where to stop, in block order).  The return value is an error of the call itself. */
+int shafa_pipe_wait_group(shafa_pipe *p, int slot, int nblocks, shafa_pipe_result *res, int *block_rc);
 
 #ifdef __cplusplus
 }

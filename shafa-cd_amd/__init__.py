@@ -56,6 +56,13 @@ class PipeResult(C.Structure):
                 ("freq", C.c_uint64 * 256), ("freq_in", C.c_uint64 * 256)]
 
 
+class PipeBlock(C.Structure):
+    """shafa_pipe_block (include/shafa_hip.h, layer 3 groups)."""
+    _fields_ = [("in_off", C.c_size_t), ("in_n", C.c_size_t), ("table", C.POINTER(CodeTable)), ("n_symbols", C.c_size_t),
+                ("out_cap", C.c_size_t)]
+
+
+PIPE_GROUP_MAX = 256
 OP_HIST, OP_RLE_ENCODE, OP_SF_ENCODE, OP_SF_DECODE, OP_RLE_DECODE, OP_SF_RLE_DECODE = 1, 2, 3, 4, 5, 6
 PIPE_INPUT_HIST = 1
 
@@ -119,7 +126,10 @@ def lib():
     L.shafa_pipe_in.restype = C.c_void_p
     L.shafa_pipe_submit.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, tp, C.c_size_t, C.c_size_t, C.c_int]
     L.shafa_pipe_wait.argtypes = [vp, C.c_int, C.POINTER(PipeResult)]
-    for name in ("shafa_pipe_create", "shafa_pipe_slots", "shafa_pipe_submit", "shafa_pipe_wait"):
+    L.shafa_pipe_submit_group.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(PipeBlock), C.c_int]
+    L.shafa_pipe_wait_group.argtypes = [vp, C.c_int, C.c_int, C.POINTER(PipeResult), C.POINTER(C.c_int)]
+    for name in ("shafa_pipe_create", "shafa_pipe_slots", "shafa_pipe_submit", "shafa_pipe_wait", "shafa_pipe_submit_group",
+                 "shafa_pipe_wait_group"):
         getattr(L, name).restype = C.c_int
     for name in ("shafa_hip_init", "shafa_hip_hist256", "shafa_hip_rle_encode", "shafa_hip_sf_encode",
                  "shafa_hip_sf_decode", "shafa_hip_rle_decode", "shafa_hipd_batch_create",
@@ -352,6 +362,37 @@ class Pipe:
             _check(rc, "pipe_wait")
         out = C.string_at(r.out, r.out_n) if rc == 0 and r.out_n else b""
         return rc, out, r
+
+
+    def submit_group(self, slot, op, datas, tables=None, n_symbols=None, out_caps=None, flags=0):
+        """several blocks in one slot: inputs laid out at 16-byte aligned offsets (shafa_pipe_submit_group)"""
+        arrs = [_np_u8(d) for d in datas]
+        offs, pos = [], 0
+        for a in arrs:
+            offs.append(pos)
+            pos += (a.size + 15) // 16 * 16
+        p = lib().shafa_pipe_in(self._h, slot, max(pos, 16))
+        if not p:
+            raise ShafaError(LACK_OF_MEMORY, "pipe_in (slot busy?)")
+        blocks = (PipeBlock * len(arrs))()
+        self._keep = tables                                   # the tables must outlive the call
+        for i, a in enumerate(arrs):
+            if a.size:
+                C.memmove(p + offs[i], a.ctypes.data, a.size)
+            blocks[i].in_off, blocks[i].in_n = offs[i], a.size
+            blocks[i].table = C.pointer(tables[i]) if tables is not None else None
+            blocks[i].n_symbols = n_symbols[i] if n_symbols is not None else 0
+            blocks[i].out_cap = out_caps[i] if out_caps is not None else 0
+        _check(lib().shafa_pipe_submit_group(self._h, slot, op, len(arrs), blocks, flags), "pipe_submit_group")
+        return len(arrs)
+
+    def wait_group(self, slot, n):
+        """-> (rc of the call, [block rc], [result bytes], [PipeResult])"""
+        res = (PipeResult * n)()
+        brc = (C.c_int * n)()
+        rc = lib().shafa_pipe_wait_group(self._h, slot, n, res, brc)
+        outs = [C.string_at(res[i].out, res[i].out_n) if rc == 0 and brc[i] == 0 and res[i].out_n else b"" for i in range(n)]
+        return rc, list(brc), outs, res
 
 
 TILE_BYTES = 32768            # SHAFA_TILE_BYTES: the tile of the tile histograms

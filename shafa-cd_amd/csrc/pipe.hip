@@ -23,6 +23,8 @@ int shafa_set_hip_error(hipError_t e, const char *what);
 int api_lazy_init();      // api.hip: shafa_hip_init(0) unless a device was selected already
 int api_pipe_device(int slot, int n_slots);   // api.hip: device of slot `slot` of a pipe of n_slots (shafa_hip_init_devices), else the layer-1 device
 
+#define PIPE_GROUP_MAX SHAFA_PIPE_GROUP_MAX
+
 namespace {
 
 struct Slot {
@@ -43,6 +45,12 @@ struct Slot {
     hipStream_t st_h2d, st_d2h;   // the device's H2D stream (shared by its slots, owned by the pipe); the slot's D2H stream
     hipEvent_t ev_in, ev_k, ev_out;   // block on the device / kernels done / payload on the host
     bool out_queued;           // a payload copy was queued on st_d2h (ev_out recorded)
+    // a group of blocks in the slot (shafa_pipe_submit_group): block i's result at d_out / h_out + i * g_stride
+    int g_n;                   // 0: the slot holds a single block
+    size_t g_stride, g_mid_stride;
+    u64 *g_in_off, *g_in_n, *g_out_off, *g_cap, *g_nsym, *g_mid_off;   // PIPE_GROUP_MAX entries each (allocated with the first group)
+    shafa_code_table *g_tab;
+    u64 *d_gsmall, *h_gsmall;  // per block of a group: [i * 256] hist of the result / input, [(G + i) * 256] hist of the input, [2 G * 256 + i] size
 };
 
 }  // namespace
@@ -184,6 +192,135 @@ int slot_submit(Slot &s, const shafa_code_table *table, const size_t pred)
     return SHAFA_SUCCESS;
 }
 
+// ---- groups: several consecutive blocks of a file in one slot, one launch per kernel for all of them --------------------
+// (one launch per block costs the submitting thread ~120 us whatever the block's size: at the reference's default 64 KiB
+// blocks that is all a file's time.  Results lie at a uniform stride so that they come back as one 2-D copy.)
+constexpr size_t G_SIZE_AT = (size_t)2 * PIPE_GROUP_MAX * 256;      // u64 index of block 0's size in d_gsmall
+
+int group_alloc(Slot &s)
+{
+    if (s.g_in_off) return SHAFA_SUCCESS;
+    u64 *a = (u64 *)calloc((size_t)6 * PIPE_GROUP_MAX, sizeof(u64));
+    shafa_code_table *t = (shafa_code_table *)calloc(PIPE_GROUP_MAX, sizeof(shafa_code_table));
+    if (!a || !t) { free(a); free(t); return SHAFA_LACK_OF_MEMORY; }
+    const size_t nsmall = G_SIZE_AT + 2 * PIPE_GROUP_MAX;
+    HIP_TRY(hipMalloc((void **)&s.d_gsmall, nsmall * sizeof(u64)));
+    HIP_TRY(hipHostMalloc((void **)&s.h_gsmall, nsmall * sizeof(u64), hipHostMallocPortable));
+    s.g_in_off = a; s.g_in_n = a + PIPE_GROUP_MAX; s.g_out_off = a + 2 * PIPE_GROUP_MAX; s.g_cap = a + 3 * PIPE_GROUP_MAX;
+    s.g_nsym = a + 4 * PIPE_GROUP_MAX; s.g_mid_off = a + 5 * PIPE_GROUP_MAX;
+    s.g_tab = t;
+    return SHAFA_SUCCESS;
+}
+
+// results at a uniform stride: rows of `width` bytes, one per block
+int group_fetch(Slot &s, size_t width, hipStream_t st)
+{
+    if (!width || !s.g_n) return SHAFA_SUCCESS;
+    if (width > s.g_stride) width = s.g_stride;
+    if (s.g_n == 1) HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, width, hipMemcpyDeviceToHost, st));
+    else HIP_TRY(hipMemcpy2DAsync(s.h_out, s.g_stride, s.d_out, s.g_stride, width, (size_t)s.g_n, hipMemcpyDeviceToHost, st));
+    return SHAFA_SUCCESS;
+}
+
+int slot_submit_group(Slot &s, int n, const shafa_pipe_block *blk)
+{
+    int rc;
+    DeviceGuard dg(s.device);
+    if ((rc = group_alloc(s))) return rc;
+    if ((rc = batch_enter(s.batch, s.st))) return rc;
+    size_t total_in = 0, max_cap = 0, max_sym = 0;
+    for (int i = 0; i < n; ++i) {
+        if (blk[i].in_off & 15) return SHAFA_OUTSIDE_MODULE;
+        s.g_in_off[i] = blk[i].in_off;
+        s.g_in_n[i] = blk[i].in_n;
+        s.g_nsym[i] = blk[i].n_symbols;
+        if (blk[i].in_off + blk[i].in_n > total_in) total_in = blk[i].in_off + blk[i].in_n;
+        size_t cap = 0;
+        switch (s.op) {
+        case SHAFA_OP_RLE_ENCODE: cap = 2 * blk[i].in_n + 3; break;                                   // f.c:244 worst case
+        case SHAFA_OP_SF_ENCODE: cap = blk[i].out_cap; break;
+        case SHAFA_OP_SF_DECODE: cap = blk[i].n_symbols; break;
+        case SHAFA_OP_RLE_DECODE:                                                                      // a triple of 3 bytes expands to 255 at most
+        case SHAFA_OP_SF_RLE_DECODE: {
+            const size_t rle_n = s.op == SHAFA_OP_RLE_DECODE ? blk[i].in_n : blk[i].n_symbols;
+            cap = rle_n <= (size_t)SHAFA_RLE_DECODE_MAX / 85 ? 85 * rle_n + 256 : (size_t)SHAFA_RLE_DECODE_MAX;
+            if (cap > (size_t)SHAFA_RLE_DECODE_MAX) cap = SHAFA_RLE_DECODE_MAX;                     // d.c:129-169
+            break;
+        }
+        default: break;
+        }
+        s.g_cap[i] = cap;
+        if (cap > max_cap) max_cap = cap;
+        if (blk[i].n_symbols > max_sym) max_sym = blk[i].n_symbols;
+        if ((s.op == SHAFA_OP_SF_ENCODE || s.op == SHAFA_OP_SF_DECODE || s.op == SHAFA_OP_SF_RLE_DECODE)) {
+            if (!blk[i].table) return SHAFA_OUTSIDE_MODULE;
+            s.g_tab[i] = *blk[i].table;
+        }
+    }
+    if (total_in > s.h_in_cap) return SHAFA_OUTSIDE_MODULE;
+    s.g_stride = (max_cap + 16 + 15) & ~(size_t)15;
+    s.g_mid_stride = (max_sym + 16 + 15) & ~(size_t)15;
+    for (int i = 0; i < n; ++i) { s.g_out_off[i] = (u64)i * s.g_stride; s.g_mid_off[i] = (u64)i * s.g_mid_stride; }
+    if ((rc = grow_dev(&s.d_in, &s.d_in_cap, total_in))) return rc;
+    if (total_in) {
+        HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, total_in, hipMemcpyHostToDevice, s.st_h2d));
+        HIP_TRY(hipEventRecord(s.ev_in, s.st_h2d));
+        HIP_TRY(hipStreamWaitEvent(s.st, s.ev_in, 0));
+    }
+    const size_t total_out = (size_t)n * s.g_stride;
+    u64 *d_size = s.d_gsmall + G_SIZE_AT;
+    if (s.op != SHAFA_OP_HIST) {
+        if ((rc = grow_dev(&s.d_out, &s.d_out_cap, total_out))) return rc;
+        if ((rc = grow_pinned(&s.h_out, &s.h_out_cap, total_out))) return rc;
+    }
+    switch (s.op) {
+    case SHAFA_OP_HIST:
+        if ((rc = hist_launch(s.batch, s.st, n, s.d_in, s.g_in_off, s.g_in_n, s.d_gsmall))) return rc;
+        HIP_TRY(hipMemcpyAsync(s.h_gsmall, s.d_gsmall, (size_t)n * 256 * sizeof(u64), hipMemcpyDeviceToHost, s.st));
+        break;
+    case SHAFA_OP_RLE_ENCODE:
+        if (s.want_in_hist) {
+            if ((rc = hist_launch(s.batch, s.st, n, s.d_in, s.g_in_off, s.g_in_n, s.d_gsmall + (size_t)PIPE_GROUP_MAX * 256))) return rc;
+            HIP_TRY(hipMemcpyAsync(s.h_gsmall + (size_t)PIPE_GROUP_MAX * 256, s.d_gsmall + (size_t)PIPE_GROUP_MAX * 256,
+                                   (size_t)n * 256 * sizeof(u64), hipMemcpyDeviceToHost, s.st));
+        }
+        if ((rc = rleenc_launch(s.batch, s.st, n, s.d_in, s.g_in_off, s.g_in_n, s.d_out, s.g_out_off, s.g_cap, d_size, s.d_gsmall))) return rc;
+        HIP_TRY(hipMemcpyAsync(s.h_gsmall, s.d_gsmall, (size_t)n * 256 * sizeof(u64), hipMemcpyDeviceToHost, s.st));
+        HIP_TRY(hipMemcpyAsync(s.h_gsmall + G_SIZE_AT, d_size, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost, s.st));
+        break;
+    case SHAFA_OP_SF_ENCODE:
+        if ((rc = sfenc_launch(s.batch, s.st, n, s.d_in, s.g_in_off, s.g_in_n, s.g_tab, s.d_out, s.g_out_off, s.g_cap, d_size))) return rc;
+        HIP_TRY(hipMemcpyAsync(s.h_gsmall + G_SIZE_AT, d_size, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost, s.st));
+        break;
+    case SHAFA_OP_SF_DECODE:
+        if ((rc = sfdec_launch(s.batch, s.st, n, s.d_in, s.g_in_off, s.g_in_n, s.g_tab, s.g_nsym, s.d_out, s.g_out_off))) return rc;
+        HIP_TRY(hipEventRecord(s.ev_k, s.st));                                   // sizes known: the rows leave behind the kernels
+        HIP_TRY(hipStreamWaitEvent(s.st_d2h, s.ev_k, 0));
+        if ((rc = group_fetch(s, max_sym, s.st_d2h))) return rc;
+        HIP_TRY(hipEventRecord(s.ev_out, s.st_d2h));
+        s.out_queued = true;
+        break;
+    case SHAFA_OP_RLE_DECODE:
+    case SHAFA_OP_SF_RLE_DECODE: {
+        const u8 *rle_in = s.d_in;
+        const u64 *rle_off = s.g_in_off, *rle_n = s.g_in_n;
+        if (s.op == SHAFA_OP_SF_RLE_DECODE) {                                   // d.c:565-586, fused on the device
+            if ((rc = grow_dev(&s.d_mid, &s.d_mid_cap, (size_t)n * s.g_mid_stride))) return rc;
+            if ((rc = sfdec_launch(s.batch, s.st, n, s.d_in, s.g_in_off, s.g_in_n, s.g_tab, s.g_nsym, s.d_mid, s.g_mid_off))) return rc;
+            rle_in = s.d_mid;
+            rle_off = s.g_mid_off;
+            rle_n = s.g_nsym;
+        }
+        if ((rc = rledec_launch(s.batch, s.st, n, rle_in, rle_off, rle_n, s.d_out, s.g_out_off, s.g_cap, d_size))) return rc;
+        HIP_TRY(hipMemcpyAsync(s.h_gsmall + G_SIZE_AT, d_size, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost, s.st));
+        break;
+    }
+    default:
+        return SHAFA_OUTSIDE_MODULE;
+    }
+    return SHAFA_SUCCESS;
+}
+
 }  // namespace
 
 extern "C" {
@@ -221,7 +358,7 @@ int shafa_pipe_create(int n_slots, shafa_pipe **out)
         if (e == hipSuccess) e = hipMalloc((void **)&s.d_small, 514 * sizeof(u64));
         if (e == hipSuccess) e = hipHostMalloc((void **)&s.h_small, 514 * sizeof(u64), hipHostMallocPortable);
         if (e != hipSuccess) { shafa_pipe_destroy(p); return shafa_set_hip_error(e, "shafa_pipe_create"); }
-        if ((rc = shafa_hipd_batch_create(1, (size_t)1 << 27, &bh))) { shafa_pipe_destroy(p); return rc; }
+        if ((rc = shafa_hipd_batch_create(PIPE_GROUP_MAX, (size_t)1 << 27, &bh))) { shafa_pipe_destroy(p); return rc; }
         s.batch = (Batch *)bh;
         s.batch->par_dma = true;                        // see batch_params_commit
     }
@@ -249,6 +386,10 @@ void shafa_pipe_destroy(shafa_pipe *p)
         if (s.d_mid) hipFree(s.d_mid);
         if (s.d_small) hipFree(s.d_small);
         if (s.h_small) hipHostFree(s.h_small);
+        if (s.d_gsmall) hipFree(s.d_gsmall);
+        if (s.h_gsmall) hipHostFree(s.h_gsmall);
+        free(s.g_in_off);
+        free(s.g_tab);
         if (s.st) hipStreamDestroy(s.st);
         if (s.st_d2h) hipStreamDestroy(s.st_d2h);
     }
@@ -285,6 +426,7 @@ int shafa_pipe_submit(shafa_pipe *p, int slot, int op, size_t in_n, const shafa_
     s.busy = true;
     s.copied = 0;
     s.out_queued = false;
+    s.g_n = 0;
     s.rc = slot_submit(s, table, (op >= 0 && op < 8) ? p->last_out[op] : 0);            // errors are reported by shafa_pipe_wait, in block order
     return SHAFA_SUCCESS;
 }
@@ -334,6 +476,77 @@ int shafa_pipe_wait(shafa_pipe *p, int slot, shafa_pipe_result *res)
     }
     if (s.op >= 0 && s.op < 8) p->last_out[s.op] = sz;
     res->out_n = sz;
+    return SHAFA_SUCCESS;
+}
+
+int shafa_pipe_submit_group(shafa_pipe *p, int slot, int op, int nblocks, const shafa_pipe_block *blocks, int flags)
+{
+    if (!p || slot < 0 || slot >= p->n_slots || !blocks || nblocks <= 0 || nblocks > PIPE_GROUP_MAX) return SHAFA_OUTSIDE_MODULE;
+    Slot &s = p->slots[slot];
+    if (s.busy) return SHAFA_OUTSIDE_MODULE;
+    s.op = op;
+    s.want_in_hist = (flags & SHAFA_PIPE_INPUT_HIST) != 0;
+    s.busy = true;
+    s.copied = 0;
+    s.out_queued = false;
+    s.g_n = nblocks;
+    s.rc = slot_submit_group(s, nblocks, blocks);        // errors are reported by shafa_pipe_wait_group
+    return SHAFA_SUCCESS;
+}
+
+int shafa_pipe_wait_group(shafa_pipe *p, int slot, int nblocks, shafa_pipe_result *res, int *block_rc)
+{
+    if (!p || slot < 0 || slot >= p->n_slots || !res || !block_rc) return SHAFA_OUTSIDE_MODULE;
+    Slot &s = p->slots[slot];
+    if (!s.busy || s.g_n != nblocks) return SHAFA_OUTSIDE_MODULE;
+    s.busy = false;
+    memset(res, 0, (size_t)nblocks * sizeof(*res));
+    for (int i = 0; i < nblocks; ++i) block_rc[i] = SHAFA_SUCCESS;
+    DeviceGuard dg(s.device);
+    int rc = shafa_hipd_finish((shafa_hipd_batch *)s.batch, s.st, nblocks, block_rc);   // synchronises the slot's stream
+    if (s.out_queued) {
+        const hipError_t e = hipEventSynchronize(s.ev_out);
+        if (e != hipSuccess && !s.rc) s.rc = shafa_set_hip_error(e, "shafa_pipe_wait_group");
+    }
+    if (s.rc) return s.rc;                               // the submission itself failed: no block has a result
+    (void)rc;                                            // per-block codes are in block_rc
+    const u64 *h_size = s.h_gsmall + G_SIZE_AT;
+    size_t width = 0;
+    for (int i = 0; i < nblocks; ++i) {
+        shafa_pipe_result &r = res[i];
+        r.out = s.h_out + (size_t)i * s.g_stride;
+        switch (s.op) {
+        case SHAFA_OP_HIST:
+            memcpy(r.freq, s.h_gsmall + (size_t)i * 256, 256 * sizeof(u64));
+            break;
+        case SHAFA_OP_SF_DECODE:
+            r.out_n = (size_t)s.g_nsym[i];
+            break;
+        case SHAFA_OP_RLE_ENCODE:
+            memcpy(r.freq, s.h_gsmall + (size_t)i * 256, 256 * sizeof(u64));
+            if (s.want_in_hist) memcpy(r.freq_in, s.h_gsmall + ((size_t)PIPE_GROUP_MAX + i) * 256, 256 * sizeof(u64));
+            r.out_n = (size_t)h_size[i];
+            break;
+        case SHAFA_OP_SF_ENCODE:
+            r.out_n = (size_t)h_size[i];
+            if (!block_rc[i] && r.out_n > s.g_cap[i]) block_rc[i] = SHAFA_LACK_OF_MEMORY;
+            break;
+        case SHAFA_OP_SF_RLE_DECODE:
+            r.mid_n = (size_t)s.g_nsym[i];
+            r.out_n = (size_t)h_size[i];
+            break;
+        default:
+            r.out_n = (size_t)h_size[i];
+            break;
+        }
+        if (block_rc[i]) r.out_n = 0;
+        if (s.op != SHAFA_OP_HIST && s.op != SHAFA_OP_SF_DECODE && r.out_n > width) width = r.out_n;
+    }
+    if (width) {                                         // the sizes are known now: the rows, as wide as the largest
+        int frc = group_fetch(s, width, s.st);
+        if (frc) return frc;
+        HIP_TRY(hipStreamSynchronize(s.st));
+    }
     return SHAFA_SUCCESS;
 }
 

@@ -141,3 +141,125 @@ def test_pipe_slots_spread_over_the_selected_devices(oracle, shafa):
     finally:
         shafa.init_devices([0])
     assert shafa.lib().shafa_hip_init_devices((__import__("ctypes").c_int * 1)(99), 1) == shafa.OUTSIDE_MODULE
+
+
+def test_pipe_groups_match_oracle_for_every_op(oracle, shafa):
+    """shafa_pipe_submit_group / shafa_pipe_wait_group: many small blocks per slot, groups in several slots at once, every op
+    against the oracle block by block — including a block whose table is malformed and a block whose stream is cut, which
+    must fail alone, in place, with the blocks around them intact (the drivers stop at the first failed block in order)."""
+    import golden.make_golden as mg
+    zt = shafa.zipf_table(1.2)
+    rng = np.random.default_rng(11)
+    n_groups, per = 5, 37
+    sizes = [int(x) for x in rng.integers(3000, 90000, n_groups * per)]
+    sizes[3], sizes[40] = 5, 17                                   # tiny blocks inside a group
+    blocks = [mg.runs_stream(500 + i % 7, 90000, zt)[:sizes[i]] if i % 3 else
+              np.frombuffer(oracle.gen_bytes(900 + i, sizes[i], zt).tobytes(), dtype=np.uint8) for i in range(len(sizes))]
+    pipe = shafa.Pipe(3)
+    groups = [list(range(g * per, (g + 1) * per)) for g in range(n_groups)]
+
+    def run(submit, retire):
+        sub = ret = 0
+        while ret < n_groups:
+            if sub < n_groups and sub - ret < pipe.n_slots:
+                submit(groups[sub], sub % pipe.n_slots)
+                sub += 1
+            else:
+                retire(groups[ret], ret % pipe.n_slots)
+                ret += 1
+
+    # F: RLE bytes + both histograms; plain histogram
+    rle = {}
+
+    def ret_rle(ids, slot):
+        rc, brc, outs, res = pipe.wait_group(slot, len(ids))
+        assert rc == 0 and not any(brc), (rc, brc)
+        for j, i in enumerate(ids):
+            want = oracle.rle_encode(blocks[i])
+            assert outs[j] == want.tobytes(), f"block {i}: rle bytes differ"
+            assert list(res[j].freq) == list(oracle.hist256(want)), f"block {i}: rle histogram"
+            assert list(res[j].freq_in) == list(oracle.hist256(blocks[i])), f"block {i}: input histogram"
+            rle[i] = np.frombuffer(outs[j], dtype=np.uint8)
+
+    run(lambda ids, slot: pipe.submit_group(slot, shafa.OP_RLE_ENCODE, [blocks[i] for i in ids], flags=shafa.PIPE_INPUT_HIST), ret_rle)
+
+    def ret_hist(ids, slot):
+        rc, brc, outs, res = pipe.wait_group(slot, len(ids))
+        assert rc == 0 and not any(brc)
+        for j, i in enumerate(ids):
+            assert list(res[j].freq) == list(oracle.hist256(blocks[i])), f"block {i}: hist"
+
+    run(lambda ids, slot: pipe.submit_group(slot, shafa.OP_HIST, [blocks[i] for i in ids]), ret_hist)
+
+    # C: SF encode of the RLE bytes; one block of the third group gets a table without a code for a byte it contains
+    tabs = {i: to_shafa_table(shafa, oracle.sf_build(oracle.hist256(rle[i]))) for i in rle}
+    bad_i = groups[2][5]
+    bad_tab = to_shafa_table(shafa, oracle.sf_build(oracle.hist256(rle[bad_i])))
+    sym = int(rle[bad_i][len(rle[bad_i]) // 2])
+    bad_tab.len[sym] = 0
+    enc = {}
+
+    def sub_enc(ids, slot):
+        ts = [bad_tab if i == bad_i else tabs[i] for i in ids]
+        caps = [(rle[i].size * max(1, int(max(t.lens()))) + 7) // 8 + 16 for i, t in zip(ids, ts)]
+        pipe.submit_group(slot, shafa.OP_SF_ENCODE, [rle[i] for i in ids], tables=ts, out_caps=caps)
+
+    def ret_enc(ids, slot):
+        rc, brc, outs, res = pipe.wait_group(slot, len(ids))
+        assert rc == 0
+        for j, i in enumerate(ids):
+            if i == bad_i:
+                assert brc[j] == shafa.FILE_UNRECOGNIZABLE, f"block {i}: rc {brc[j]}"
+                continue
+            assert brc[j] == 0, f"block {i}: rc {brc[j]}"
+            orc, want = oracle.sf_encode(rle[i], oracle.sf_build(oracle.hist256(rle[i])))
+            assert orc == 0 and outs[j] == want.tobytes(), f"block {i}: SF bytes differ"
+            enc[i] = np.frombuffer(outs[j], dtype=np.uint8)
+
+    run(sub_enc, ret_enc)
+
+    # D: SF decode, RLE decode, and both fused; one stream of the second group is cut short
+    enc[bad_i] = enc[groups[2][4]]                               # something decodable in the failed block's place
+    tabs_d = dict(tabs)
+    tabs_d[bad_i] = tabs[groups[2][4]]
+    nsym = {i: rle[i].size for i in rle}
+    nsym[bad_i] = rle[groups[2][4]].size
+    cut_i = groups[1][9]
+
+    def sub_dec(op):
+        def f(ids, slot):
+            data = [enc[i][:max(1, enc[i].size // 2)] if i == cut_i else enc[i] for i in ids]
+            pipe.submit_group(slot, op, data, tables=[tabs_d[i] for i in ids], n_symbols=[nsym[i] for i in ids])
+        return f
+
+    def ret_dec(fused):
+        def f(ids, slot):
+            rc, brc, outs, res = pipe.wait_group(slot, len(ids))
+            assert rc == 0
+            for j, i in enumerate(ids):
+                if i == cut_i:
+                    assert brc[j] == shafa.FILE_UNRECOGNIZABLE, f"block {i}: rc {brc[j]}"
+                    continue
+                assert brc[j] == 0, f"block {i}: rc {brc[j]}"
+                src = groups[2][4] if i == bad_i else i
+                want = blocks[src] if fused else rle[src]
+                assert outs[j] == want.tobytes(), f"block {i}: decoded bytes differ (fused {fused})"
+                if fused:
+                    assert res[j].mid_n == rle[src].size
+        return f
+
+    run(sub_dec(shafa.OP_SF_DECODE), ret_dec(False))
+    run(sub_dec(shafa.OP_SF_RLE_DECODE), ret_dec(True))
+
+    def ret_rled(ids, slot):
+        rc, brc, outs, res = pipe.wait_group(slot, len(ids))
+        assert rc == 0 and not any(brc), (rc, brc)
+        for j, i in enumerate(ids):
+            assert outs[j] == blocks[i].tobytes(), f"block {i}: RLE decode differs"
+
+    run(lambda ids, slot: pipe.submit_group(slot, shafa.OP_RLE_DECODE, [rle[i] for i in ids]), ret_rled)
+    # a slot holds a group or a single block, alternately
+    pipe.submit(0, shafa.OP_HIST, blocks[0])
+    rc, out, r = pipe.wait(0)
+    assert rc == 0 and list(r.freq) == list(oracle.hist256(blocks[0]))
+    pipe.close()
