@@ -137,11 +137,12 @@ static bool par_io(int fd, const uint8_t *buf, size_t n, off_t off, bool write)
  * are written inline.  A job's payload is a slot's pinned result buffer: the slot must not be
  * submitted again before writer_wait() on the job's ticket. */
 typedef struct { char hdr[40]; size_t hdr_n; const uint8_t *data; size_t n; } wjob;
+enum { WRITER_Q = 64 };        /* jobs in flight: a group of small blocks pushes one job per block */
 typedef struct {
     pthread_t th;
     pthread_mutex_t mu;
     pthread_cond_t cv;
-    wjob q[8];
+    wjob q[WRITER_Q];
     uint64_t pushed, done;
     int fd;                      /* every job of a writer goes to this file ... */
     off_t off;                   /* ... at this offset (advanced by the thread that runs the jobs) */
@@ -166,7 +167,7 @@ static void *writer_main(void *arg)
     for (;;) {
         while (w->done == w->pushed && !w->stop) pthread_cond_wait(&w->cv, &w->mu);
         if (w->done == w->pushed) break;
-        const wjob j = w->q[w->done % 8];
+        const wjob j = w->q[w->done % WRITER_Q];
         pthread_mutex_unlock(&w->mu);
         const int e = wjob_run(w, &j);
         pthread_mutex_lock(&w->mu);
@@ -212,8 +213,8 @@ static uint64_t writer_push(writer_t *w, const char *hdr, const uint8_t *data, s
         return ++w->pushed, ++w->done;
     }
     pthread_mutex_lock(&w->mu);
-    while (w->pushed - w->done == 8) pthread_cond_wait(&w->cv, &w->mu);
-    w->q[w->pushed % 8] = j;
+    while (w->pushed - w->done == WRITER_Q) pthread_cond_wait(&w->cv, &w->mu);
+    w->q[w->pushed % WRITER_Q] = j;
     const uint64_t t = ++w->pushed;
     pthread_cond_broadcast(&w->cv);
     pthread_mutex_unlock(&w->mu);
@@ -364,6 +365,109 @@ static void f_summary(uint64_t n_blocks, const uint64_t *sizes, uint64_t size_f,
     else if (p_rle_freq) printf("%s\n", p_rle_freq);
 }
 
+/* ------------------------------------------------------------------ groups of small blocks
+ * One launch per block costs the submitting thread ~0.1 ms whatever the block's size: at the reference's default 64 KiB
+ * blocks (file.h) that was all of a file's time.  Blocks of less than 2 MiB therefore go through the pipe in groups of
+ * consecutive blocks (layer 3: shafa_pipe_submit_group, one launch per kernel for the whole group); the block structure
+ * of the files, the order of the writes and the block whose error is reported stay what they are block by block.  The
+ * module drivers describe their blocks through two callbacks, both called in block order. */
+typedef struct {
+    uint64_t in_n;                 /* the block's bytes in the input file ... */
+    off_t file_off;                /* ... and where they start */
+    shafa_code_table tab;          /* SF ops */
+    uint64_t n_symbols;            /* SF decodes */
+    size_t out_cap;                /* SF encode */
+    int perr;                      /* the block's own error found on the host: surfaces when the block is retired */
+} gblk;
+typedef int (*g_prepare_fn)(void *ctx, uint64_t b, gblk *g);       /* an error stops further submissions; it is returned once
+                                                                     the blocks before b are retired */
+typedef int (*g_consume_fn)(void *ctx, uint64_t b, const shafa_pipe_result *r, uint64_t *ticket);
+
+static int group_size(uint64_t block_bytes, bool rle_decode)
+{
+    if (NO_MULTITHREAD || block_bytes >= (2u << 20)) return 1;
+    uint64_t g = block_bytes ? (16u << 20) / block_bytes : SHAFA_PIPE_GROUP_MAX;
+    if (rle_decode) {                                           /* the pipe sizes a block's result for 85 bytes out of one in */
+        const uint64_t cap = 85 * block_bytes + 256;
+        const uint64_t fit = (128u << 20) / (cap < ((64u << 20) + 1024) ? cap : ((64u << 20) + 1024));
+        if (g > fit) g = fit;
+    }
+    if (g > SHAFA_PIPE_GROUP_MAX) g = SHAFA_PIPE_GROUP_MAX;
+    return g < 2 ? 1 : (int)g;
+}
+
+/* blocks [first, end) through `pipe` in groups of at most G */
+static int run_groups(shafa_pipe *pipe, int in_fd, uint64_t first, uint64_t end, int G, int op, int flags,
+                      g_prepare_fn prepare, g_consume_fn consume, void *ctx, writer_t *wr, uint64_t *ticket)
+{
+    const uint64_t depth = (uint64_t)shafa_pipe_slots(pipe);
+    gblk *gb = malloc(depth * (size_t)G * sizeof(gblk));
+    shafa_pipe_block *pb = malloc((size_t)G * sizeof(*pb));
+    shafa_pipe_result *res = malloc((size_t)G * sizeof(*res));
+    int *brc = malloc((size_t)G * sizeof(int));
+    shafa_code_table *no_codes = calloc(1, sizeof(*no_codes));  /* a block with an error of its own is submitted empty */
+    uint64_t g_first[PIPE_SLOTS], g_cnt[PIPE_SLOTS];
+    int err = (gb && pb && res && brc && no_codes) ? SHAFA_SUCCESS : SHAFA_LACK_OF_MEMORY;
+    int deferred = 0;
+    uint64_t sub = first, ret = first, sg = 0, rg = 0;
+    while (!err && ret < end) {
+        if (!deferred && sub < end && sg - rg < depth) {
+            const int slot = (int)(sg % depth);
+            gblk *g = gb + (size_t)slot * (size_t)G;
+            uint64_t cnt = 0;
+            while (cnt < (uint64_t)G && sub + cnt < end) {
+                memset(&g[cnt], 0, sizeof(gblk));
+                const int e = prepare(ctx, sub + cnt, &g[cnt]);
+                if (e) { deferred = e; break; }
+                ++cnt;
+            }
+            size_t pos = 0;
+            for (uint64_t i = 0; i < cnt; ++i) {
+                pb[i].in_off = pos;
+                pb[i].in_n = g[i].perr ? 0 : (size_t)g[i].in_n;
+                pb[i].table = g[i].perr ? no_codes : &g[i].tab;
+                pb[i].n_symbols = g[i].perr ? 0 : (size_t)g[i].n_symbols;
+                pb[i].out_cap = g[i].perr ? 16 : g[i].out_cap;
+                pos += (pb[i].in_n + 15) & ~(size_t)15;
+            }
+            uint8_t *buf = cnt ? shafa_pipe_in(pipe, slot, pos ? pos : 16) : NULL;
+            if (cnt && !buf) { err = SHAFA_LACK_OF_MEMORY; break; }
+            for (uint64_t i = 0; i < cnt; ++i)
+                if (pb[i].in_n && !io_all(in_fd, buf + pb[i].in_off, pb[i].in_n, g[i].file_off, false)) {
+                    deferred = SHAFA_FILE_STREAM_FAILED;                  /* the file is shorter than announced: block i and on */
+                    cnt = i;
+                    break;
+                }
+            if (!cnt) continue;
+            if ((err = writer_wait(wr, ticket[slot]))) break;              /* the slot's previous results are on disk */
+            if ((err = shafa_pipe_submit_group(pipe, slot, op, (int)cnt, pb, flags))) break;
+            g_first[slot] = sub;
+            g_cnt[slot] = cnt;
+            sub += cnt;
+            ++sg;
+            continue;
+        }
+        if (sg == rg) { err = deferred ? deferred : SHAFA_FILE_STREAM_FAILED; break; }   /* nothing in flight any more */
+        const int slot = (int)(rg % depth);
+        const gblk *g = gb + (size_t)slot * (size_t)G;
+        const uint64_t cnt = g_cnt[slot];
+        if ((err = shafa_pipe_wait_group(pipe, slot, (int)cnt, res, brc))) break;
+        for (uint64_t i = 0; i < cnt && !err; ++i) {
+            if (g[i].perr) err = g[i].perr;
+            else if (brc[i]) err = brc[i];
+            else {
+                uint64_t tk = 0;
+                err = consume(ctx, g_first[slot] + i, &res[i], &tk);
+                if (tk) ticket[slot] = tk;
+                if (!err) ++ret;
+            }
+        }
+        ++rg;
+    }
+    free(gb); free(pb); free(res); free(brc); free(no_codes);
+    return err;
+}
+
 static int put_freq_block(FILE *f, uint64_t size, const uint64_t freq[256], bool last)
 {
     char text[SHAFA_FREQ_BLOCK_MAX + 1];
@@ -372,6 +476,36 @@ static int put_freq_block(FILE *f, uint64_t size, const uint64_t freq[256], bool
     if (fwrite(text, 1, n, f) != n) return SHAFA_FILE_STREAM_FAILED;
     if (last && fputs("@0", f) < 0) return SHAFA_FILE_STREAM_FAILED;          /* f.c:112-116 */
     return SHAFA_SUCCESS;
+}
+
+typedef struct {
+    uint64_t *sizes, *rle_sizes, bs, last, n_blocks;
+    bool use_rle, force_freq;
+    FILE *f_rle_freq, *f_freq;
+    writer_t *wr;
+} f_ctx;
+static int f_prepare(void *vc, uint64_t b, gblk *g)
+{
+    f_ctx *c = vc;
+    const uint64_t n = (b + 1 == c->n_blocks) ? c->last : c->bs;
+    c->sizes[b] = n;
+    g->in_n = n;
+    g->file_off = (off_t)(b * c->bs);
+    return SHAFA_SUCCESS;
+}
+static int f_consume(void *vc, uint64_t b, const shafa_pipe_result *r, uint64_t *ticket)
+{
+    f_ctx *c = vc;
+    int err = SHAFA_SUCCESS;
+    const bool is_last = b + 1 == c->n_blocks;
+    if (c->use_rle) {
+        c->rle_sizes[b] = r->out_n;
+        *ticket = writer_push(c->wr, NULL, r->out, r->out_n);
+        if ((err = put_freq_block(c->f_rle_freq, r->out_n, r->freq, is_last))) return err;
+    }
+    if (!c->use_rle || c->force_freq)                                           /* make_freq of the original, f.c:325 */
+        err = put_freq_block(c->f_freq, c->sizes[b], c->use_rle ? r->freq_in : r->freq, is_last);
+    return err;
 }
 
 _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, unsigned long block_size)
@@ -449,6 +583,13 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
         if (!use_rle || force_freq)                                             /* make_freq of the original, f.c:325 */
             err = put_freq_block(f_freq, n, was_rle ? res->freq_in : res->freq, bk + 1 == n_blocks);
         ++ret;
+        if (!err && bk == 0 && n_blocks > 1 && group_size(bs, false) > 1) {    /* small blocks: the rest in groups, with block 0's decision */
+            f_ctx c = {sizes, rle_sizes, bs, last, n_blocks, use_rle, force_freq, f_rle_freq, f_freq, &wr};
+            err = run_groups(pipe, in, 1, n_blocks, group_size(bs, false), use_rle ? SHAFA_OP_RLE_ENCODE : SHAFA_OP_HIST,
+                             force_freq ? SHAFA_PIPE_INPUT_HIST : 0, f_prepare, f_consume, &c, &wr, ticket);
+            ret = n_blocks;
+            break;
+        }
     }
     {
         const int werr = writer_stop(&wr);
@@ -530,6 +671,45 @@ _modules_error get_shafa_codes(const char *path)
 
 /* ------------------------------------------------------------------ Module C (c.c:306-472) */
 
+typedef struct { text_t *t; in_budget *left; uint64_t *in_sizes, *out_sizes; writer_t *wr; } c_ctx;
+static int c_prepare(void *vc, uint64_t b, gblk *g)
+{
+    c_ctx *c = vc;
+    uint64_t size = 0;
+    char *codes = NULL;
+    if (!read_block(c->t, &size, &codes, SHAFA_COD_BLOCK_MAX)) return SHAFA_FILE_STREAM_FAILED;       /* c.c:369 */
+    const char keep = c->t->buf[c->t->pos];
+    c->t->buf[c->t->pos] = '\0';
+    g->perr = shafa_cod_parse(codes, &g->tab);                                                       /* c.c:115-177 */
+    c->t->buf[c->t->pos] = keep;
+    if (!budget_has(c->left, size)) return SHAFA_FILE_STREAM_FAILED;                                 /* fread would come up short */
+    g->in_n = size;
+    g->file_off = (off_t)c->left->used;
+    c->left->used += size;
+    unsigned lmax = 0;
+    for (int q = 0; q < 256; ++q) lmax = g->tab.len[q] > lmax ? g->tab.len[q] : lmax;
+    g->out_cap = (size_t)((size * (uint64_t)lmax + 7) / 8) + 16;
+    c->in_sizes[b] = size;
+    return SHAFA_SUCCESS;
+}
+static int c_consume(void *vc, uint64_t b, const shafa_pipe_result *r, uint64_t *ticket)
+{
+    c_ctx *c = vc;
+    c->out_sizes[b] = r->out_n;
+    char hdr[40];
+    snprintf(hdr, sizeof(hdr), "@%lu@", (unsigned long)r->out_n);                                    /* c.c:256-258 */
+    *ticket = writer_push(c->wr, hdr, r->out, r->out_n);
+    return SHAFA_SUCCESS;
+}
+/* the size of the next block of a .cod / .freq text without consuming it */
+static uint64_t peek_block_size(const text_t *t, size_t max_payload)
+{
+    text_t q = *t;
+    uint64_t size = 0;
+    char *skip = NULL;
+    return read_block(&q, &size, &skip, max_payload) ? size : 0;
+}
+
 _modules_error shafa_compress(char **path)
 {
     const double t0 = now_ms();
@@ -568,6 +748,12 @@ _modules_error shafa_compress(char **path)
     writer_t wr;
     writer_start(&wr);
     writer_target(&wr, out, out_off);
+    const int G = (!err && n_blocks > 1) ? group_size(peek_block_size(&t, SHAFA_COD_BLOCK_MAX), false) : 1;
+    if (!err && G > 1) {                                                                /* small blocks: in groups */
+        c_ctx c = {&t, &left, in_sizes, out_sizes, &wr};
+        err = run_groups(pipe, in, 0, n_blocks, G, SHAFA_OP_SF_ENCODE, 0, c_prepare, c_consume, &c, &wr, ticket);
+        ret = n_blocks;
+    }
     while (!err && ret < n_blocks) {
         if (sub < n_blocks && sub - ret < depth) {
             uint64_t size = 0;
@@ -650,6 +836,24 @@ static void d_summary(double ms, const uint64_t *before, const uint64_t *after, 
     printf("Module runtime (in milliseconds): %f\nGenerated file %s\n", ms, path);
 }
 
+typedef struct { in_budget *left; uint64_t *sizes, *finals; writer_t *wr; } rd_ctx;
+static int rd_prepare(void *vc, uint64_t b, gblk *g)
+{
+    rd_ctx *c = vc;
+    if (!budget_has(c->left, c->sizes[b])) return SHAFA_FILE_STREAM_FAILED;
+    g->in_n = c->sizes[b];
+    g->file_off = (off_t)c->left->used;
+    c->left->used += c->sizes[b];
+    return SHAFA_SUCCESS;
+}
+static int rd_consume(void *vc, uint64_t b, const shafa_pipe_result *r, uint64_t *ticket)
+{
+    rd_ctx *c = vc;
+    c->finals[b] = r->out_n;
+    *ticket = writer_push(c->wr, NULL, r->out, r->out_n);
+    return SHAFA_SUCCESS;
+}
+
 _modules_error rle_decompress(char **path)
 {
     const double t0 = now_ms();
@@ -683,6 +887,12 @@ _modules_error rle_decompress(char **path)
     writer_t wr;
     writer_start(&wr);
     writer_target(&wr, out, out_off);
+    const int G = (!err && n_blocks > 1) ? group_size(sizes[0], true) : 1;
+    if (!err && G > 1) {                                                                /* small blocks: in groups */
+        rd_ctx c = {&left, sizes, finals, &wr};
+        err = run_groups(pipe, in, 0, n_blocks, G, SHAFA_OP_RLE_DECODE, 0, rd_prepare, rd_consume, &c, &wr, ticket);
+        ret = n_blocks;
+    }
     while (!err && ret < n_blocks) {
         if (sub < n_blocks && sub - ret < depth) {
             const int slot = (int)(sub % depth);
@@ -740,6 +950,36 @@ static bool shaf_read_u64(int fd, off_t *off, char lead, uint64_t *v, bool trail
     return true;
 }
 
+typedef struct { int in; off_t *in_off; text_t *t; in_budget *left; uint64_t *sf_sizes, *sizes, *finals; writer_t *wr; } d_ctx;
+static int d_prepare(void *vc, uint64_t b, gblk *g)
+{
+    d_ctx *c = vc;
+    uint64_t sf_n = 0, n_sym = 0;
+    if (!shaf_read_u64(c->in, c->in_off, '@', &sf_n, true)) return SHAFA_FILE_STREAM_FAILED;         /* d.c:697 */
+    if (!budget_has(c->left, sf_n)) return SHAFA_FILE_STREAM_FAILED;
+    g->in_n = sf_n;
+    g->file_off = *c->in_off;
+    *c->in_off += (off_t)sf_n;
+    c->left->used += sf_n;
+    char *codes = NULL;
+    if (!read_block(c->t, &n_sym, &codes, SHAFA_COD_BLOCK_MAX)) return SHAFA_FILE_STREAM_FAILED;     /* d.c:709,716 */
+    const char keep = c->t->buf[c->t->pos];
+    c->t->buf[c->t->pos] = '\0';
+    g->perr = shafa_cod_parse(codes, &g->tab);
+    c->t->buf[c->t->pos] = keep;
+    g->n_symbols = n_sym;
+    c->sf_sizes[b] = sf_n;
+    c->sizes[b] = n_sym;
+    return SHAFA_SUCCESS;
+}
+static int d_consume(void *vc, uint64_t b, const shafa_pipe_result *r, uint64_t *ticket)
+{
+    d_ctx *c = vc;
+    c->finals[b] = r->out_n;
+    *ticket = writer_push(c->wr, NULL, r->out, r->out_n);
+    return SHAFA_SUCCESS;
+}
+
 _modules_error shafa_decompress(char **path, bool decompress_rle)
 {
     const double t0 = now_ms();
@@ -775,6 +1015,13 @@ _modules_error shafa_decompress(char **path, bool decompress_rle)
     writer_t wr;
     writer_start(&wr);
     writer_target(&wr, out, out_off);
+    const int G = (!err && n_blocks > 1) ? group_size(peek_block_size(&t, SHAFA_COD_BLOCK_MAX), decompress_rle) : 1;
+    if (!err && G > 1) {                                                                /* small blocks: in groups */
+        d_ctx c = {in, &in_off, &t, &left, sf_sizes, sizes, finals, &wr};
+        err = run_groups(pipe, in, 0, n_blocks, G, decompress_rle ? SHAFA_OP_SF_RLE_DECODE : SHAFA_OP_SF_DECODE, 0,
+                         d_prepare, d_consume, &c, &wr, ticket);
+        ret = n_blocks;
+    }
     while (!err && ret < n_blocks) {
         if (sub < n_blocks && sub - ret < depth) {
             uint64_t sf_n = 0, n_sym = 0;
