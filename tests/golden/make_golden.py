@@ -354,6 +354,24 @@ def main():
         ["g.rle", "-m", "c"],
     ], "12 blocks of 64 KiB, block 6 of the .cod file malformed: Module C fails, what it wrote before stays")
 
+    # 12. hundreds of default-size blocks: the drivers take blocks of less than 2 MiB through the pipe in GROUPS (layer 3,
+    #     shafa_pipe_submit_group) — several groups per slot, a ragged last block, every module and every decode mode
+    big_case("many_default_rle", "m", {"kind": "runs", "seed": 51, "n": 700 * 65536 + 12345}, [
+        ["m", "-c", "f"], ["__copy__", "m", "orig__m"], ["__rm__", "m"],
+        ["m.rle.shaf"], ["__copy__", "m", "decoded__sf_rle"], ["__rm__", "m"],
+        ["m.rle.shaf", "-m", "d", "-d", "s"], ["__copy__", "m.rle", "decoded__sf"],
+        ["m.rle", "-m", "d", "-d", "r"], ["__copy__", "m", "decoded__rle_only"],
+    ], "701 blocks of 64 KiB (runs: RLE accepted), -c f: F (RLE + both histograms), T, C, then D fused, D SF only, D RLE only")
+    big_case("many_default_plain", "n", {"kind": "zipf", "seed": 52, "n": 530 * 65536 + 7}, [
+        ["n"], ["__copy__", "n", "orig__n"], ["__rm__", "n"],
+        ["n.shaf"], ["__copy__", "n", "decoded__sf"],
+    ], "531 blocks of 64 KiB (Zipf: RLE declined by block 0), F (histograms only), T, C, D")
+    big_case("many_default_bad_cod", "h", {"kind": "runs", "seed": 53, "n": 600 * 65536}, [
+        ["h", "-m", "f"], ["h.rle.freq", "-m", "t"],
+        ["__corrupt_cod__", "h.rle.cod", 437],
+        ["h.rle", "-m", "c"],
+    ], "600 blocks of 64 KiB, block 437 of the .cod file malformed (inside the second group of a slot): Module C fails there")
+
     # 9. CLI behaviour samples (exit codes + stderr text)
     run_case("cli_errors", {"z": runs_stream(11, 5000, zt).tobytes()}, [
         ["z", "-m", "f", "-m", "c"],          # c after f without t: error after F ran (shafa.c:193)
