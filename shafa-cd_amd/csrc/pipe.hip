@@ -47,8 +47,10 @@ struct Slot {
     bool out_queued;           // a payload copy was queued on st_d2h (ev_out recorded)
     // a group of blocks in the slot (shafa_pipe_submit_group): block i's result at d_out / h_out + i * g_stride
     int g_n;                   // 0: the slot holds a single block
+    bool g_wide;               // RLE decodes of the group with the full 85 x capacities (second attempt)
     size_t g_stride, g_mid_stride;
     u64 *g_in_off, *g_in_n, *g_out_off, *g_cap, *g_nsym, *g_mid_off;   // PIPE_GROUP_MAX entries each (allocated with the first group)
+    shafa_pipe_block *g_blk;   // the group as it was submitted (for the second attempt)
     shafa_code_table *g_tab;
     u64 *d_gsmall, *h_gsmall;  // per block of a group: [i * 256] hist of the result / input, [(G + i) * 256] hist of the input, [2 G * 256 + i] size
 };
@@ -202,7 +204,8 @@ int group_alloc(Slot &s)
     if (s.g_in_off) return SHAFA_SUCCESS;
     u64 *a = (u64 *)calloc((size_t)6 * PIPE_GROUP_MAX, sizeof(u64));
     shafa_code_table *t = (shafa_code_table *)calloc(PIPE_GROUP_MAX, sizeof(shafa_code_table));
-    if (!a || !t) { free(a); free(t); return SHAFA_LACK_OF_MEMORY; }
+    s.g_blk = (shafa_pipe_block *)calloc(PIPE_GROUP_MAX, sizeof(shafa_pipe_block));
+    if (!a || !t || !s.g_blk) { free(a); free(t); free(s.g_blk); s.g_blk = nullptr; return SHAFA_LACK_OF_MEMORY; }
     const size_t nsmall = G_SIZE_AT + 2 * PIPE_GROUP_MAX;
     HIP_TRY(hipMalloc((void **)&s.d_gsmall, nsmall * sizeof(u64)));
     HIP_TRY(hipHostMalloc((void **)&s.h_gsmall, nsmall * sizeof(u64), hipHostMallocPortable));
@@ -228,6 +231,7 @@ int slot_submit_group(Slot &s, int n, const shafa_pipe_block *blk)
     DeviceGuard dg(s.device);
     if ((rc = group_alloc(s))) return rc;
     if ((rc = batch_enter(s.batch, s.st))) return rc;
+    if (blk != s.g_blk) memcpy(s.g_blk, blk, (size_t)n * sizeof(*blk));
     size_t total_in = 0, max_cap = 0, max_sym = 0;
     for (int i = 0; i < n; ++i) {
         if (blk[i].in_off & 15) return SHAFA_OUTSIDE_MODULE;
@@ -245,6 +249,9 @@ int slot_submit_group(Slot &s, int n, const shafa_pipe_block *blk)
             const size_t rle_n = s.op == SHAFA_OP_RLE_DECODE ? blk[i].in_n : blk[i].n_symbols;
             cap = rle_n <= (size_t)SHAFA_RLE_DECODE_MAX / 85 ? 85 * rle_n + 256 : (size_t)SHAFA_RLE_DECODE_MAX;
             if (cap > (size_t)SHAFA_RLE_DECODE_MAX) cap = SHAFA_RLE_DECODE_MAX;                     // d.c:129-169
+            // ... but real blocks expand by a few per cent: the group is sized for 8 x + 4 KiB first (s.g_wide false) and
+            // decoded again with the full capacities when a block does not fit (shafa_pipe_wait_group)
+            if (!s.g_wide && cap > 8 * rle_n + 4096) cap = 8 * rle_n + 4096;
             break;
         }
         default: break;
@@ -254,7 +261,8 @@ int slot_submit_group(Slot &s, int n, const shafa_pipe_block *blk)
         if (blk[i].n_symbols > max_sym) max_sym = blk[i].n_symbols;
         if ((s.op == SHAFA_OP_SF_ENCODE || s.op == SHAFA_OP_SF_DECODE || s.op == SHAFA_OP_SF_RLE_DECODE)) {
             if (!blk[i].table) return SHAFA_OUTSIDE_MODULE;
-            s.g_tab[i] = *blk[i].table;
+            if (blk[i].table != &s.g_tab[i]) s.g_tab[i] = *blk[i].table;
+            s.g_blk[i].table = &s.g_tab[i];                                   // the caller's table need not outlive the call
         }
     }
     if (total_in > s.h_in_cap) return SHAFA_OUTSIDE_MODULE;
@@ -262,7 +270,7 @@ int slot_submit_group(Slot &s, int n, const shafa_pipe_block *blk)
     s.g_mid_stride = (max_sym + 16 + 15) & ~(size_t)15;
     for (int i = 0; i < n; ++i) { s.g_out_off[i] = (u64)i * s.g_stride; s.g_mid_off[i] = (u64)i * s.g_mid_stride; }
     if ((rc = grow_dev(&s.d_in, &s.d_in_cap, total_in))) return rc;
-    if (total_in) {
+    if (total_in && !s.g_wide) {                   // (the second attempt finds the input where the first left it)
         HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, total_in, hipMemcpyHostToDevice, s.st_h2d));
         HIP_TRY(hipEventRecord(s.ev_in, s.st_h2d));
         HIP_TRY(hipStreamWaitEvent(s.st, s.ev_in, 0));
@@ -390,6 +398,7 @@ void shafa_pipe_destroy(shafa_pipe *p)
         if (s.h_gsmall) hipHostFree(s.h_gsmall);
         free(s.g_in_off);
         free(s.g_tab);
+        free(s.g_blk);
         if (s.st) hipStreamDestroy(s.st);
         if (s.st_d2h) hipStreamDestroy(s.st_d2h);
     }
@@ -490,6 +499,7 @@ int shafa_pipe_submit_group(shafa_pipe *p, int slot, int op, int nblocks, const 
     s.copied = 0;
     s.out_queued = false;
     s.g_n = nblocks;
+    s.g_wide = false;
     s.rc = slot_submit_group(s, nblocks, blocks);        // errors are reported by shafa_pipe_wait_group
     return SHAFA_SUCCESS;
 }
@@ -507,6 +517,16 @@ int shafa_pipe_wait_group(shafa_pipe *p, int slot, int nblocks, shafa_pipe_resul
     if (s.out_queued) {
         const hipError_t e = hipEventSynchronize(s.ev_out);
         if (e != hipSuccess && !s.rc) s.rc = shafa_set_hip_error(e, "shafa_pipe_wait_group");
+    }
+    if (!s.rc && !s.g_wide && (s.op == SHAFA_OP_RLE_DECODE || s.op == SHAFA_OP_SF_RLE_DECODE)) {
+        bool again = false;                              // a block that expands more than eightfold: the whole group once more,
+        for (int i = 0; i < nblocks; ++i) again = again || block_rc[i] == SHAFA_LACK_OF_MEMORY;   //   sized for the worst case
+        if (again) {
+            s.g_wide = true;
+            s.rc = slot_submit_group(s, nblocks, s.g_blk);
+            for (int i = 0; i < nblocks; ++i) block_rc[i] = SHAFA_SUCCESS;
+            rc = shafa_hipd_finish((shafa_hipd_batch *)s.batch, s.st, nblocks, block_rc);
+        }
     }
     if (s.rc) return s.rc;                               // the submission itself failed: no block has a result
     (void)rc;                                            // per-block codes are in block_rc

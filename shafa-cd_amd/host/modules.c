@@ -387,8 +387,9 @@ static int group_size(uint64_t block_bytes, bool rle_decode)
 {
     if (NO_MULTITHREAD || block_bytes >= (2u << 20)) return 1;
     uint64_t g = block_bytes ? (16u << 20) / block_bytes : SHAFA_PIPE_GROUP_MAX;
-    if (rle_decode) {                                           /* the pipe sizes a block's result for 85 bytes out of one in */
-        const uint64_t cap = 85 * block_bytes + 256;
+    if (rle_decode) {                                           /* the pipe sizes a block's result for eight bytes out of one in
+                                                                   (and decodes a group again, sized for 85, if one expands more) */
+        const uint64_t cap = 8 * block_bytes + 4096;
         const uint64_t fit = (128u << 20) / (cap < ((64u << 20) + 1024) ? cap : ((64u << 20) + 1024));
         if (g > fit) g = fit;
     }

@@ -366,6 +366,12 @@ def main():
         ["n"], ["__copy__", "n", "orig__n"], ["__rm__", "n"],
         ["n.shaf"], ["__copy__", "n", "decoded__sf"],
     ], "531 blocks of 64 KiB (Zipf: RLE declined by block 0), F (histograms only), T, C, D")
+    big_case("many_default_single_run", "k", {"kind": "const", "byte": 0x41, "n": 40 * 65536 + 300}, [
+        ["k"], ["__copy__", "k", "orig__k"], ["__rm__", "k"],
+        ["k.rle.shaf"], ["__copy__", "k", "decoded__sf_rle"],
+        ["__copy__", "k.rle", "keep__k.rle"], ["__rm__", "k"],
+        ["k.rle", "-m", "d"], ["__copy__", "k", "decoded__rle_only"],
+    ], "41 blocks of 64 KiB of one byte: every block's RLE bytes (774) expand 85-fold — the pipe's groups are sized for eightfold and decode again")
     big_case("many_default_bad_cod", "h", {"kind": "runs", "seed": 53, "n": 600 * 65536}, [
         ["h", "-m", "f"], ["h.rle.freq", "-m", "t"],
         ["__corrupt_cod__", "h.rle.cod", 437],

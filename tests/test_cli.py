@@ -87,7 +87,7 @@ GPU_CASES = ["runs_default", "edges_forced_rle", "uniform_no_rle", "uniform_forc
 FULL_CASES = ["full_uniform_m", "full_zipf_M", "full_zipfmod_M_forced_rle", "full_single_run_M", "full_alt01_M",
               "full_longtail_M", "full_mixed_M",
               # hundreds of default-size blocks: the drivers' group mode (several groups per slot)
-              "many_default_rle", "many_default_plain", "many_default_bad_cod"]
+              "many_default_rle", "many_default_plain", "many_default_bad_cod", "many_default_single_run"]
 
 
 def scratch_dir(tmp_path, case):
