@@ -1491,12 +1491,531 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_spec_check(const DecBlk *__re
     bool any = false;
     for (u32 t = threadIdx.x + blockIdx.y * DEC_THREADS; t < blk.n_tiles; t += DEC_THREADS * gridDim.y) {   // gridDim.y workgroups per block
         const size_t gt = (size_t)blk.tile_base + t;
-        const bool diff = t > 0 && tile_guess[gt] != tile_exit[gt - 1];
+        const bool diff = t > 0 ? tile_guess[gt] != tile_exit[gt - 1] : tile_guess[gt] == 0xFFu;   // 0xFF: left to the repair launch (sfd_scan)
         if (!FINAL) tile_fix[gt] = diff ? 1 : 0;
         any |= diff;
     }
     if (FINAL && __syncthreads_or(any) && threadIdx.x == 0)
         __hip_atomic_store(blk.run_dp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ================================================================================================
+// sfd_scan: the speculative entries again, built for the way gfx950's LDS and vector ALUs price the walk
+// (DESIGN.md §3.2).  Same contract and same outputs as sfd_spec (entry and code count of every 256-bit chunk, tile
+// counts, a guess / exit pair per unit for sfd_spec_check), different shape:
+//   * a lane owns a STRIP of SC_SB = 256 bytes (8 chunks) and walks it front to back with its exact position carried
+//     from chunk to chunk, so only the strip's first entry is a guess: the 256-bit run-up is paid once per 2048 bits
+//     (sfd_spec: once per 512);
+//   * the strip passes through LDS one 64-byte PHASE at a time (17 words per lane, as before), each lane's words in
+//     its own COLUMN (word i of lane c at dword i * 256 + c): a lane only ever reads bank c % 32, so the stream
+//     reads are conflict free whatever word each lane is at (rows 17 words apart met on a bank whenever two lanes 2,
+//     15 or 17 apart were 2 or 1 words apart: ds_read_b32 banks are (a / 4) % 32 within each half wave);
+//   * a wave loads, walks and verifies its own 64 strips (16 KiB of stream): nothing in the walk waits for another wave,
+//     there is no workgroup barrier after the table fill;
+//   * the phase's words are fetched by lane PAIRS (32 contiguous bytes per pair and instruction, two lanes per column
+//     and store: a 2-way store conflict is free), one phase ahead of the walk.
+// A phase's row holds stream words 16 k - 1 .. 16 k + 15 of the strip (word 0 = the previous phase's last word, carried
+// over), so a window never needs a word that is not there: a fetch at row bit q reads words q >> 5 and (q >> 5) + 1 <= 16.
+// Row bit 32 is the strip's bit 512 k (a chunk boundary), 288 the next one, 544 = the next phase's 32.  The walk of a
+// phase: finish the chunk in progress (single codes up to row bit 32), walk chunk 2 k (three codes per look-up, then
+// single codes up to 288), start chunk 2 k + 1 (three codes per look-up while the fetch stays inside the row: q < 512).
+// The run-up is the same last step on a row that holds the 32 bytes in front of the strip.
+// Lanes whose guess differs from the exit of the lane before them walk again from that exit until they are back on
+// their first path (scan_strip<.., true>: the wave reloads the phases, only those lanes walk); the first lane of a wave
+// is compared with the wave before it by sfd_spec_check and redone by sfd_scan<true> with its entry forced.
+// ================================================================================================
+constexpr int SC_PHW = 16;                          // stream words per phase and strip (64 bytes)
+constexpr int SC_M = 4;                             // phases per strip
+constexpr int SC_SB = SC_PHW * 4 * SC_M;            // bytes per strip
+constexpr int SC_CH = SC_SB / CH_BYTES;             // chunks per strip
+constexpr int SC_STRIPS_TILE = DTILE / SC_SB;       // strips per tile (32: half a wave)
+constexpr int SC_WTILES = 64 / SC_STRIPS_TILE;      // tiles per wave (2): the "unit" of sfd_spec_check's links
+constexpr int SC_TILES = DEC_THREADS / SC_STRIPS_TILE;   // tiles per workgroup (8)
+constexpr int SC_ROWW = SC_PHW + 1;                 // row words: the carried word, then the phase's 16
+constexpr int SC_COLB = DEC_THREADS * 4;            // bytes between two words of a column
+constexpr int SC_LDS_ROWS = SC_ROWW * SC_COLB;
+constexpr int SC_MISC = 64;                         // flags of wg_any
+constexpr int SC_FIX_REGIONS = 16;                  // regions a workgroup of a repair launch looks at
+static_assert(SC_COLB == 1024 && SC_WTILES == 2 && SC_STRIPS_TILE == 32, "sfd_scan's lane maps");
+
+struct ScanWin {
+    u32 lo, hi, wa, cb;                                 // words at LDS address wa, wa + SC_COLB; cb: the lane's column
+    __device__ __forceinline__ void init(u32 col) { cb = col; wa = 0xFFFFFFFFu; hi = lo = 0; }
+    __device__ __forceinline__ void flush() { wa = 0xFFFFFFFFu; }      // the row was rewritten
+    __device__ __forceinline__ u32 at(u32 q)            // the 32 stream bits from row bit q on
+    {
+        const u32 a = cb + ((q >> 5) << 10);
+        if (a != wa) {
+            lo = *(const lds_u32 *)(size_t)a;
+            hi = *(const lds_u32 *)(size_t)(a + SC_COLB);
+            wa = a;
+        }
+        return __builtin_amdgcn_alignbit(hi, lo, q);
+    }
+};
+
+template <int LONG>
+__device__ __forceinline__ u32 scan_long_len(const u16 *lt, ScanWin &sw, const u32 qq)
+{
+    const u32 win = __builtin_bitreverse32(sw.at(qq));
+    const u32 l = (LONG == 1 ? long_code(lt, win) : long_code32(lt, win)) >> 8;
+    return l ? l : 1u;                                  // at least 1: the walk must move
+}
+
+// whole fetches (two or three look-ups of up to three codes each) from row bit q while every code taken ends by `qe`
+// and the fetch (and a long code's window behind it) stays inside the row; counts the codes started on the way
+template <int LONG>
+__device__ __forceinline__ void scan_multi(const lds_u8 *tab, const u16 *lt, const u32 KW, u32 &q, const u32 qe, u32 &cnt, ScanWin &sw)
+{
+    const u32 mask = (1u << KW) - 1u;
+    const u32 q0 = q;
+    u32 acc = 0;                                        // sum of the entries = bits walked + 16 * codes
+    auto multi = [&](auto nlook) {
+        constexpr u32 N = decltype(nlook)::value;
+        const u32 in_row = 32u * SC_PHW - 1u - (LONG ? (N - 1u) * KW : 0u);
+        const u32 qs = qe - N * KW < in_row ? qe - N * KW : in_row;
+        while (q <= qs) {
+            const u32 w = sw.at(q);
+            u32 used = 0, e = 0;
+#pragma unroll
+            for (u32 i = 0; i < N; ++i) {
+                e = tab[(w >> used) & mask];
+                used += e & 15u;
+                acc += e;
+            }
+            q += used;
+            if (LONG && __builtin_expect((e & 15u) == 0u, 0)) {      // a long code stopped the look-ups: it starts at q
+                const u32 l = scan_long_len<LONG>(lt, sw, q);
+                q += l;
+                acc += l + 16u;
+            }
+        }
+    };
+    if (KW <= 10) multi(std::integral_constant<u32, 3>{});
+    else multi(std::integral_constant<u32, 2>{});
+    cnt += (acc - (q - q0)) >> 4;
+}
+
+// single codes from row bit q to the first code start >= qe.  LAST: the stream ends at row bit `qlimit` (may lie in
+// front of q); a code that does not end inside it is not a symbol and nothing starts after it: returns true ("cut")
+template <bool LAST, int LONG>
+__device__ __forceinline__ bool scan_single(const lds_u8 *tab, const u16 *lt, const u32 KW, u32 &q, const u32 qe, const int qlimit,
+                                            u32 &cnt, ScanWin &sw)
+{
+    const u32 mask = (1u << KW) - 1u;
+    const lds_u8 *len0 = tab + (1u << KW);
+    while (q < qe) {
+        u32 l0 = len0[sw.at(q) & mask];
+        if (LONG && __builtin_expect(l0 == 0u, 0)) l0 = scan_long_len<LONG>(lt, sw, q);
+        if (LAST && (int)(q + l0) > qlimit) return true;
+        q += l0;
+        ++cnt;
+    }
+    return false;
+}
+
+// What a wave's lanes share while they load and walk 64 strips from byte `wave_off` of the block's stream (lane = strip =
+// column).  The phase's words are fetched by lane PAIRS: pair px loads strips px and px + 32, 32 contiguous bytes per
+// pair and load, and stores them into those strips' columns.
+#ifndef SC_QUAD
+#define SC_QUAD 0
+#endif
+#ifndef SC_NT
+#define SC_NT 0
+#endif
+struct ScanIO {
+    const u8 *in;
+    u64 in_n;
+    long long grp_off;                                  // the lane group's first byte of phase 0, first strip
+    u32 wbase, ph, cb;
+    // lanes per strip and load (SC_QUAD: four lanes fetch the 64 bytes of a strip's phase as one contiguous piece — one
+    // request — and store into one column: a 4-way store conflict, twice the cycles of ds_write_b32; else pairs, 32 bytes
+    // per request, 2-way stores = free)
+    static constexpr u32 G = SC_QUAD ? 4u : 2u, SPL = 64u / G;        // strips per load instruction
+    __device__ __forceinline__ void init(const DecBlk &blk, const u64 wave_off)
+    {
+        const u32 tid = threadIdx.x, lane = tid & 63u, px = lane / G;
+        in = blk.in;
+        in_n = blk.in_n;
+        ph = lane % G;
+        grp_off = (long long)wave_off + (long long)px * SC_SB + 16ll * ph;
+        wbase = 4u * ((tid & ~63u) + px);
+        cb = 4u * tid;
+    }
+    // 16 stream bytes at `off`; CHECKED: zeros outside the stream (the piece the stream ends in byte by byte, rolled:
+    // one per block)
+    template <bool CHECKED>
+    __device__ __forceinline__ uint4 fetch16(const long long off) const
+    {
+        if (!CHECKED || (off >= 0 && (u64)off + 16 <= in_n)) return SC_NT ? gload_nt<uint4>(in + off) : gload<uint4>(in + off);
+        u32 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+        if (off >= 0 && (u64)off < in_n) {
+            const int nv = (int)(in_n - (u64)off);
+#pragma clang loop unroll(disable)
+            for (int b = 0; b < nv; ++b) {
+                const u32 v = (u32)gload<u8>(in + off + b) << (8 * (b & 3));
+                const int wi = b >> 2;
+                w0 |= wi == 0 ? v : 0u;
+                w1 |= wi == 1 ? v : 0u;
+                w2 |= wi == 2 ? v : 0u;
+                w3 |= wi == 3 ? v : 0u;
+            }
+        }
+        return make_uint4(w0, w1, w2, w3);
+    }
+    // load t of a phase: strips px + SPL * sgrp(t), 16 bytes at piece(t) of the phase's 64
+    static __device__ __forceinline__ constexpr u32 sgrp(const int t) { return SC_QUAD ? (u32)t : (u32)t >> 1; }
+    static __device__ __forceinline__ constexpr u32 piece(const int t) { return SC_QUAD ? 0u : 32u * ((u32)t & 1u); }
+    template <bool CHECKED>
+    __device__ __forceinline__ void load_phase(const int k, uint4 (&R)[4]) const
+    {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            R[t] = fetch16<CHECKED>(grp_off + (long long)sgrp(t) * SPL * SC_SB + 64ll * k + piece(t));
+    }
+    // the 32 bytes in front of every strip (the block's first strip has none: it is never guessed; reads its own head)
+    static constexpr int NRU = SC_QUAD ? 4 : 2;        // loads of the run-up (SC_QUAD: half of the lanes idle)
+    template <bool CHECKED>
+    __device__ __forceinline__ void load_runup(uint4 (&RU)[NRU]) const
+    {
+#pragma unroll
+        for (int t = 0; t < NRU; ++t) {
+            const long long o = grp_off - 32ll - (SC_QUAD ? 16ll * (ph & 2u) : 0ll) + (long long)t * SPL * SC_SB;
+            RU[t] = fetch16<CHECKED>(o < 0 ? o + 32 : o);
+        }
+    }
+    // row word r of the column of strip px + SPL * xhi
+    __device__ __forceinline__ void put(const u32 r, const u32 xhi, const u32 v) const
+    {
+        *(lds_u32 *)(size_t)(wbase + r * SC_COLB + 4u * SPL * xhi) = rev_bytes(v);
+    }
+    __device__ __forceinline__ void wave_sync() const  // LDS operations of one wave execute in order: only the compiler is told
+    {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ void put_runup(const uint4 (&RU)[NRU]) const    // row words 9..16
+    {
+#pragma unroll
+        for (int t = 0; t < NRU; ++t) {
+            const u32 r = 9u + 4u * (ph & 1u);
+            if (!SC_QUAD || ph < 2u) {
+                put(r, t, RU[t].x);
+                put(r + 1, t, RU[t].y);
+                put(r + 2, t, RU[t].z);
+                put(r + 3, t, RU[t].w);
+            }
+        }
+        wave_sync();
+    }
+    // the row of a phase: word 0 = the old row's last word, words 1..16 = the phase
+    __device__ __forceinline__ void put_phase(const uint4 (&R)[4]) const
+    {
+        const u32 carry = *(const lds_u32 *)(size_t)(cb + 16u * SC_COLB);
+        wave_sync();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const u32 r = 1u + 4u * ph + piece(t) / 4u;
+            put(r, sgrp(t), R[t].x);
+            put(r + 1, sgrp(t), R[t].y);
+            put(r + 2, sgrp(t), R[t].z);
+            put(r + 3, sgrp(t), R[t].w);
+        }
+        *(lds_u32 *)(size_t)cb = carry;
+        wave_sync();
+    }
+    // the strip's last chunk ends in the next strip's first word: row = carried word, that word
+    template <bool CHECKED>
+    __device__ __forceinline__ void put_next_strip(const u64 wave_off) const
+    {
+        u32 nw = 0;
+        const long long off = (long long)wave_off + (long long)((threadIdx.x & 63u) + 1u) * SC_SB;
+        if (!CHECKED || (u64)off + 4 <= in_n) nw = gload<u32>(in + off);
+        else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if ((u64)off + b < in_n) nw |= (u32)gload<u8>(in + off + b) << (8 * b);
+        }
+        const u32 carry = *(const lds_u32 *)(size_t)(cb + 16u * SC_COLB);
+        *(lds_u32 *)(size_t)cb = carry;
+        *(lds_u32 *)(size_t)(cb + SC_COLB) = rev_bytes(nw);
+    }
+};
+
+// The walk of a wave whose strips lie inside the stream with room to spare (all but a block's last wave): no bounds, no
+// stream end, every lane walks; the phases unrolled, entries and counts in registers.
+template <int LONG>
+__device__ __forceinline__ void scan_strip_fast(const lds_u8 *tab, const u16 *lt, const u32 KW, const DecBlk &blk, const u64 wave_off,
+                                                const u32 e_forced, const bool forced, u32 (&ent)[SC_CH], u32 (&cnt)[SC_CH], u32 &exit_)
+{
+    ScanIO io;
+    io.init(blk, wave_off);
+    ScanWin sw;
+    sw.init(io.cb);
+    uint4 R[4];
+    u32 q, pc = 0;
+    // the chunk in progress up to where the row ends (q >= 512 afterwards): the last step of a phase, and the whole run-up
+    auto to_row_end = [&]() {
+        scan_multi<LONG>(tab, lt, KW, q, 32u * SC_PHW + 32u, pc, sw);
+        if (LONG) scan_single<false, LONG>(tab, lt, KW, q, 32u * SC_PHW, 0, pc, sw);
+    };
+    {
+        uint4 RU[ScanIO::NRU];
+        io.load_runup<false>(RU);
+        io.load_phase<false>(0, R);
+        io.put_runup(RU);
+    }
+    q = 32u * 9u;
+    to_row_end();
+    q -= 32u * SC_PHW;
+#pragma unroll
+    for (int k = 0; k < SC_M; ++k) {
+        io.put_phase(R);
+        sw.flush();
+        if (k + 1 < SC_M) io.load_phase<false>(k + 1, R);
+        // 1. finish the chunk in progress: its count, and the entry of chunk 2 k
+        scan_single<false, LONG>(tab, lt, KW, q, 32u, 0, pc, sw);
+        if (k > 0) cnt[2 * k - 1] = pc;
+        if (k == 0 && forced) q = 32u + e_forced;
+        ent[2 * k] = q - 32u;
+        // 2. chunk 2 k
+        u32 c = 0;
+        scan_multi<LONG>(tab, lt, KW, q, 288u, c, sw);
+        scan_single<false, LONG>(tab, lt, KW, q, 288u, 0, c, sw);
+        cnt[2 * k] = c;
+        ent[2 * k + 1] = q - 288u;
+        // 3. chunk 2 k + 1 as far as the row reaches
+        pc = 0;
+        to_row_end();
+        q -= 32u * SC_PHW;
+    }
+    io.put_next_strip<false>(wave_off);
+    sw.flush();
+    scan_single<false, LONG>(tab, lt, KW, q, 32u, 0, pc, sw);
+    cnt[SC_CH - 1] = pc;
+    exit_ = (q - 32u) & spec_emask<LONG>();
+}
+
+// entries and counts of a strip's chunks packed for access by a run-time index (the rolled walk below)
+struct ScanOut {
+    u64 e, c[2];
+    __device__ __forceinline__ u32 ent(const u32 j) const { return (u32)(e >> (8u * j)) & 0xFFu; }
+    __device__ __forceinline__ void set_ent(const u32 j, const u32 v) { e = (e & ~(0xFFull << (8u * j))) | ((u64)v << (8u * j)); }
+    __device__ __forceinline__ void set_cnt(const u32 j, const u32 v)
+    {
+        const u32 sh = 16u * (j & 3u);
+        const u64 m = ~(0xFFFFull << sh), x = (u64)v << sh;
+        if (j < 4) c[0] = (c[0] & m) | x; else c[1] = (c[1] & m) | x;
+    }
+    __device__ __forceinline__ void pack(const u32 (&en)[SC_CH], const u32 (&cn)[SC_CH])
+    {
+        e = 0; c[0] = c[1] = 0;
+#pragma unroll
+        for (int j = 0; j < SC_CH; ++j) { e |= (u64)en[j] << (8 * j); c[j >> 2] |= (u64)cn[j] << (16 * (j & 3)); }
+    }
+    __device__ __forceinline__ void unpack(u32 (&en)[SC_CH], u32 (&cn)[SC_CH]) const
+    {
+#pragma unroll
+        for (int j = 0; j < SC_CH; ++j) { en[j] = (u32)(e >> (8 * j)) & 0xFFu; cn[j] = (u32)(c[j >> 2] >> (16 * (j & 3))) & 0xFFFFu; }
+    }
+};
+static_assert(SC_CH == 8, "ScanOut packs eight chunks");
+
+// The same walk for the rare cases, phases rolled (a few of them per launch: registers matter, speed does not):
+// LAST: the stream ends inside (or in front of) the wave's strips, at `end_bits` relative to the lane's strip (any sign);
+//       loads are bounded, a code that does not end inside the stream is not a symbol and nothing starts after it.
+// REDO = false: every lane walks: run-up (or `e_forced` where `forced`), then the strip.
+// REDO = true : the lanes with `walking` walk again from entry `e_forced` until an entry equals the one recorded in `o`
+//               (back on the first walk's path: the rest of o / exit stands); the others only help loading.
+template <bool LAST, int LONG, bool REDO>
+__device__ __forceinline__ void scan_strip_gen(const lds_u8 *tab, const u16 *lt, const u32 KW, const DecBlk &blk, const u64 wave_off,
+                                            const int end_bits, const u32 e_forced, const bool forced, bool walking,
+                                            ScanOut &o, u32 &exit_)
+{
+    const u32 emask = spec_emask<LONG>();
+    ScanIO io;
+    io.init(blk, wave_off);
+    ScanWin sw;
+    sw.init(io.cb);
+    uint4 R[4];
+    u32 q = 0, pc = 0;
+    bool cut = false;
+    auto to_row_end = [&](const int ql) {
+        if (!LAST) scan_multi<LONG>(tab, lt, KW, q, 32u * SC_PHW + 32u, pc, sw);
+        if (LAST || LONG) cut = scan_single<LAST, LONG>(tab, lt, KW, q, 32u * SC_PHW, ql, pc, sw);
+    };
+    if (!REDO) {
+        uint4 RU[ScanIO::NRU];
+        io.load_runup<LAST>(RU);
+        io.put_runup(RU);
+        q = 32u * 9u;
+        to_row_end(end_bits + 32 * (SC_PHW + 1));
+        q -= 32u * SC_PHW;
+    }
+    // (a walk that repeats loads each phase when it gets there: no registers held across the look-up loops)
+    if (!REDO) io.load_phase<LAST>(0, R);
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < SC_M; ++k) {
+        if (REDO) io.load_phase<LAST>(k, R);
+        io.put_phase(R);
+        sw.flush();
+        if (!REDO && k + 1 < SC_M) io.load_phase<LAST>(k + 1, R);
+        const int ql = end_bits - 32 * SC_PHW * k + 32;
+        if (!REDO) {
+            if (!cut) cut = scan_single<LAST, LONG>(tab, lt, KW, q, 32u, ql, pc, sw);
+            if (k > 0) o.set_cnt(2 * k - 1, pc);
+            u32 e = cut ? emask : q - 32u;
+            if (k == 0 && forced) { e = e_forced; q = 32u + e; cut = false; }
+            o.set_ent(2 * k, e);
+        } else if (walking) {
+            if (k == 0) {
+                q = 32u + e_forced;
+                cut = false;
+                o.set_ent(0, e_forced);
+            } else {
+                if (!cut) cut = scan_single<LAST, LONG>(tab, lt, KW, q, 32u, ql, pc, sw);
+                o.set_cnt(2 * k - 1, pc);
+                const u32 e = cut ? emask : q - 32u;
+                if (e == o.ent(2 * k)) walking = false; else o.set_ent(2 * k, e);
+            }
+        }
+        if (walking) {
+            u32 c = 0;
+            if (!cut) {
+                if (!LAST) scan_multi<LONG>(tab, lt, KW, q, 288u, c, sw);
+                cut = scan_single<LAST, LONG>(tab, lt, KW, q, 288u, ql, c, sw);
+            }
+            o.set_cnt(2 * k, c);
+            const u32 e = cut ? emask : q - 288u;
+            if (REDO && e == o.ent(2 * k + 1)) walking = false; else o.set_ent(2 * k + 1, e);
+        }
+        if (walking) {
+            pc = 0;
+            if (!cut) to_row_end(ql);
+            q -= 32u * SC_PHW;
+        }
+        if (REDO && !__any(walking)) return;            // (uniform) every lane is back on its first path
+    }
+    io.put_next_strip<LAST>(wave_off);
+    sw.flush();
+    if (walking) {
+        const int ql = end_bits - 32 * SC_PHW * SC_M + 32;
+        if (!cut) cut = scan_single<LAST, LONG>(tab, lt, KW, q, 32u, ql, pc, sw);
+        o.set_cnt(SC_CH - 1, pc);
+        exit_ = cut ? emask : (q - 32u) & emask;
+    }
+}
+
+// the wave's unit: tiles wtile, wtile + 1 of the block
+template <bool FIX, int LONG>
+__device__ __forceinline__ void scan_unit(u8 *smem, const DecBlk &blk, const u32 wtile, u8 *__restrict__ chunk_entry,
+                                          u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt, u8 *__restrict__ tile_guess,
+                                          u8 *__restrict__ tile_exit, const u32 tab_bytes)
+{
+    const u32 lane = threadIdx.x & 63u;
+    const size_t gtw = (size_t)blk.tile_base + wtile;
+    const u32 KW = blk.KW;
+    const lds_u8 *tab = (const lds_u8 *)(size_t)SC_LDS_ROWS;      // a literal: the dynamic segment starts at 0 (checked by the kernel)
+    const u16 *lt = (const u16 *)(smem + SC_LDS_ROWS + tab_bytes + SC_MISC);
+    const u64 wave_off = (u64)wtile * DTILE;
+    const u64 left = blk.in_n > wave_off ? blk.in_n - wave_off : 0;
+    const bool last = left < (u64)64 * SC_SB + 4;       // the stream ends inside (or in front of) the wave's strips
+    const int end_bits = last ? (int)(left * 8) - (int)(8u * SC_SB * lane) : 0;
+    const bool exact0 = wtile == 0 && lane == 0;        // the block's first bit: entry 0, no guess
+    const bool forced = exact0 || (FIX && lane == 0);
+    const u32 e_forced = exact0 ? 0u : (FIX && lane == 0) ? (u32)tile_exit[gtw - 1] : 0u;
+    u32 ent[SC_CH], cnt[SC_CH], exit_ = 0;
+    if (!FIX) {
+        if (last) {                                     // (uniform) the block's last wave is left to the repair launch: a guess
+            if (lane == 0) {                            // that no exit equals marks it (sfd_spec_check)
+                tile_guess[gtw] = 0xFFu;
+                if (wtile + 1 < blk.n_tiles) { tile_exit[gtw] = 0; tile_guess[gtw + 1] = 0; }
+            }
+            return;
+        }
+        scan_strip_fast<LONG>(tab, lt, KW, blk, wave_off, e_forced, forced, ent, cnt, exit_);
+    } else {
+        ScanOut o;
+        o.e = 0; o.c[0] = o.c[1] = 0;
+        if (last) scan_strip_gen<true, LONG, false>(tab, lt, KW, blk, wave_off, end_bits, e_forced, forced, true, o, exit_);
+        else scan_strip_gen<false, LONG, false>(tab, lt, KW, blk, wave_off, 0, e_forced, forced, true, o, exit_);
+        o.unpack(ent, cnt);
+    }
+    // lanes whose guess differs from the exit in front of them walk again from that exit
+    bool bad = false;
+    for (int round = 0; round < 3; ++round) {
+        const u32 prev = (u32)__shfl_up((int)exit_, 1, 64);
+        bad = lane > 0 && ent[0] != prev;
+        if (!__any(bad) || round == 2) break;
+        ScanOut o;
+        o.pack(ent, cnt);
+        if (FIX && last) scan_strip_gen<true, LONG, true>(tab, lt, KW, blk, wave_off, end_bits, prev, false, bad, o, exit_);
+        else scan_strip_gen<false, LONG, true>(tab, lt, KW, blk, wave_off, 0, prev, false, bad, o, exit_);
+        o.unpack(ent, cnt);
+    }
+    if (__any(bad)) {                                   // did not settle: the block takes the exact kernels
+        if (lane == 0) __hip_atomic_store(blk.run_dp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const u32 my_tile = wtile + lane / SC_STRIPS_TILE;
+    u32 mine = 0;
+#pragma unroll
+    for (int j = 0; j < SC_CH; ++j) mine += cnt[j];
+    const u32 incl = dpp_scan_add(mine);
+    const u32 half = (u32)__builtin_amdgcn_readlane((int)incl, 31);
+    if (my_tile < blk.n_tiles) {
+        const size_t c0 = gtw * DEC_THREADS + (size_t)lane * SC_CH;
+        gstore<uint2>(chunk_entry + c0, make_uint2(ent[0] | (ent[1] << 8) | (ent[2] << 16) | (ent[3] << 24),
+                                                   ent[4] | (ent[5] << 8) | (ent[6] << 16) | (ent[7] << 24)));
+        gstore<uint4>(chunk_cnt + c0, make_uint4(cnt[0] | (cnt[1] << 16), cnt[2] | (cnt[3] << 16), cnt[4] | (cnt[5] << 16),
+                                                 cnt[6] | (cnt[7] << 16)));
+    }
+    const bool two = wtile + 1 < blk.n_tiles;
+    if (lane == 0) tile_guess[gtw] = (u8)ent[0];
+    if (lane == 31) {
+        tile_cnt[gtw] = half;
+        if (two) { tile_exit[gtw] = 0; tile_guess[gtw + 1] = 0; }      // the link inside the unit was checked above
+    }
+    if (lane == 63) {
+        if (two) tile_cnt[gtw + 1] = incl - half;
+        tile_exit[gtw + (two ? 1 : 0)] = (u8)exit_;
+    }
+}
+
+// dynamic LDS: rows (SC_LDS_ROWS) | cnt3 + len0 (tab_bytes) | flags (SC_MISC) | long-code table (LONG)
+template <bool FIX, int LONG>
+__global__ __launch_bounds__(DEC_THREADS) __attribute__((amdgpu_waves_per_eu(FIX ? 1 : 8, 8))) void sfd_scan(const DecBlk *__restrict__ blks, u8 *__restrict__ chunk_entry,
+                                                        u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt,
+                                                        u8 *__restrict__ tile_guess, u8 *__restrict__ tile_exit,
+                                                        const u8 *__restrict__ tile_fix, u32 tab_bytes, u32 long_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const DecBlk blk = blks[blockIdx.y];
+    if (!blk.run_dp || __hip_atomic_load(blk.run_dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // exact path
+    if (lds_addr(smem) != 0) __builtin_trap();
+    const u32 wv = threadIdx.x >> 6;
+    const u32 t_lo = blockIdx.x * (FIX ? SC_FIX_REGIONS * SC_TILES : SC_TILES);
+    if (t_lo >= blk.n_tiles) return;
+    if (FIX) {                                          // repair launch: almost no workgroup has a marked unit
+        bool mine = false;
+        for (u32 t = t_lo + threadIdx.x; t < t_lo + SC_FIX_REGIONS * SC_TILES && t < blk.n_tiles; t += DEC_THREADS)
+            mine |= tile_fix[(size_t)blk.tile_base + t] != 0;
+        u32 turn = 0;
+        if (!wg_any(mine, (u32 *)(smem + SC_LDS_ROWS + tab_bytes), turn)) return;
+    }
+    fill_lds16((void *)(smem + SC_LDS_ROWS), (const void *)blk.cnt3, 2u << blk.KW);
+    if (LONG) {
+        u16 *lt = (u16 *)(smem + SC_LDS_ROWS + tab_bytes + SC_MISC);
+        const u16 *src = LONG == 1 ? blk.longtab : blk.long32;
+        if (src) fill_lds16((void *)lt, src, long_bytes);
+        else if (threadIdx.x == 0) *lt = 0;
+    }
+    lds_barrier();
+    for (u32 r = 0; r < (FIX ? (u32)SC_FIX_REGIONS : 1u); ++r) {
+        const u32 wtile = t_lo + r * SC_TILES + wv * SC_WTILES;
+        if (wtile >= blk.n_tiles) break;
+        if (FIX && tile_fix[(size_t)blk.tile_base + wtile] == 0) continue;      // (wave-uniform)
+        scan_unit<FIX, LONG>(smem, blk, wtile, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tab_bytes);
+    }
 }
 
 // sfd_write13: the symbol pass for incomplete codes of <= 13 bits (one code per look-up, direct stores; complete
@@ -2115,6 +2634,9 @@ void sfdec_configure(int speculate) { g_sfd_speculate = speculate; }
 // sfd_write) that otherwise serve codes of more than 32 bits
 static int g_sfd_path = 0;
 void sfdec_configure_path(int path) { g_sfd_path = path; }
+// "sf_decode_scan": 1 = the speculative entries by sfd_scan (strips of 256 bytes, a wave on its own), 0 = by sfd_spec
+static int g_sfd_scan = 1;
+void sfdec_configure_scan(int scan) { g_sfd_scan = scan; }
 
 // Does a decoder that starts 256 bits early agree with the true parse when it reaches the chunk?  Answered per table by
 // simulation on random bits (any bit string is a concatenation of code words of a complete code, distributed as the
@@ -2421,10 +2943,27 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
                 hipLaunchKernelGGL((sfd_spec<FIX, 0>), grid, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
                                    (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb, long_used);
         };
-        spec(std::false_type{}, grid_s);
+        const size_t lds_scan = (size_t)SC_LDS_ROWS + tabb + SC_MISC + (spec_long ? (size_t)long_used : 0);
+        const dim3 grid_c((u32)ceil_div_u64(max_tiles, SC_TILES), (u32)nblocks);
+        const dim3 grid_cf((u32)ceil_div_u64(max_tiles, SC_TILES * SC_FIX_REGIONS), (u32)nblocks);
+        auto scan = [&](auto fix, const dim3 grid) {
+            constexpr bool FIX = decltype(fix)::value;
+            if (spec_long == 2)
+                hipLaunchKernelGGL((sfd_scan<FIX, 2>), grid, dim3(DEC_THREADS), lds_scan, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
+                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb, long_used);
+            else if (spec_long == 1)
+                hipLaunchKernelGGL((sfd_scan<FIX, 1>), grid, dim3(DEC_THREADS), lds_scan, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
+                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb, long_used);
+            else
+                hipLaunchKernelGGL((sfd_scan<FIX, 0>), grid, dim3(DEC_THREADS), lds_scan, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
+                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb, long_used);
+        };
+        if (g_sfd_scan) scan(std::false_type{}, grid_c);
+        else spec(std::false_type{}, grid_s);
         for (int round = 0; round < 2; ++round) {
             hipLaunchKernelGGL(sfd_spec_check<false>, dim3((u32)nblocks, 4), dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
-            spec(std::true_type{}, grid_sf);
+            if (g_sfd_scan) scan(std::true_type{}, grid_cf);
+            else spec(std::true_type{}, grid_sf);
         }
         hipLaunchKernelGGL(sfd_spec_check<true>, dim3((u32)nblocks, 4), dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
     };
