@@ -245,10 +245,6 @@ int shafa_hip_set_option(const char *name, long value)
         rleenc_configure(value != 0);
         return SHAFA_SUCCESS;
     }
-    if (name && !strcmp(name, "sf_decode_scan")) {
-        sfdec_configure_scan(value != 0);
-        return SHAFA_SUCCESS;
-    }
     if (name && !strcmp(name, "sf_decode_speculate")) {
         sfdec_configure(value <= 0 ? 0 : value >= 2 ? 2 : 1);
         return SHAFA_SUCCESS;
@@ -469,7 +465,6 @@ int shafa_hip_init(int device)
     DeviceGuard dg(device);                      // the caller's current device is left as it was
     if (const char *e = getenv("SHAFA_SF_ENCODE_ONE_PASS_MIN_BLOCKS")) shafa_hip_set_option("sf_encode_one_pass_min_blocks", atol(e));
     if (const char *e = getenv("SHAFA_SF_DECODE_SPECULATE")) shafa_hip_set_option("sf_decode_speculate", atol(e));
-    if (const char *e = getenv("SHAFA_SF_DECODE_SCAN")) shafa_hip_set_option("sf_decode_scan", atol(e));
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     shafa_hipd_batch *bh = nullptr;
     int rc = shafa_hipd_batch_create(1, (size_t)1 << 27, &bh);

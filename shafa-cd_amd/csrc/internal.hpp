@@ -131,6 +131,5 @@ int rledec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
 void sfenc_configure(int sfe4_min_blocks);
 void sfdec_configure(int speculate);
 void sfdec_configure_path(int path);
-void sfdec_configure_scan(int scan);
 void rleenc_configure(int force_general);
 int gen_launch(hipStream_t st, u64 seed, u64 first, const u8 *d_map, u8 *d_out, size_t n);

@@ -69,7 +69,7 @@ struct DecBlk {
                            //   group (next nb bits index lut2[base..]) ; 0 = go to the trie
     const u16 *lut2;       // level 2 (codes of K+1 .. K+8 bits): sym | len << 8 ; 0 = go to the trie
     const u8 *lenlut;      // 2^K1 entries: len only (DP of the packed path); 0 = longer than K1 bits
-    u16 *cnt3;             // sfd_spec's tables, 2^spec_window(K1) bytes each: [total bits | codes << 4 of the whole codes in a
+    u16 *cnt3;             // sfd_scan's tables, 2^KW bytes each: [total bits | codes << 5 of the whole codes (at most 7) in a
                            // window] then [length of the window's first code]
     u32 *sym3;             // 2^K3 entries: sym0 | sym1 << 8 | sym2 << 16 | total bits << 24 (6 bits) | n << 30
     u8 *pairlut;           // 2^(K1+1) entries: (len(p)-1) | (len(p+1)-1) << 4 from a K1+1-bit window (complete codes)
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
     const u32 KW = blk.KW, maskw = (1u << KW) - 1;               // the counting window may be wider than the longest code, or
     for (u32 i = T0; i <= maskw; i += TS) {                      // one bit narrower than the 13-bit table (host: sfdec_launch)
         u32 pos = 0, n = 0, l0 = 0;
-        for (; n < 15; ++n) {
+        for (; n < 7; ++n) {
             const u32 wv = (i << pos) & maskw;                   // window shifted left, zero filled
             const u32 L = blk.lut13[KW >= K1 ? wv >> (KW - K1) : wv << (K1 - KW)] >> 8;
             if (L == 0 || L > KW - pos) break;                   // longer than the window / would use bits outside it
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
             pos += L;
         }
         const u32 j = __builtin_bitreverse32(i) >> (32 - KW);    // sfd_spec reads its windows LSB first
-        ((u8 *)blk.cnt3)[j] = (u8)(pos | (n << 4));
+        ((u8 *)blk.cnt3)[j] = (u8)(pos | (n << 5));              // bits in the low five: the sum of a fetch's entries is the next look-up's shift
         ((u8 *)blk.cnt3)[(1u << KW) + j] = (u8)l0;
     }
     for (u32 i = T0; i < (1u << K3); i += TS) {   // K3-bit window; n = 0: first code is longer
@@ -1174,311 +1174,23 @@ __global__ __launch_bounds__(DEC_THREADS * SUBS) __attribute__((amdgpu_waves_per
 // The packed DP above prices every bit position (6.7 VALU per bit) to be exact for ANY code.  Shannon-Fano codes of
 // skewed data re-synchronise: a decoder started at an arbitrary bit agrees with the true parse after a few dozen bits
 // (measured: started 256 bits early it is off at the chunk boundary in 0.2 % of the chunks of Zipf(1.2) mod 256 data,
-// 0.02 % for Zipf truncated to 256 ranks, 85 % for uniform bytes, whose 8/9-bit codes never merge).  So every lane
-// takes a strip of SPEC_STRIP chunks and
-//   1. walks the chunk BEFORE its strip from that chunk's first bit (three codes per look-up, cnt3), which leaves it at
-//      its guess of the strip's entry, then walks the strip, noting entry and code count of each chunk, to its exit;
+// 0.02 % for Zipf truncated to 256 ranks, 85 % for uniform bytes, whose 8/9-bit codes never merge).  So a lane
+//   1. walks the 256 bits in front of its strip from their first bit (three codes per look-up), which leaves it at its
+//      guess of the strip's entry, then walks the strip, noting entry and code count of each chunk, to its exit;
 //   2. compares its guess with the exit of the lane before it; lanes that differ take that exit as their entry and walk
-//      again until they are back on their earlier path (a few rounds: a repaired lane's exit almost never moves).
-// A workgroup covers SPEC_STRIP tiles; its first lane guesses from the last chunk of the previous tile;
-// sfd_spec_check compares every tile's guess with the previous tile's exit and sfd_spec<true> redoes the regions that
-// differ with the entry forced.  When every
-// comparison of a block holds — entry(c) == exit(c-1) for all chunks, entry 0 at the block's first bit — the entries
-// ARE the true parse, by induction: nothing is approximate.  A block that does not get there in the fixed number of
-// rounds sets *run_dp and goes through the exact kernels, which skip the blocks that verified; which blocks try at all
+//      again until they are back on their earlier path.
+// The first lane of a wave is compared with the wave before it by sfd_spec_check and redone with its entry forced.  When
+// every comparison of a block holds — entry(c) == exit(c-1) for all chunks, entry 0 at the block's first bit — the
+// entries ARE the true parse, by induction: nothing is approximate.  A block that does not get there in the fixed number
+// of rounds sets *run_dp and goes through the exact kernels, which skip the blocks that verified; which blocks try at all
 // is decided per table on the host (spec_worthwhile()).  Outputs are those of sfd_countfsm.
 // ================================================================================================
 typedef __attribute__((address_space(3))) u32 lds_u32;
 typedef __attribute__((address_space(3))) u16 lds_u16;
 typedef __attribute__((address_space(3))) u8 lds_u8;
-constexpr int SPEC_STRIP = 2;                      // chunks per lane: the 256-bit run-up is paid once per strip
-                                                   // (4: a fifth fewer steps, but twice the LDS per walk in flight: slower)
-constexpr int SPEC_TILES = SPEC_STRIP;             // a workgroup covers SPEC_STRIP tiles
-constexpr int SPEC_SW = 8 * SPEC_STRIP;            // stream words per strip
-constexpr int SPEC_ROW = SPEC_SW + 1;              // LDS words per strip: the strip, then a copy of the next strip's first word
-// LDS frame: strip 0 = the strip in front of the region (its last chunk is lane 0's run-up), strips 1..256 = the lanes';
-// neighbouring lanes are an odd number of words apart (no bank conflicts) and every walk sees its strip and one word
-// more as linear memory
-constexpr int SPEC_STRIPS = DEC_THREADS + 1;
-constexpr int SPEC_LDS_DATA = (SPEC_STRIPS * SPEC_ROW + 3) / 4 * 16;
-
-// The frame holds the stream LSB first (bit-reversed bytes): stream bit p of the frame is bit p & 31 of word p >> 5, so
-// the window at LDS bit address q is alignbit(W[(q>>5)+1], W[q>>5], q) & mask — no negation, no shift down to the
-// table index — and the tables are indexed by the window read that way (first stream bit = bit 0).
-// The two stream words a window needs are kept across steps: a walk moves ~8 bits a step, so a lane needs new words
-// only every fourth step, and an LDS read costs bank cycles per ACTIVE lane.
-struct SpecWin {
-    u32 lo, hi, wa;                                     // words at LDS address wa, wa + 4
-    __device__ __forceinline__ void init() { wa = 0xFFFFFFFFu; hi = lo = 0; }
-    __device__ __forceinline__ u32 at(u32 q)            // the 32 stream bits from LDS bit address q on
-    {
-        const u32 a = (q >> 3) & ~3u;
-        if (a != wa) {
-            const lds_u32 *pa = (const lds_u32 *)(size_t)a;
-            lo = pa[0];
-            hi = pa[1];
-            wa = a;
-        }
-        return __builtin_amdgcn_alignbit(hi, lo, q);
-    }
-};
-
-// one walk: from LDS bit address q (a code start, by assumption) to the first code start >= qe, counting the codes
-// started on the way.  tab: [total bits | codes << 4 of the whole codes in a K1-bit window] then [length of the window's
-// first code], 1 << K1 bytes each.
-// LAST: the stream ends at bit address `qlimit` (may lie in front of q); a code that does not end inside it is not a symbol.
-// LONG (1: codes of up to 16 bits, 2: up to 32): a window whose first code is longer than K1 bits has the entry 0; its
-// length comes from the table of long codes lt (long_code / long_code32) — rare by construction, a divergent branch.
-// entries / exits of a chunk are < 16 (< 32 for LONG == 2)
+// entries / exits of a chunk are < 16 (< 32 for LONG == 2: codes of up to 32 bits); the value itself marks "the stream
+// ended in front of this chunk"
 template <int LONG> constexpr u32 spec_emask() { return LONG == 2 ? 31u : 15u; }
-
-template <bool LAST, int LONG>
-__device__ __forceinline__ void spec_walk(const lds_u8 *tab, const u16 *lt, u32 K1, u32 &q, u32 qe, int qlimit, u32 &cnt, SpecWin &sw)
-{
-    const u32 mask = (1u << K1) - 1u;
-    auto long_len = [&](const u32 qq) -> u32 {          // the code of more than K1 bits at qq (at least 1: the walk must move)
-        const u32 win = __builtin_bitreverse32(sw.at(qq));
-        const u32 l = (LONG == 1 ? long_code(lt, win) : long_code32(lt, win)) >> 8;
-        return l ? l : 1u;
-    };
-    if (!LAST) {
-        const u32 q0 = q;
-        u32 acc = 0;                                    // sum of the entries = bits walked + 16 * codes: one add a step
-        // N look-ups per window fetch: the 32 bits fetched hold further windows behind the first one's codes
-        auto multi = [&](auto nlook) {
-            constexpr u32 N = decltype(nlook)::value;
-            const u32 qs = qe - N * K1;
-            while (q <= qs) {
-                const u32 w = sw.at(q);
-                u32 used = 0, e = 0;
-#pragma unroll
-                for (u32 i = 0; i < N; ++i) {
-                    e = tab[(w >> used) & mask];
-                    used += e & 15u;
-                    acc += e;
-                }
-                q += used;
-                if (LONG && __builtin_expect((e & 15u) == 0u, 0)) {      // a long code stopped the look-ups: it starts at q
-                    const u32 l = long_len(q);
-                    q += l;
-                    acc += l + 16u;
-                }
-            }
-        };
-        if (K1 <= 10) multi(std::integral_constant<u32, 3>{});
-        else multi(std::integral_constant<u32, 2>{});     // K1 <= 13: 26 bits
-        cnt += (acc - (q - q0)) >> 4;
-    }
-    const lds_u8 *len0 = tab + (1u << K1);
-    while (q < qe) {
-        u32 l0 = len0[sw.at(q) & mask];
-        if (LONG && __builtin_expect(l0 == 0u, 0)) l0 = long_len(q);
-        if (LAST && (int)(q + l0) > qlimit) { q = qe + spec_emask<LONG>(); break; }   // cut by the end of the stream: nothing starts after it
-        q += l0;
-        ++cnt;
-    }
-}
-
-// a strip (LDS bit address qrow) from entry `ent0` of its first chunk: entries and counts of its SPEC_STRIP chunks, exit
-// of the last one.  HAVE_OLD: ent[] holds the entries of an earlier walk of the same strip: once this walk meets it the
-// rest is unchanged.
-template <bool LAST, bool HAVE_OLD, int LONG>
-__device__ __forceinline__ void spec_strip(const lds_u8 *tab, const u16 *lt, u32 K1, u32 qrow, int qlimit, u32 ent0,
-                                           u32 (&ent)[SPEC_STRIP], u32 (&cnt)[SPEC_STRIP], u32 &exit_)
-{
-    u32 q = qrow + ent0;
-    SpecWin sw;
-    sw.init();
-#pragma unroll
-    for (int k = 0; k < SPEC_STRIP; ++k) {
-        const u32 r = q - (qrow + 256u * k);
-        if (HAVE_OLD && k > 0 && r == ent[k]) return;   // back on the earlier walk's path
-        ent[k] = r;
-        u32 c = 0;
-        spec_walk<LAST, LONG>(tab, lt, K1, q, qrow + 256u * (k + 1), qlimit, c, sw);
-        cnt[k] = c;
-    }
-    exit_ = (q - (qrow + 256u * SPEC_STRIP)) & spec_emask<LONG>();
-}
-
-// dynamic LDS: stream frame | cnt3 (2 << K1max bytes) | exits[256] | wsum[4] | flags[8] | long-code table (LONG)
-constexpr int SPEC_FIX_REGIONS = 32;               // regions a workgroup of a repair launch looks at (almost none needs work)
-
-template <bool FIX, int LONG>
-__device__ __forceinline__ void spec_region(u8 *smem, const DecBlk &blk, const u32 tile0, u8 *__restrict__ chunk_entry,
-                                            u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt,
-                                            u8 *__restrict__ tile_guess, u8 *__restrict__ tile_exit,
-                                            const u8 *__restrict__ tile_fix, u32 tab_bytes, u32 long_bytes)
-{
-    const size_t gt0 = (size_t)blk.tile_base + tile0;
-    const u32 ntl = blk.n_tiles - tile0 < (u32)SPEC_TILES ? blk.n_tiles - tile0 : (u32)SPEC_TILES;   // tiles of the region
-    u32 *data = (u32 *)smem;
-    const u32 tab_off = SPEC_LDS_DATA;
-    u8 *ex = smem + SPEC_LDS_DATA + tab_bytes;
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 K1 = blk.KW;                              // the counting table's window
-    fill_lds16((void *)(smem + tab_off), (const void *)blk.cnt3, 2u << K1);
-    const u16 *lt = (const u16 *)(smem + SPEC_LDS_DATA + tab_bytes + DEC_THREADS + 16 + 32);
-    if (LONG) {
-        const u16 *src = LONG == 1 ? blk.longtab : blk.long32;
-        if (src) fill_lds16((void *)lt, src, long_bytes);                                     // up to what the launch's blocks use, as sfd_wstage
-        else if (threadIdx.x == 0) *(u16 *)lt = 0;
-    }
-    {   // the region's stream from one strip before it, 16 bytes a lane; frame word f -> LDS word f + f / SPEC_SW.
-        // All of a lane's pieces are requested before the first is used (five loads in flight, not five round trips).
-        const long long base = (long long)tile0 * DTILE - 4 * SPEC_SW;
-        constexpr u32 UNITS = (u32)(SPEC_STRIPS * SPEC_SW / 4 + 1), NIT = (UNITS + DEC_THREADS - 1) / DEC_THREADS;
-        uint4 v[NIT];
-#pragma unroll
-        for (u32 it = 0; it < NIT; ++it) {
-            const u32 i = tid + it * DEC_THREADS;
-            const long long off = base + (long long)i * 16;
-            v[it] = make_uint4(0, 0, 0, 0);
-            if (i < UNITS && off >= 0 && (u64)off + 16 <= blk.in_n) v[it] = gload_nt<uint4>(blk.in + off);
-        }
-#pragma unroll
-        for (u32 it = 0; it < NIT; ++it) {
-            const u32 i = tid + it * DEC_THREADS;
-            if (i >= UNITS) break;
-            const long long off = base + (long long)i * 16;
-            u32 w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
-            if (off >= 0 && (u64)off < blk.in_n && (u64)off + 16 > blk.in_n) {      // the piece the stream ends in
-                const int nv = (int)(blk.in_n - (u64)off);
-#pragma unroll
-                for (int q = 0; q < 16; ++q)
-                    if (q < nv) w[q >> 2] |= (u32)gload<u8>(blk.in + off + q) << (8 * (q & 3));
-            }
-            const u32 f = 4 * i, at = f + f / SPEC_SW;
-            const u32 w0 = rev_bytes(w[0]);
-            if (f % SPEC_SW == 0 && f > 0) data[at - 1] = w0;       // the previous row's look-ahead word
-            if (i < UNITS - 1) {
-                data[at] = w0;
-                data[at + 1] = rev_bytes(w[1]);
-                data[at + 2] = rev_bytes(w[2]);
-                data[at + 3] = rev_bytes(w[3]);
-            }
-        }
-    }
-    __syncthreads();
-    // lane tid owns frame strip tid + 1; the stream ends at bit `limit` of that strip (<= 0: before it)
-    const u64 start = (u64)tile0 * DTILE;
-    const u64 left = blk.in_n > start ? blk.in_n - start : 0;
-    const u64 capb = (u64)SPEC_TILES * DTILE + 4;
-    const bool last = left < capb;                      // the stream ends inside this frame
-    const int limit = last ? (int)(left * 8) - (int)(256u * SPEC_STRIP * tid) : 0;
-    // LDS bit address of the strip's first bit; addresses are absolute (the segment's base folded into the constants)
-    const u32 qrow = 8u * (lds_addr(smem) + (4u * SPEC_ROW) * (tid + 1));
-    const int qlimit = (int)qrow + limit;
-    // the table's LDS address as a literal: the kernel has no static LDS, its dynamic segment starts at 0 (checked:
-    // the comparison folds at compile time), and a literal goes into the ds offset field where "smem + offset" leaves
-    // an add per look-up
-    if (lds_addr(smem) != 0) __builtin_trap();
-    const lds_u8 *tab = (const lds_u8 *)(size_t)tab_off;
-    u32 ent[SPEC_STRIP], cnt[SPEC_STRIP], exit_ = 0;
-    {
-        u32 e0;
-        const bool exact0 = tile0 == 0 && tid == 0;     // the block's first bit: entry 0, no guess
-        const bool forced = FIX && tid == 0 && tile0 > 0 && tile_fix[gt0] != 0;
-        if (exact0) e0 = 0;
-        else if (forced) e0 = (u32)tile_exit[gt0 - 1];
-        else {                                          // run-up: the last chunk of the strip in front, from its first bit
-            const u32 qprow = qrow - 8u * (4u * SPEC_ROW), qe = qprow + 256u * SPEC_STRIP;
-            u32 q = qe - 256u, dummy = 0;
-            SpecWin sw;
-            sw.init();
-            if (last) spec_walk<true, LONG>(tab, lt, K1, q, qe, qlimit, dummy, sw);
-            else spec_walk<false, LONG>(tab, lt, K1, q, qe, 0, dummy, sw);
-            e0 = (q - qe) & spec_emask<LONG>();
-        }
-        if (last) spec_strip<true, false, LONG>(tab, lt, K1, qrow, qlimit, e0, ent, cnt, exit_);
-        else spec_strip<false, false, LONG>(tab, lt, K1, qrow, qlimit, e0, ent, cnt, exit_);
-    }
-    ex[tid] = (u8)exit_;
-    __syncthreads();
-    // strips whose guess differs from the exit in front of them walk again from that exit, until the walk meets the old one
-    bool bad = false;
-    u32 *const wsum = (u32 *)(ex + DEC_THREADS), *const flags = wsum + 4;
-    u32 turn = 0;
-    for (int round = 0; round < 4; ++round) {
-        bad = tid > 0 && ent[0] != (u32)ex[tid - 1];
-        if (!wg_any(bad, flags, turn)) break;
-        if (bad) {
-            const u32 e0 = ex[tid - 1];
-            if (last) spec_strip<true, true, LONG>(tab, lt, K1, qrow, qlimit, e0, ent, cnt, exit_);
-            else spec_strip<false, true, LONG>(tab, lt, K1, qrow, qlimit, e0, ent, cnt, exit_);
-        }
-        __syncthreads();                                // every lane has read the exit in front of it
-        ex[tid] = (u8)exit_;
-        __syncthreads();
-        bad = tid > 0 && ent[0] != (u32)ex[tid - 1];
-    }
-    if (wg_any(bad, flags, turn)) {                     // did not settle: the block takes the exact kernels
-        if (tid == 0) __hip_atomic_store(blk.run_dp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // chunk tid * SPEC_STRIP + k of the region; a tile is 256 / SPEC_STRIP consecutive lanes
-    const u32 my_tile = tid * SPEC_STRIP / DEC_THREADS;
-    u32 mine = 0;
-#pragma unroll
-    for (int k = 0; k < SPEC_STRIP; ++k) mine += cnt[k];
-    const u32 wtot = dpp_scan_add(mine);                // lane 63: the wave's codes
-    if (lane == 63) wsum[wv] = wtot;
-    __syncthreads();
-    if (my_tile < ntl) {
-        const size_t c0 = gt0 * DEC_THREADS + (size_t)tid * SPEC_STRIP;
-        if (SPEC_STRIP == 4) {
-            gstore<u32>(chunk_entry + c0, (ent[0] & 0xFFu) | ((ent[1 % SPEC_STRIP] & 0xFFu) << 8) |
-                                              ((ent[2 % SPEC_STRIP] & 0xFFu) << 16) | (ent[3 % SPEC_STRIP] << 24));
-            gstore<uint2>(chunk_cnt + c0, make_uint2(cnt[0] | (cnt[1 % SPEC_STRIP] << 16), cnt[2 % SPEC_STRIP] | (cnt[3 % SPEC_STRIP] << 16)));
-        } else if (SPEC_STRIP == 2) {
-            gstore<u16>(chunk_entry + c0, (u16)((ent[0] & 0xFFu) | (ent[1 % SPEC_STRIP] << 8)));
-            gstore<u32>(chunk_cnt + c0, cnt[0] | (cnt[1 % SPEC_STRIP] << 16));
-        } else {
-            for (int k = 0; k < SPEC_STRIP; ++k) { chunk_entry[c0 + k] = (u8)ent[k]; chunk_cnt[c0 + k] = (u16)cnt[k]; }
-        }
-        constexpr u32 LPT = DEC_THREADS / SPEC_STRIP;   // lanes per tile
-        constexpr u32 WPT = LPT / 64;                   // waves per tile
-        const u32 in_tile = tid % LPT;
-        if (in_tile == 0) {
-            u32 tot = 0;
-            for (u32 w = 0; w < WPT; ++w) tot += wsum[my_tile * WPT + w];
-            tile_cnt[gt0 + my_tile] = tot;
-            tile_guess[gt0 + my_tile] = (u8)ent[0];
-        }
-        if (in_tile == LPT - 1) tile_exit[gt0 + my_tile] = (u8)exit_;
-    }
-}
-
-template <bool FIX, int LONG>
-__global__ __launch_bounds__(DEC_THREADS) void sfd_spec(const DecBlk *__restrict__ blks, u8 *__restrict__ chunk_entry,
-                                                        u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt,
-                                                        u8 *__restrict__ tile_guess, u8 *__restrict__ tile_exit,
-                                                        const u8 *__restrict__ tile_fix, u32 tab_bytes, u32 long_bytes)
-{
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const DecBlk blk = blks[blockIdx.y];
-    if (!blk.run_dp || __hip_atomic_load(blk.run_dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // exact path
-    if (!FIX) {
-        const u32 tile0 = blockIdx.x * SPEC_TILES;      // first tile of this workgroup's region
-        if (tile0 < blk.n_tiles) spec_region<false, LONG>(smem, blk, tile0, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tile_fix, tab_bytes, long_bytes);
-        return;
-    }
-    // repair launch: a workgroup looks at the flags of SPEC_FIX_REGIONS regions and redoes the few that are marked
-    const u32 t_lo = blockIdx.x * (SPEC_FIX_REGIONS * SPEC_TILES);
-    if (t_lo >= blk.n_tiles) return;
-    const u32 t = t_lo + threadIdx.x;
-    const bool mine = threadIdx.x < SPEC_FIX_REGIONS * SPEC_TILES && t < blk.n_tiles && tile_fix[(size_t)blk.tile_base + t] != 0;
-    u32 turn = 0;
-    if (!wg_any(mine, (u32 *)(smem + SPEC_LDS_DATA + tab_bytes + DEC_THREADS + 16), turn)) return;
-    for (u32 r = 0; r < SPEC_FIX_REGIONS; ++r) {
-        const u32 tile0 = t_lo + r * SPEC_TILES;
-        if (tile0 >= blk.n_tiles) break;
-        bool any = false;
-        for (u32 q = 0; q < SPEC_TILES && tile0 + q < blk.n_tiles; ++q) any |= tile_fix[(size_t)blk.tile_base + tile0 + q] != 0;
-        if (!any) continue;                             // uniform
-        __syncthreads();                                // the region before is done with the LDS
-        spec_region<true, LONG>(smem, blk, tile0, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tile_fix, tab_bytes, long_bytes);
-    }
-}
 
 // per block: tiles whose first lane's guess differs from the previous tile's exit get tile_fix = 1 (redone by
 // sfd_spec<true>); FINAL: any difference left sends the block to the exact kernels
@@ -1500,12 +1212,10 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_spec_check(const DecBlk *__re
 }
 
 // ================================================================================================
-// sfd_scan: the speculative entries again, built for the way gfx950's LDS and vector ALUs price the walk
-// (DESIGN.md §3.2).  Same contract and same outputs as sfd_spec (entry and code count of every 256-bit chunk, tile
-// counts, a guess / exit pair per unit for sfd_spec_check), different shape:
+// sfd_scan: the speculative entries, shaped for the way gfx950's LDS and vector ALUs price the walk.
+// Outputs: entry and code count of every 256-bit chunk, tile counts, a guess / exit pair per unit for sfd_spec_check.
 //   * a lane owns a STRIP of SC_SB = 256 bytes (8 chunks) and walks it front to back with its exact position carried
-//     from chunk to chunk, so only the strip's first entry is a guess: the 256-bit run-up is paid once per 2048 bits
-//     (sfd_spec: once per 512);
+//     from chunk to chunk, so only the strip's first entry is a guess: the 256-bit run-up is paid once per 2048 bits;
 //   * the strip passes through LDS one 64-byte PHASE at a time (17 words per lane, as before), each lane's words in
 //     its own COLUMN (word i of lane c at dword i * 256 + c): a lane only ever reads bank c % 32, so the stream
 //     reads are conflict free whatever word each lane is at (rows 17 words apart met on a bank whenever two lanes 2,
@@ -1562,38 +1272,39 @@ __device__ __forceinline__ u32 scan_long_len(const u16 *lt, ScanWin &sw, const u
     return l ? l : 1u;                                  // at least 1: the walk must move
 }
 
-// whole fetches (two or three look-ups of up to three codes each) from row bit q while every code taken ends by `qe`
-// and the fetch (and a long code's window behind it) stays inside the row; counts the codes started on the way
+// whole fetches (two or three look-ups of up to seven codes each) from row bit q while every code taken ends by `qe`
+// and the fetch (and a long code's window behind it) stays inside the row; counts the codes started on the way.
+// An entry is bits | codes << 5 and a fetch uses at most 30 bits, so the running sum of a fetch's entries has the bits used
+// so far in its low five bits — exactly what v_bfe_u32 takes as its shift: one v_bfe per window, one add per look-up.
 template <int LONG>
 __device__ __forceinline__ void scan_multi(const lds_u8 *tab, const u16 *lt, const u32 KW, u32 &q, const u32 qe, u32 &cnt, ScanWin &sw)
 {
-    const u32 mask = (1u << KW) - 1u;
     const u32 q0 = q;
-    u32 acc = 0;                                        // sum of the entries = bits walked + 16 * codes
+    u32 acc = 0;                                        // sum of the entries = bits walked + 32 * codes
     auto multi = [&](auto nlook) {
         constexpr u32 N = decltype(nlook)::value;
         const u32 in_row = 32u * SC_PHW - 1u - (LONG ? (N - 1u) * KW : 0u);
         const u32 qs = qe - N * KW < in_row ? qe - N * KW : in_row;
         while (q <= qs) {
             const u32 w = sw.at(q);
-            u32 used = 0, e = 0;
+            u32 sum = 0, e = 0;
 #pragma unroll
             for (u32 i = 0; i < N; ++i) {
-                e = tab[(w >> used) & mask];
-                used += e & 15u;
-                acc += e;
+                e = tab[__builtin_amdgcn_ubfe(w, sum, KW)];
+                sum += e;
             }
-            q += used;
-            if (LONG && __builtin_expect((e & 15u) == 0u, 0)) {      // a long code stopped the look-ups: it starts at q
+            acc += sum;
+            q += sum & 31u;
+            if (LONG && __builtin_expect((e & 31u) == 0u, 0)) {      // a long code stopped the look-ups: it starts at q
                 const u32 l = scan_long_len<LONG>(lt, sw, q);
                 q += l;
-                acc += l + 16u;
+                acc += l + 32u;
             }
         }
     };
     if (KW <= 10) multi(std::integral_constant<u32, 3>{});
     else multi(std::integral_constant<u32, 2>{});
-    cnt += (acc - (q - q0)) >> 4;
+    cnt += (acc - (q - q0)) >> 5;
 }
 
 // single codes from row bit q to the first code start >= qe.  LAST: the stream ends at row bit `qlimit` (may lie in
@@ -1742,12 +1453,45 @@ struct ScanIO {
     }
 };
 
+// entries (a byte each) and counts (16 bits each) of a strip's eight chunks, packed as they are stored
+struct ScanOut {
+    u32 e[2], c[4];
+    __device__ __forceinline__ void clear() { e[0] = e[1] = 0; c[0] = c[1] = c[2] = c[3] = 0; }
+    // compile-time index, fields still zero: one v_lshl_or each
+    template <int J> __device__ __forceinline__ void put_ent(const u32 v) { e[J >> 2] |= v << (8 * (J & 3)); }
+    template <int J> __device__ __forceinline__ void put_cnt(const u32 v) { c[J >> 1] |= v << (16 * (J & 1)); }
+    // run-time index (the rolled walk below)
+    __device__ __forceinline__ u32 ent(const u32 j) const { return ((j < 4 ? e[0] : e[1]) >> (8u * (j & 3u))) & 0xFFu; }
+    __device__ __forceinline__ void set_ent(const u32 j, const u32 v)
+    {
+        const u32 sh = 8u * (j & 3u), m = ~(0xFFu << sh), x = v << sh;
+        if (j < 4) e[0] = (e[0] & m) | x; else e[1] = (e[1] & m) | x;
+    }
+    __device__ __forceinline__ void set_cnt(const u32 j, const u32 v)
+    {
+        const u32 sh = 16u * (j & 1u), m = ~(0xFFFFu << sh), x = v << sh, i = j >> 1;
+        c[0] = i == 0 ? (c[0] & m) | x : c[0];
+        c[1] = i == 1 ? (c[1] & m) | x : c[1];
+        c[2] = i == 2 ? (c[2] & m) | x : c[2];
+        c[3] = i == 3 ? (c[3] & m) | x : c[3];
+    }
+    __device__ __forceinline__ u32 total() const
+    {
+        u32 t = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t += (c[i] & 0xFFFFu) + (c[i] >> 16);
+        return t;
+    }
+};
+static_assert(SC_CH == 8, "ScanOut packs eight chunks");
+
 // The walk of a wave whose strips lie inside the stream with room to spare (all but a block's last wave): no bounds, no
 // stream end, every lane walks; the phases unrolled, entries and counts in registers.
 template <int LONG>
 __device__ __forceinline__ void scan_strip_fast(const lds_u8 *tab, const u16 *lt, const u32 KW, const DecBlk &blk, const u64 wave_off,
-                                                const u32 e_forced, const bool forced, u32 (&ent)[SC_CH], u32 (&cnt)[SC_CH], u32 &exit_)
+                                                const u32 e_forced, const bool forced, ScanOut &o, u32 &exit_)
 {
+    o.clear();
     ScanIO io;
     io.init(blk, wave_off);
     ScanWin sw;
@@ -1768,58 +1512,38 @@ __device__ __forceinline__ void scan_strip_fast(const lds_u8 *tab, const u16 *lt
     q = 32u * 9u;
     to_row_end();
     q -= 32u * SC_PHW;
-#pragma unroll
-    for (int k = 0; k < SC_M; ++k) {
+    auto phase = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
         io.put_phase(R);
         sw.flush();
         if (k + 1 < SC_M) io.load_phase<false>(k + 1, R);
         // 1. finish the chunk in progress: its count, and the entry of chunk 2 k
         scan_single<false, LONG>(tab, lt, KW, q, 32u, 0, pc, sw);
-        if (k > 0) cnt[2 * k - 1] = pc;
+        if (k > 0) o.put_cnt<(k > 0 ? 2 * k - 1 : 0)>(pc);
         if (k == 0 && forced) q = 32u + e_forced;
-        ent[2 * k] = q - 32u;
+        o.put_ent<2 * k>(q - 32u);
         // 2. chunk 2 k
         u32 c = 0;
         scan_multi<LONG>(tab, lt, KW, q, 288u, c, sw);
         scan_single<false, LONG>(tab, lt, KW, q, 288u, 0, c, sw);
-        cnt[2 * k] = c;
-        ent[2 * k + 1] = q - 288u;
+        o.put_cnt<2 * k>(c);
+        o.put_ent<2 * k + 1>(q - 288u);
         // 3. chunk 2 k + 1 as far as the row reaches
         pc = 0;
         to_row_end();
         q -= 32u * SC_PHW;
-    }
+    };
+    phase(std::integral_constant<int, 0>{});
+    phase(std::integral_constant<int, 1>{});
+    phase(std::integral_constant<int, 2>{});
+    phase(std::integral_constant<int, 3>{});
+    static_assert(SC_M == 4, "four phases written out");
     io.put_next_strip<false>(wave_off);
     sw.flush();
     scan_single<false, LONG>(tab, lt, KW, q, 32u, 0, pc, sw);
-    cnt[SC_CH - 1] = pc;
+    o.put_cnt<SC_CH - 1>(pc);
     exit_ = (q - 32u) & spec_emask<LONG>();
 }
-
-// entries and counts of a strip's chunks packed for access by a run-time index (the rolled walk below)
-struct ScanOut {
-    u64 e, c[2];
-    __device__ __forceinline__ u32 ent(const u32 j) const { return (u32)(e >> (8u * j)) & 0xFFu; }
-    __device__ __forceinline__ void set_ent(const u32 j, const u32 v) { e = (e & ~(0xFFull << (8u * j))) | ((u64)v << (8u * j)); }
-    __device__ __forceinline__ void set_cnt(const u32 j, const u32 v)
-    {
-        const u32 sh = 16u * (j & 3u);
-        const u64 m = ~(0xFFFFull << sh), x = (u64)v << sh;
-        if (j < 4) c[0] = (c[0] & m) | x; else c[1] = (c[1] & m) | x;
-    }
-    __device__ __forceinline__ void pack(const u32 (&en)[SC_CH], const u32 (&cn)[SC_CH])
-    {
-        e = 0; c[0] = c[1] = 0;
-#pragma unroll
-        for (int j = 0; j < SC_CH; ++j) { e |= (u64)en[j] << (8 * j); c[j >> 2] |= (u64)cn[j] << (16 * (j & 3)); }
-    }
-    __device__ __forceinline__ void unpack(u32 (&en)[SC_CH], u32 (&cn)[SC_CH]) const
-    {
-#pragma unroll
-        for (int j = 0; j < SC_CH; ++j) { en[j] = (u32)(e >> (8 * j)) & 0xFFu; cn[j] = (u32)(c[j >> 2] >> (16 * (j & 3))) & 0xFFFFu; }
-    }
-};
-static_assert(SC_CH == 8, "ScanOut packs eight chunks");
 
 // The same walk for the rare cases, phases rolled (a few of them per launch: registers matter, speed does not):
 // LAST: the stream ends inside (or in front of) the wave's strips, at `end_bits` relative to the lane's strip (any sign);
@@ -1924,7 +1648,8 @@ __device__ __forceinline__ void scan_unit(u8 *smem, const DecBlk &blk, const u32
     const bool exact0 = wtile == 0 && lane == 0;        // the block's first bit: entry 0, no guess
     const bool forced = exact0 || (FIX && lane == 0);
     const u32 e_forced = exact0 ? 0u : (FIX && lane == 0) ? (u32)tile_exit[gtw - 1] : 0u;
-    u32 ent[SC_CH], cnt[SC_CH], exit_ = 0;
+    ScanOut o;
+    u32 exit_ = 0;
     if (!FIX) {
         if (last) {                                     // (uniform) the block's last wave is left to the repair launch: a guess
             if (lane == 0) {                            // that no exit equals marks it (sfd_spec_check)
@@ -1933,44 +1658,34 @@ __device__ __forceinline__ void scan_unit(u8 *smem, const DecBlk &blk, const u32
             }
             return;
         }
-        scan_strip_fast<LONG>(tab, lt, KW, blk, wave_off, e_forced, forced, ent, cnt, exit_);
+        scan_strip_fast<LONG>(tab, lt, KW, blk, wave_off, e_forced, forced, o, exit_);
     } else {
-        ScanOut o;
-        o.e = 0; o.c[0] = o.c[1] = 0;
+        o.clear();
         if (last) scan_strip_gen<true, LONG, false>(tab, lt, KW, blk, wave_off, end_bits, e_forced, forced, true, o, exit_);
         else scan_strip_gen<false, LONG, false>(tab, lt, KW, blk, wave_off, 0, e_forced, forced, true, o, exit_);
-        o.unpack(ent, cnt);
     }
     // lanes whose guess differs from the exit in front of them walk again from that exit
     bool bad = false;
     for (int round = 0; round < 3; ++round) {
         const u32 prev = (u32)__shfl_up((int)exit_, 1, 64);
-        bad = lane > 0 && ent[0] != prev;
+        bad = lane > 0 && (o.e[0] & 0xFFu) != prev;
         if (!__any(bad) || round == 2) break;
-        ScanOut o;
-        o.pack(ent, cnt);
         if (FIX && last) scan_strip_gen<true, LONG, true>(tab, lt, KW, blk, wave_off, end_bits, prev, false, bad, o, exit_);
         else scan_strip_gen<false, LONG, true>(tab, lt, KW, blk, wave_off, 0, prev, false, bad, o, exit_);
-        o.unpack(ent, cnt);
     }
     if (__any(bad)) {                                   // did not settle: the block takes the exact kernels
         if (lane == 0) __hip_atomic_store(blk.run_dp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const u32 my_tile = wtile + lane / SC_STRIPS_TILE;
-    u32 mine = 0;
-#pragma unroll
-    for (int j = 0; j < SC_CH; ++j) mine += cnt[j];
-    const u32 incl = dpp_scan_add(mine);
+    const u32 incl = dpp_scan_add(o.total());
     const u32 half = (u32)__builtin_amdgcn_readlane((int)incl, 31);
     if (my_tile < blk.n_tiles) {
         const size_t c0 = gtw * DEC_THREADS + (size_t)lane * SC_CH;
-        gstore<uint2>(chunk_entry + c0, make_uint2(ent[0] | (ent[1] << 8) | (ent[2] << 16) | (ent[3] << 24),
-                                                   ent[4] | (ent[5] << 8) | (ent[6] << 16) | (ent[7] << 24)));
-        gstore<uint4>(chunk_cnt + c0, make_uint4(cnt[0] | (cnt[1] << 16), cnt[2] | (cnt[3] << 16), cnt[4] | (cnt[5] << 16),
-                                                 cnt[6] | (cnt[7] << 16)));
+        gstore<uint2>(chunk_entry + c0, make_uint2(o.e[0], o.e[1]));
+        gstore<uint4>(chunk_cnt + c0, make_uint4(o.c[0], o.c[1], o.c[2], o.c[3]));
     }
     const bool two = wtile + 1 < blk.n_tiles;
-    if (lane == 0) tile_guess[gtw] = (u8)ent[0];
+    if (lane == 0) tile_guess[gtw] = (u8)(o.e[0] & 0xFFu);
     if (lane == 31) {
         tile_cnt[gtw] = half;
         if (two) { tile_exit[gtw] = 0; tile_guess[gtw + 1] = 0; }      // the link inside the unit was checked above
@@ -2634,9 +2349,6 @@ void sfdec_configure(int speculate) { g_sfd_speculate = speculate; }
 // sfd_write) that otherwise serve codes of more than 32 bits
 static int g_sfd_path = 0;
 void sfdec_configure_path(int path) { g_sfd_path = path; }
-// "sf_decode_scan": 1 = the speculative entries by sfd_scan (strips of 256 bytes, a wave on its own), 0 = by sfd_spec
-static int g_sfd_scan = 1;
-void sfdec_configure_scan(int scan) { g_sfd_scan = scan; }
 
 // Does a decoder that starts 256 bits early agree with the true parse when it reaches the chunk?  Answered per table by
 // simulation on random bits (any bit string is a concatenation of code words of a complete code, distributed as the
@@ -2927,22 +2639,6 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         u32 k1_max = 1;
         for (int b = 0; b < nblocks; ++b) if (spec_blk[b] && hblk_kw[b] > k1_max) k1_max = hblk_kw[b];
         const u32 tabb = 2u << k1_max;
-        const size_t lds_spec = (size_t)SPEC_LDS_DATA + tabb + DEC_THREADS + 16 + 32 +
-                                (spec_long ? (size_t)long_used : 0);
-        const dim3 grid_s((u32)ceil_div_u64(max_tiles, SPEC_TILES), (u32)nblocks);
-        const dim3 grid_sf((u32)ceil_div_u64(max_tiles, SPEC_TILES * SPEC_FIX_REGIONS), (u32)nblocks);
-        auto spec = [&](auto fix, const dim3 grid) {
-            constexpr bool FIX = decltype(fix)::value;
-            if (spec_long == 2)
-                hipLaunchKernelGGL((sfd_spec<FIX, 2>), grid, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
-                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb, long_used);
-            else if (spec_long == 1)
-                hipLaunchKernelGGL((sfd_spec<FIX, 1>), grid, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
-                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb, long_used);
-            else
-                hipLaunchKernelGGL((sfd_spec<FIX, 0>), grid, dim3(DEC_THREADS), lds_spec, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
-                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb, long_used);
-        };
         const size_t lds_scan = (size_t)SC_LDS_ROWS + tabb + SC_MISC + (spec_long ? (size_t)long_used : 0);
         const dim3 grid_c((u32)ceil_div_u64(max_tiles, SC_TILES), (u32)nblocks);
         const dim3 grid_cf((u32)ceil_div_u64(max_tiles, SC_TILES * SC_FIX_REGIONS), (u32)nblocks);
@@ -2958,12 +2654,10 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
                 hipLaunchKernelGGL((sfd_scan<FIX, 0>), grid, dim3(DEC_THREADS), lds_scan, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
                                    (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb, long_used);
         };
-        if (g_sfd_scan) scan(std::false_type{}, grid_c);
-        else spec(std::false_type{}, grid_s);
+        scan(std::false_type{}, grid_c);
         for (int round = 0; round < 2; ++round) {
             hipLaunchKernelGGL(sfd_spec_check<false>, dim3((u32)nblocks, 4), dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
-            if (g_sfd_scan) scan(std::true_type{}, grid_cf);
-            else spec(std::true_type{}, grid_sf);
+            scan(std::true_type{}, grid_cf);
         }
         hipLaunchKernelGGL(sfd_spec_check<true>, dim3((u32)nblocks, 4), dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
     };
