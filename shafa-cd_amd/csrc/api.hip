@@ -32,8 +32,13 @@ int batch_enter(Batch *b, hipStream_t st)
         snprintf(g_last_error, sizeof(g_last_error), "batch of device %d used while device %d is current", b->device, dev);
         return SHAFA_DEVICE_ERROR;
     }
-    if (b->has_last && b->last_st != st && hipStreamSynchronize(b->last_st) != hipSuccess)
-        (void)hipGetLastError();           // the previous stream was destroyed by its owner (legal once its work is done): nothing to wait for
+    if (b->has_last && b->last_st != st) {
+        const hipError_t e = hipStreamSynchronize(b->last_st);
+        if (e == hipErrorInvalidHandle || e == hipErrorInvalidResourceHandle || e == hipErrorContextIsDestroyed)
+            (void)hipGetLastError();       // the previous stream was destroyed by its owner (legal once its work is done): nothing to wait for
+        else if (e != hipSuccess)          // a kernel or copy on it failed: the workspace and the error words cannot be trusted
+            return shafa_set_hip_error(e, "hipStreamSynchronize(previous stream of the batch)");
+    }
     b->last_st = st;
     b->has_last = true;
     return SHAFA_SUCCESS;
@@ -381,18 +386,32 @@ int shafa_hipd_rle_decode(shafa_hipd_batch *b, void *stream, int nblocks, const 
                          h_out_cap, d_out_n);
 }
 
-int shafa_hipd_finish(shafa_hipd_batch *hb, void *stream, int nblocks, int *h_block_err)
+}  // extern "C"
+
+// the call itself (not a block) failed: no block has a result — every block reports the call's code
+static int finish_failed(Batch *b, int nblocks, int *h_block_err, int rc)
 {
-    Batch *b = (Batch *)hb;
-    hipStream_t st = (hipStream_t)stream;
-    if (int rc = batch_enter(b, st)) return rc;
+    for (int i = 0; b && i < nblocks && i < b->max_blocks; ++i) {
+        if (h_block_err) h_block_err[i] = rc;
+        b->h_hosterr[i] = 0;
+    }
+    return rc;
+}
+
+int batch_finish(Batch *b, hipStream_t st, int nblocks, int *h_block_err, bool *call_failed)
+{
+    if (call_failed) *call_failed = true;
+    if (int rc = batch_enter(b, st)) return finish_failed(b, nblocks, h_block_err, rc);
     if (nblocks > b->max_blocks) nblocks = b->max_blocks;
     if (nblocks < 0) nblocks = 0;
+    hipError_t e = hipSuccess;
     if (nblocks) {
-        HIP_TRY(hipMemcpyAsync(b->h_err, b->d_err, (size_t)nblocks * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemsetAsync(b->d_err, 0, (size_t)nblocks * sizeof(int), st));
+        e = hipMemcpyAsync(b->h_err, b->d_err, (size_t)nblocks * sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemsetAsync(b->d_err, 0, (size_t)nblocks * sizeof(int), st);
     }
-    HIP_TRY(hipStreamSynchronize(st));
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return finish_failed(b, nblocks, h_block_err, shafa_set_hip_error(e, "shafa_hipd_finish"));
+    if (call_failed) *call_failed = false;
     batch_stage_retire(b, st);
     if (b->copy_st) batch_stage_retire(b, b->copy_st);  // `st` waited for every parameter copy: they are through as well
     int first = SHAFA_SUCCESS;
@@ -405,6 +424,13 @@ int shafa_hipd_finish(shafa_hipd_batch *hb, void *stream, int nblocks, int *h_bl
     if (first == SHAFA_DEVICE_ERROR)
         snprintf(g_last_error, sizeof(g_last_error), "kernel reported a lost predecessor tile (spin bound hit)");
     return first;
+}
+
+extern "C" {
+
+int shafa_hipd_finish(shafa_hipd_batch *hb, void *stream, int nblocks, int *h_block_err)
+{
+    return batch_finish((Batch *)hb, (hipStream_t)stream, nblocks, h_block_err, nullptr);
 }
 
 int shafa_hipd_gen_bytes(void *stream, uint64_t seed, uint64_t first_index, const uint8_t *d_map65536,

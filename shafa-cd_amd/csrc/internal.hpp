@@ -53,6 +53,9 @@ struct Batch {
 // serialises a change of stream (the workspace, the error words and the staging ring are shared by all launches of
 // a batch, so work enqueued on another stream must have finished before the new stream's launch reuses them).
 int batch_enter(Batch *b, hipStream_t st);
+// shafa_hipd_finish, telling a failure of the call (stream / copy error: no block has a result, every block_err = the code)
+// from the first block's error
+int batch_finish(Batch *b, hipStream_t st, int nblocks, int *h_block_err, bool *call_failed);
 
 // RAII: make `device` current for the calling thread, restore the caller's device on exit (a torch caller, or layer 1
 // next to a multi-device pipe, must not see its current device change under it)
@@ -86,6 +89,18 @@ u8 *batch_params_begin(Batch *b, size_t bytes);
 int batch_upload(Batch *b, hipStream_t st, void *dst, const void *src, size_t bytes);
 int batch_params_commit(Batch *b, hipStream_t st, const void *hs, size_t bytes);
 int batch_params_done(Batch *b, hipStream_t st);
+// A launcher's early `return rc` after batch_params_begin must still mark the buffer's last reader: kernels already enqueued
+// may be reading it, and the next launch that gets this buffer waits on par_free before it overwrites it.
+struct ParamsScope {
+    Batch *b;
+    hipStream_t st;
+    bool open;
+    ParamsScope(Batch *b_, hipStream_t st_) : b(b_), st(st_), open(true) {}
+    ~ParamsScope() { if (open) (void)batch_params_done(b, st); }
+    int done() { open = false; return batch_params_done(b, st); }
+    ParamsScope(const ParamsScope &) = delete;
+    ParamsScope &operator=(const ParamsScope &) = delete;
+};
 
 // ---- per-op parameter records (device arrays) --------------------------------------------------
 struct EncBlk {

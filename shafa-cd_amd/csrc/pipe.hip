@@ -235,18 +235,28 @@ int slot_submit_group(Slot &s, int n, const shafa_pipe_block *blk)
     size_t total_in = 0, max_cap = 0, max_sym = 0;
     for (int i = 0; i < n; ++i) {
         if (blk[i].in_off & 15) return SHAFA_OUTSIDE_MODULE;
+        size_t in_end = 0;
+        if (__builtin_add_overflow(blk[i].in_off, blk[i].in_n, &in_end) || in_end > s.h_in_cap) return SHAFA_OUTSIDE_MODULE;
         s.g_in_off[i] = blk[i].in_off;
         s.g_in_n[i] = blk[i].in_n;
-        s.g_nsym[i] = blk[i].n_symbols;
-        if (blk[i].in_off + blk[i].in_n > total_in) total_in = blk[i].in_off + blk[i].in_n;
+        if (in_end > total_in) total_in = in_end;
+        // n_symbols comes from a file's text.  A code has at least one bit, so a stream of in_n bytes holds at most 8 in_n
+        // symbols: rows are sized for that at most (a block that announces more ends as "stream too short", the kernels
+        // write only symbols they counted), and no product below can wrap
+        const size_t sym_most = blk[i].in_n <= (SIZE_MAX >> 4) ? 8 * blk[i].in_n + 1 : SIZE_MAX >> 1;      // + 1: still "too short"
+        const size_t nsym = blk[i].n_symbols < sym_most ? blk[i].n_symbols : sym_most;
+        s.g_nsym[i] = nsym;
         size_t cap = 0;
         switch (s.op) {
-        case SHAFA_OP_RLE_ENCODE: cap = 2 * blk[i].in_n + 3; break;                                   // f.c:244 worst case
+        case SHAFA_OP_RLE_ENCODE:                                                                      // f.c:244 worst case
+            if (blk[i].in_n > (SIZE_MAX >> 2)) return SHAFA_LACK_OF_MEMORY;
+            cap = 2 * blk[i].in_n + 3;
+            break;
         case SHAFA_OP_SF_ENCODE: cap = blk[i].out_cap; break;
-        case SHAFA_OP_SF_DECODE: cap = blk[i].n_symbols; break;
+        case SHAFA_OP_SF_DECODE: cap = nsym; break;
         case SHAFA_OP_RLE_DECODE:                                                                      // a triple of 3 bytes expands to 255 at most
         case SHAFA_OP_SF_RLE_DECODE: {
-            const size_t rle_n = s.op == SHAFA_OP_RLE_DECODE ? blk[i].in_n : blk[i].n_symbols;
+            const size_t rle_n = s.op == SHAFA_OP_RLE_DECODE ? blk[i].in_n : nsym;
             cap = rle_n <= (size_t)SHAFA_RLE_DECODE_MAX / 85 ? 85 * rle_n + 256 : (size_t)SHAFA_RLE_DECODE_MAX;
             if (cap > (size_t)SHAFA_RLE_DECODE_MAX) cap = SHAFA_RLE_DECODE_MAX;                     // d.c:129-169
             // ... but real blocks expand by a few per cent: the group is sized for 8 x + 4 KiB first (s.g_wide false) and
@@ -258,7 +268,7 @@ int slot_submit_group(Slot &s, int n, const shafa_pipe_block *blk)
         }
         s.g_cap[i] = cap;
         if (cap > max_cap) max_cap = cap;
-        if (blk[i].n_symbols > max_sym) max_sym = blk[i].n_symbols;
+        if (nsym > max_sym) max_sym = nsym;
         if ((s.op == SHAFA_OP_SF_ENCODE || s.op == SHAFA_OP_SF_DECODE || s.op == SHAFA_OP_SF_RLE_DECODE)) {
             if (!blk[i].table) return SHAFA_OUTSIDE_MODULE;
             if (blk[i].table != &s.g_tab[i]) s.g_tab[i] = *blk[i].table;
@@ -266,8 +276,12 @@ int slot_submit_group(Slot &s, int n, const shafa_pipe_block *blk)
         }
     }
     if (total_in > s.h_in_cap) return SHAFA_OUTSIDE_MODULE;
+    if (max_cap > (SIZE_MAX >> 8) || max_sym > (SIZE_MAX >> 8)) return SHAFA_LACK_OF_MEMORY;
     s.g_stride = (max_cap + 16 + 15) & ~(size_t)15;
     s.g_mid_stride = (max_sym + 16 + 15) & ~(size_t)15;
+    size_t total_out = 0, total_mid = 0;
+    if (__builtin_mul_overflow((size_t)n, s.g_stride, &total_out) || __builtin_mul_overflow((size_t)n, s.g_mid_stride, &total_mid))
+        return SHAFA_LACK_OF_MEMORY;
     for (int i = 0; i < n; ++i) { s.g_out_off[i] = (u64)i * s.g_stride; s.g_mid_off[i] = (u64)i * s.g_mid_stride; }
     if ((rc = grow_dev(&s.d_in, &s.d_in_cap, total_in))) return rc;
     if (total_in && !s.g_wide) {                   // (the second attempt finds the input where the first left it)
@@ -275,7 +289,6 @@ int slot_submit_group(Slot &s, int n, const shafa_pipe_block *blk)
         HIP_TRY(hipEventRecord(s.ev_in, s.st_h2d));
         HIP_TRY(hipStreamWaitEvent(s.st, s.ev_in, 0));
     }
-    const size_t total_out = (size_t)n * s.g_stride;
     u64 *d_size = s.d_gsmall + G_SIZE_AT;
     if (s.op != SHAFA_OP_HIST) {
         if ((rc = grow_dev(&s.d_out, &s.d_out_cap, total_out))) return rc;
@@ -313,7 +326,7 @@ int slot_submit_group(Slot &s, int n, const shafa_pipe_block *blk)
         const u8 *rle_in = s.d_in;
         const u64 *rle_off = s.g_in_off, *rle_n = s.g_in_n;
         if (s.op == SHAFA_OP_SF_RLE_DECODE) {                                   // d.c:565-586, fused on the device
-            if ((rc = grow_dev(&s.d_mid, &s.d_mid_cap, (size_t)n * s.g_mid_stride))) return rc;
+            if ((rc = grow_dev(&s.d_mid, &s.d_mid_cap, total_mid))) return rc;
             if ((rc = sfdec_launch(s.batch, s.st, n, s.d_in, s.g_in_off, s.g_in_n, s.g_tab, s.g_nsym, s.d_mid, s.g_mid_off))) return rc;
             rle_in = s.d_mid;
             rle_off = s.g_mid_off;
@@ -513,7 +526,8 @@ int shafa_pipe_wait_group(shafa_pipe *p, int slot, int nblocks, shafa_pipe_resul
     memset(res, 0, (size_t)nblocks * sizeof(*res));
     for (int i = 0; i < nblocks; ++i) block_rc[i] = SHAFA_SUCCESS;
     DeviceGuard dg(s.device);
-    int rc = shafa_hipd_finish((shafa_hipd_batch *)s.batch, s.st, nblocks, block_rc);   // synchronises the slot's stream
+    bool call_failed = false;
+    int rc = batch_finish(s.batch, s.st, nblocks, block_rc, &call_failed);   // synchronises the slot's stream
     if (s.out_queued) {
         const hipError_t e = hipEventSynchronize(s.ev_out);
         if (e != hipSuccess && !s.rc) s.rc = shafa_set_hip_error(e, "shafa_pipe_wait_group");
@@ -525,11 +539,11 @@ int shafa_pipe_wait_group(shafa_pipe *p, int slot, int nblocks, shafa_pipe_resul
             s.g_wide = true;
             s.rc = slot_submit_group(s, nblocks, s.g_blk);
             for (int i = 0; i < nblocks; ++i) block_rc[i] = SHAFA_SUCCESS;
-            rc = shafa_hipd_finish((shafa_hipd_batch *)s.batch, s.st, nblocks, block_rc);
+            rc = batch_finish(s.batch, s.st, nblocks, block_rc, &call_failed);
         }
     }
     if (s.rc) return s.rc;                               // the submission itself failed: no block has a result
-    (void)rc;                                            // per-block codes are in block_rc
+    if (call_failed) return rc;                          // so did the wait (stream or copy error): sizes and rows are stale
     const u64 *h_size = s.h_gsmall + G_SIZE_AT;
     size_t width = 0;
     for (int i = 0; i < nblocks; ++i) {

@@ -2558,6 +2558,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     // (batch_params_*): the copy overlaps the launch before this one instead of sitting in front of sfd_tables
     u8 *dpar = batch_params_begin(bt, stage_bytes);
     if (!dpar) return SHAFA_LACK_OF_MEMORY;
+    ParamsScope pscope(bt, st);                        // every return below records the buffer's last reader
     u8 *hs = (u8 *)batch_stage(bt, bt->par_inline ? st : bt->copy_st, stage_bytes);
     if (!hs) return SHAFA_LACK_OF_MEMORY;
     DecBlk *hb = (DecBlk *)hs;
@@ -2810,5 +2811,5 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
                            (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff));
     }
     HIP_TRY(hipGetLastError());
-    return batch_params_done(bt, st);
+    return pscope.done();
 }

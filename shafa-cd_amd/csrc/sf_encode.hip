@@ -306,6 +306,7 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const size_t stage_bytes = off - o_blk;
     u8 *dpar = batch_params_begin(bt, stage_bytes);
     if (!dpar) return SHAFA_LACK_OF_MEMORY;
+    ParamsScope pscope(bt, st);                        // every return below records the buffer's last reader
     u8 *hs = (u8 *)batch_stage(bt, bt->par_inline ? st : bt->copy_st, stage_bytes);
     if (!hs) return SHAFA_LACK_OF_MEMORY;
     EncBlk *hb = (EncBlk *)hs;
@@ -393,5 +394,5 @@ int sfenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         hipLaunchKernelGGL(sf_encode_generic, dim3(max_tiles[3] * cls_count[3]), dim3(ENC_THREADS), 0, st,
                            dblk + cls_first[3], cls_count[3], ddesc, dtick);
     HIP_TRY(hipGetLastError());
-    return batch_params_done(bt, st);
+    return pscope.done();
 }

@@ -93,14 +93,25 @@ __global__ __launch_bounds__(256) void sfe6_dot(const EncBlk *__restrict__ blks,
         v[i] = gload_nt_off<uint2>(th, ti * 512u + (u32)lane * 8u);
     }
     u32 mine = 0, seen = 0;                            // seen bit j: symbol 4 lane + j occurs in one of the tiles
+    bool foreign = false;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         seen |= ((v[i].x & 0xFFFFu) ? 1u : 0u) | ((v[i].x >> 16) ? 2u : 0u) | ((v[i].y & 0xFFFFu) ? 4u : 0u) | ((v[i].y >> 16) ? 8u : 0u);
         u32 s = (v[i].x & 0xFFFFu) * l[0] + (v[i].x >> 16) * l[1] + (v[i].y & 0xFFFFu) * l[2] + (v[i].y >> 16) * l[3];
         s = dpp_scan_add(s);
-        const u32 tot = (u32)__builtin_amdgcn_readlane((int)s, 63);
+        u32 tot = (u32)__builtin_amdgcn_readlane((int)s, 63);
+        // the counts must be this tile's: they add up to its bytes.  Histograms of something else (an uninitialised or foreign
+        // sidecar) would make totals of up to 2^28 bits a tile, offsets that wrap in sfe6_scan and stores outside the
+        // block in sfe6_kernel: such a tile counts as empty (its strings then never match: nothing is stored) and the
+        // block reports SHAFA_OUTSIDE_MODULE
+        const u32 c = dpp_scan_add((v[i].x & 0xFFFFu) + (v[i].x >> 16) + (v[i].y & 0xFFFFu) + (v[i].y >> 16));
+        const u32 have = (u32)__builtin_amdgcn_readlane((int)c, 63);
+        const u64 at = (u64)(t0 + (u32)i) * T6_TILE;
+        const u32 want = t0 + (u32)i < nt ? (bp->n - at < (u64)T6_TILE ? (u32)(bp->n - at) : T6_TILE) : have;
+        if (have != want) { foreign = true; tot = 0; }
         if (lane == i) mine = tot;
     }
+    if (foreign) set_error(bp->err, SHAFA_OUTSIDE_MODULE);
     if (lane < 16 && t0 + (u32)lane < nt) tbits[bp->desc_base + t0 + (u32)lane] = mine;
     // a data symbol without a code (c.c:156-159): reported here, ahead of sfe6_scan's size check, as the other encoders
     // meet it before they run out of room
@@ -221,6 +232,7 @@ __global__ __launch_bounds__(T6_NT, E6_WPS) void sfe6_kernel(const EncBlk *__res
     const u32 E_lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)Ev), E_hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(Ev >> 32));
     const u64 B = ((u64)B_hi << 32) | B_lo, E = ((u64)E_hi << 32) | E_lo;
     if (((E + 7) >> 3) > bp->out_cap) return;          // the block does not fit (sfe6_scan flagged it): store nothing
+    if (B > E || E - B > (u64)T6_TILE * 32u) return;   // offsets no tile of codes of <= 32 bits can have
     u8 *const o_tile = bp->out + 16ull * (B >> 7);     // the 16-byte piece that holds the tile's first bit
     const u32 S0 = B_lo & 127u;                        // bit positions below count from that piece
     const u32 S_end = S0 + (u32)(E - B);               // where the offsets say the tile ends

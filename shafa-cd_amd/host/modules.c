@@ -411,16 +411,45 @@ static int run_groups(shafa_pipe *pipe, int in_fd, uint64_t first, uint64_t end,
     int err = (gb && pb && res && brc && no_codes) ? SHAFA_SUCCESS : SHAFA_LACK_OF_MEMORY;
     int deferred = 0;
     uint64_t sub = first, ret = first, sg = 0, rg = 0;
+    /* G comes from the FIRST block's size, and the pipe sizes every row of a group for the group's largest block: a file whose
+       later blocks are far larger than its first (8 MiB of zeros, then noise, at -b m; a crafted .cod) must not turn into
+       165 rows of 64 MiB.  So a group also closes on a byte budget, and a large block goes on its own; the block that
+       did not fit is kept (prepare() has consumed it) and opens the next group. */
+    gblk held;
+    bool have_held = false;
     while (!err && ret < end) {
         if (!deferred && sub < end && sg - rg < depth) {
             const int slot = (int)(sg % depth);
             gblk *g = gb + (size_t)slot * (size_t)G;
-            uint64_t cnt = 0;
+            uint64_t cnt = 0, sum_in = 0, max_out = 0;
             while (cnt < (uint64_t)G && sub + cnt < end) {
-                memset(&g[cnt], 0, sizeof(gblk));
-                const int e = prepare(ctx, sub + cnt, &g[cnt]);
-                if (e) { deferred = e; break; }
+                if (have_held) { g[cnt] = held; have_held = false; }
+                else {
+                    memset(&g[cnt], 0, sizeof(gblk));
+                    const int e = prepare(ctx, sub + cnt, &g[cnt]);
+                    if (e) { deferred = e; break; }
+                }
+                uint64_t out_b = 0;                                      /* the row the pipe will size for this block */
+                if (!g[cnt].perr) switch (op) {
+                    case SHAFA_OP_RLE_ENCODE: out_b = 2 * g[cnt].in_n + 3; break;
+                    case SHAFA_OP_SF_ENCODE: out_b = g[cnt].out_cap; break;
+                    case SHAFA_OP_SF_DECODE: out_b = g[cnt].n_symbols; break;
+                    case SHAFA_OP_RLE_DECODE: out_b = 8 * g[cnt].in_n + 4096; break;
+                    case SHAFA_OP_SF_RLE_DECODE: out_b = 8 * g[cnt].n_symbols + 4096; break;
+                    default: break;
+                }
+                const uint64_t in_b = g[cnt].perr ? 0 : g[cnt].in_n;
+                const bool large = in_b >= (2u << 20) || out_b >= (16u << 20);
+                const uint64_t widest = out_b > max_out ? out_b : max_out;
+                if (cnt && (large || sum_in + in_b > (16u << 20) || (cnt + 1) * widest > (128u << 20))) {
+                    held = g[cnt];                                       /* opens the next group */
+                    have_held = true;
+                    break;
+                }
+                sum_in += in_b;
+                max_out = widest;
                 ++cnt;
+                if (large) break;                                        /* on its own */
             }
             size_t pos = 0;
             for (uint64_t i = 0; i < cnt; ++i) {

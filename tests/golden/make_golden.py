@@ -124,6 +124,9 @@ def make_input(gen):
         return np.full(n, gen["byte"], dtype=np.uint8)
     if kind == "alt01":
         return (np.arange(n, dtype=np.uint32) & 1).astype(np.uint8)
+    if kind == "zeros_then_uniform":
+        z = gen["zeros"]
+        return np.concatenate([np.zeros(z, dtype=np.uint8), gen_bytes(seed, n - z)])
     raise ValueError(kind)
 
 
@@ -332,6 +335,13 @@ def main():
         ["s", "-b", "M"], ["__copy__", "s", "orig__s"], ["__rm__", "s"],
         ["s.rle.shaf"], ["__copy__", "s", "decoded__sf_rle"],
     ], "3 x 64 MiB at -b M: binary section then dictionary text; RLE verdict of block 0 applied to the text blocks")
+
+    # a first block far smaller (as .rle) than the ones behind it: the drivers size their groups from the first block
+    # (host/modules.c run_groups: a group also closes on a byte budget, a large block goes alone)
+    big_case("full_skewed_blocks_m", "k", {"kind": "zeros_then_uniform", "seed": 4208, "zeros": 8 * MiB, "n": 24 * MiB + 333}, [
+        ["k", "-b", "m"], ["__copy__", "k", "orig__k"], ["__rm__", "k"],
+        ["k.rle.shaf"], ["__copy__", "k", "decoded__sf_rle"],
+    ], "8 MiB of zeros (98 KB of .rle), then 16 MiB + 333 B of noise, -b m: block 0 accepts RLE for the file")
 
     # 11. block-split edges through the drivers (file.c:78-85 last-block size, f.c:231-236 block loop)
     big_case("edge_exact_K", "q", {"kind": "runs", "seed": 21, "n": 2 * 655360}, [

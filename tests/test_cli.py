@@ -85,7 +85,7 @@ GPU_CASES = ["runs_default", "edges_forced_rle", "uniform_no_rle", "uniform_forc
              "edge_exact_K", "edge_tail_1", "edge_tail_7", "edge_tail_15", "edge_bad_cod_mid"]
 # full-size blocks (8 MiB / 64 MiB; inputs rebuilt from the manifest's generators, outputs pinned by SHA-256)
 FULL_CASES = ["full_uniform_m", "full_zipf_M", "full_zipfmod_M_forced_rle", "full_single_run_M", "full_alt01_M",
-              "full_longtail_M", "full_mixed_M",
+              "full_longtail_M", "full_mixed_M", "full_skewed_blocks_m",
               # hundreds of default-size blocks: the drivers' group mode (several groups per slot)
               "many_default_rle", "many_default_plain", "many_default_bad_cod", "many_default_single_run"]
 

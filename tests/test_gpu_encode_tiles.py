@@ -29,7 +29,7 @@ def layout(sizes, align=16, pad=0):
     return off, pos
 
 
-def run_tiles(shafa, oracle, blocks, tables, caps=None, expect_err=None, corrupt_hist_of=None):
+def run_tiles(shafa, oracle, blocks, tables, caps=None, expect_err=None, corrupt_hist_of=None, garbage_hist_of=None):
     """hist256_tiles -> (check sidecar and histogram) -> sf_encode_tiles -> compare with the oracle."""
     import torch
     dev = torch.device("cuda", 0)
@@ -72,6 +72,14 @@ def run_tiles(shafa, oracle, blocks, tables, caps=None, expect_err=None, corrupt
         v[a] -= 1
         v[cand[0]] += 1                                  # ... counted as one with another code length
         d_th[toff[i]:toff[i] + 512] = torch.from_numpy(v.view(np.uint8)).to(dev)
+
+    for i, mode in (garbage_hist_of or {}).items():     # the whole sidecar of a block is something else
+        nbytes = shafa.tile_hist_bytes(sizes[i])
+        if mode == "ff":
+            d_th[toff[i]:toff[i] + nbytes] = 0xFF
+        else:
+            rng = np.random.default_rng(99 + i)
+            d_th[toff[i]:toff[i] + nbytes] = torch.from_numpy(rng.integers(0, 256, nbytes, dtype=np.uint8)).to(dev)
 
     want = [oracle.sf_encode(b, t) for b, t in zip(blocks, tables)]
     if caps is None:
@@ -197,6 +205,16 @@ def test_tiles_error_semantics(shafa, oracle):
     caps[4] = (want_sizes[4] // 2) // 16 * 16
     run_tiles(shafa, oracle, blocks, tables, caps=caps,
               expect_err={2: shafa.FILE_UNRECOGNIZABLE, 4: shafa.LACK_OF_MEMORY, 5: shafa.OUTSIDE_MODULE}, corrupt_hist_of=5)
+
+
+def test_tiles_garbage_sidecar_is_refused(shafa, oracle):
+    """Tile histograms that are not histograms of the block at all (all 0xFFFF, random bytes: an uninitialised or foreign
+    sidecar, 40 tiles so that the offsets scan over more than one wave's worth) -> _OUTSIDE_MODULE for that block only,
+    nothing written outside its region; its neighbours encode as usual."""
+    shafa.lib().shafa_hip_init(0)
+    blocks, tables = zipf_blocks(shafa, oracle, [32768 * 40 + 123, 150000, 32768 * 40, 150000, 70000], seed0=6600)
+    run_tiles(shafa, oracle, blocks, tables, garbage_hist_of={0: "ff", 2: "random", 4: "random"},
+              expect_err={0: shafa.OUTSIDE_MODULE, 2: shafa.OUTSIDE_MODULE, 4: shafa.OUTSIDE_MODULE})
 
 
 def test_tiles_of_rle_output_feed_the_encoder(shafa, oracle):
