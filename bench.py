@@ -72,9 +72,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-sample-blocks", type=int, default=16)
     ap.add_argument("--encode-only", action="store_true")
-    ap.add_argument("--no-tiles", action="store_true",
-                    help="Module C without Module F's tile histograms: the chained one-pass encoder (sf_encode4.hip) instead of the "
-                         "one-shot grid (sf_encode6.hip); the default line reports it beside the headline as `encode_chained`")
+    ap.add_argument("--tiles", action="store_true",
+                    help="time the F-fed encoder in the headline instead: Module F's tile histograms (prepared before the timed "
+                         "region) -> one-shot grid sf_encode6.  Not Module C as c.c:306-472 defines it (input + .cod), so not "
+                         "the default: the default line is the chained one-pass encoder and reports this one as `encode_f_fed`")
+    ap.add_argument("--no-tiles", action="store_true", help="(kept for old command lines: the chained encoder is the default)")
     ap.add_argument("--scatter-gather", action="store_true",
                     help="time X1 (root scatters whole blocks) + encode + X2 (root gathers the payloads) also at N=1")
     ap.add_argument("--no-scatter-gather", action="store_true", help="skip the X1/X2 leg at N>1")
@@ -503,14 +505,16 @@ def main():
     in_off = np.arange(nb, dtype=np.uint64) * np.uint64(bs)       # host arrays once, not per call: at -b m the launcher's
     in_n = np.full(nb, bs, dtype=np.uint64)                        # host time is of the order of the kernels' time
     d_freq = torch.zeros(nb * 256, dtype=torch.int64, device=dev)
-    # Module F's products, prepared before the timed region like the .freq / .cod files: the block histograms and (unless
-    # --no-tiles) the histogram of every 32 KiB tile, which depends on the data only (include/shafa_hip.h "Tile histograms")
-    use_tiles = not args.no_tiles
+    # Module F's products, prepared before the timed region like the .freq / .cod files: the block histograms — and, for the
+    # F-fed encoder only (`encode_f_fed`, or the headline with --tiles), the histogram of every 32 KiB tile (include/shafa_hip.h
+    # "Tile histograms").  The headline times Module C as the reference defines it: the input and the .cod tables, nothing else.
+    use_tiles = args.tiles and not args.no_tiles
+    side_tiles = not use_tiles and nb <= 256          # (a second copy of the encoded blocks: not at cfg[3]'s full 1024)
     thb = pkg.tile_hist_bytes(bs)
     th_off = np.arange(nb, dtype=np.uint64) * np.uint64(thb)
-    d_th = torch.zeros(nb * thb if use_tiles else 16, dtype=torch.uint8, device=dev)
+    d_th = torch.zeros(nb * thb if (use_tiles or side_tiles) else 16, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()              # torch's fills run on its own stream: finish them before ours starts
-    if use_tiles:
+    if use_tiles or side_tiles:
         bt.hist256_tiles(st, d_in, in_off, in_n, d_freq, d_th, th_off)
     else:
         bt.hist256(st, d_in, in_off, in_n, d_freq)
@@ -565,26 +569,27 @@ def main():
         assert pkg.sf_encode(blk, t).tobytes() == want.tobytes(), "HIP encode differs from oracle"
 
     # the other encoder on the same blocks: same bytes (and its time, for the line)
-    chained = None
-    if use_tiles and not ablation and nb <= 256:          # (a second copy of the encoded blocks: not at cfg[3]'s full 1024)
+    other_t = None
+    other = encode_chained if use_tiles else encode_tiles
+    if (use_tiles or side_tiles) and not ablation and nb <= 256:
         ref_enc = d_enc.clone()
         d_enc.zero_()
-        encode_chained()
+        other()
         bt.finish(st, nb)
         for b in range(nb):
             o, m = int(out_off[b]), int(enc_bytes[b])
             assert torch.equal(d_enc[o:o + m], ref_enc[o:o + m]), f"tile path and chained encoder differ in block {b}"
         del ref_enc
         for _ in range(3):                                   # (the checks above left the GPU idle: clocks, first touches)
-            encode_chained()
+            other()
         bt.finish(st, nb)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
         for _ in range(5):
-            encode_chained()
+            other()
         e1.record(st)
         bt.finish(st, nb)
-        chained = e0.elapsed_time(e1) / 5 * 1e-3
+        other_t = e0.elapsed_time(e1) / 5 * 1e-3
         encode()
         bt.finish(st, nb)
 
@@ -640,7 +645,7 @@ def main():
     dec_gbs = alg / dec_t / 1e9 if have_decode else None
     # HBM traffic per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/gpu_traffic.sh,
     # gfx950 FETCH correction applied) on this workload AND this csrc hash; null when no matching profile exists.
-    wkey = f"{args.dist}:{args.zipf_s:g}:{args.block_mib}:{args.blocks}" + ("" if use_tiles else ":chained")
+    wkey = f"{args.dist}:{args.zipf_s:g}:{args.block_mib}:{args.blocks}" + (":tiles" if use_tiles else ":chained")
     traffic = {"sf_encode": None, "sf_decode": None}
     tsrc = None
     m = measured_traffic(wkey)
@@ -744,13 +749,21 @@ def main():
             "roofline_decode": ({"bound": "hbm", "achieved": dec_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": dec_gbs / HBM_PEAK_GBS, "traffic": traffic["sf_decode"],
                                  "algorithmic_bytes_per_launch": alg} if have_decode else None),
-            "encode_path": ("tile histograms from Module F (prepared once, like the .cod tables) -> tile offsets (dot + scan, "
-                            "inside the timed encode) -> one-shot grid sf_encode6" if use_tiles
-                            else "chained one-pass encoder sf_encode4 (no tile histograms)"),
+            "encode_path": ("F-fed (--tiles): tile histograms from Module F (prepared before the timed region) -> tile offsets (dot "
+                            "+ scan, inside the timed encode) -> one-shot grid sf_encode6" if use_tiles
+                            else "Module C as c.c:306-472 defines it: the block and its .cod table -> chained one-pass encoder "
+                                 "sf_encode4 (shafa_hipd_sf_encode)"),
         }
-        if chained:
-            out["encode_chained"] = {"ms": chained * 1e3, "frac": alg / chained / 1e9 / HBM_PEAK_GBS,
+        if other_t and use_tiles:
+            out["encode_chained"] = {"ms": other_t * 1e3, "frac": alg / other_t / 1e9 / HBM_PEAK_GBS,
                                      "what": "the same blocks through shafa_hipd_sf_encode (no tile histograms): sf_encode4's chained scan"}
+        elif other_t:
+            out["encode_f_fed"] = {"ms": other_t * 1e3, "frac": alg / other_t / 1e9 / HBM_PEAK_GBS,
+                                   "what": "the same blocks through shafa_hipd_sf_encode_tiles, fed Module F's 32 KiB tile histograms "
+                                           "(computed outside this time: hist256_tiles / rle_encode_tiles leave them, one more pass "
+                                           "over the input when they have to be made for the encoder alone): the C stage of a "
+                                           "device-resident F -> T -> C, not Module C on its own"}
+            out["roofline_encode_f_fed"] = out["encode_f_fed"]["frac"]
         out["per_rank"] = per_rank
         if comm.oversubscribed:
             out["invalid"] = "oversubscribed: ranks share GPUs (plumbing test only)"

@@ -97,9 +97,11 @@ for k in sorted(set(fe) | set(wr)):
 
 total_in = bench.get("config", {}).get("blocks_per_gpu", 0) * bench.get("config", {}).get("block_bytes", 0)
 if total_in:
-    # with the tile path measured, sfe5_kernel in the trace is bench.py's `encode_chained` comparison leg, not part of a launch
-    one_shot = "--no-tiles" not in args and any(k.startswith("sfe6_kernel") for k in per)
-    enc = sum(r + w for k, (r, w) in per.items() if k.startswith("sfe") and not (one_shot and k.startswith("sfe5_kernel")))
+    # the headline times ONE encoder (the chained sfe5 by default, the F-fed sfe6 family with --tiles); the other one in the
+    # trace is bench.py's comparison leg (`encode_f_fed` / `encode_chained`), not part of a launch
+    tiles = "--tiles" in args
+    enc = sum(r + w for k, (r, w) in per.items()
+              if k.startswith("sfe") and (k.startswith("sfe6") == tiles or not any(q.startswith("sfe6_kernel") for q in per)))
     dec = sum(r + w for k, (r, w) in per.items() if k.startswith("sfd"))
     ratio = bench["config"].get("compressed_ratio") or 0.0
     print(f"\n## bytes per input byte: sf_encode {enc / total_in:.3f}  sf_decode {dec / total_in:.3f}  (algorithmic {1 + ratio:.3f})")
@@ -109,7 +111,7 @@ if total_in:
             a[x] = args[i + 1]
     j = {"what": "HBM traffic from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, tools/gpu_prof.sh); "
                  "FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes",
-         "workload_key": f"{a['--dist']}:{float(a['--zipf-s']):g}:{a['--block-mib']}:{a['--blocks']}" + (":chained" if "--no-tiles" in args else ""),
+         "workload_key": f"{a['--dist']}:{float(a['--zipf-s']):g}:{a['--block-mib']}:{a['--blocks']}" + (":tiles" if "--tiles" in args else ":chained"),
          # a profile of one pipeline leg alone (--pipeline-only --pipeline-kind K): what bench.py's `pipeline` objects take
          # their per-family traffic from; a headline profile carries null
          "pipeline_key": ("pipeline:%s:%s:%s" % (next((args[i + 1] for i, x in enumerate(args) if x == "--pipeline-kind"), "runs"), a["--block-mib"],
