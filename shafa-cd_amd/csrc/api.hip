@@ -117,11 +117,7 @@ u8 *batch_params_begin(Batch *b, size_t bytes)
     const int i = b->par_turn;
     b->par_turn ^= 1;
     b->par_cur = i;
-#ifndef PARAMS_ALWAYS_SIDE
     b->par_inline = !b->par_dma && bytes <= PARAMS_INLINE_BYTES;   // the caller stages on the stream that will read the staging arena
-#else
-    b->par_inline = false;
-#endif
     if (bytes > b->par_bytes[i]) {                     // grow: the kernels that read the old buffer must be through
         if (b->par_used[i] && hipEventSynchronize(b->par_free[i]) != hipSuccess) return nullptr;
         if (b->d_par[i]) (void)hipFree(b->d_par[i]);

@@ -32,26 +32,12 @@ namespace {
 constexpr int RLD_THREADS = 256;
 constexpr int RLD_BPL = 32;                        // bytes per lane
 constexpr int RLD_TILE = RLD_THREADS * RLD_BPL;
-#ifndef RLD_IMG_KB
 #define RLD_IMG_KB 12
-#endif
 constexpr int RLD_IMG = RLD_IMG_KB * 1024;         // bytes of the output image
 constexpr u32 FN_IDENT = 0u | (1u << 2) | (2u << 4);
-#ifndef RLD_DSTRIDE
 #define RLD_DSTRIDE 4                              // u64 words between the descriptors of consecutive tiles
-#endif
-#ifndef RLD_SLEEP
 #define RLD_SLEEP 1
-#endif
 
-#ifdef RLD_STAMPS
-// diagnostic build only (tools/dbg/rld_stamps.py): per workgroup eight phase stamps in 100 MHz ticks
-constexpr u32 RLD_NSTAMP = 1u << 16;
-__device__ unsigned long long rld_stamp_buf[RLD_NSTAMP * 8];
-#define RLD_STAMP(slot) do { if (tid == 0 && blockIdx.x < RLD_NSTAMP) rld_stamp_buf[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define RLD_STAMP(slot)
-#endif
 
 // per 8-bit zero mask (bit i = byte i is 0) and entry state s: bits [10 s, 10 s + 8) = token starts, [10 s + 8, 10 s + 10) = exit
 struct RldFsm {
@@ -193,9 +179,7 @@ __device__ __forceinline__ void rld_fill(u8 *smem, u32 p, u32 sym, u32 c)
         if (q < (c & 3u)) smem[p + q] = (u8)sym;
 }
 
-#ifndef RLD_WAVES
 #define RLD_WAVES 7
-#endif
 __global__ __launch_bounds__(RLD_THREADS) __attribute__((amdgpu_waves_per_eu(RLD_WAVES, RLD_WAVES))) void rle_decode_kernel(const RldBlk *__restrict__ blks, int nblk,
                                                                  u64 *desc_state, u64 *desc_sum, u32 *tickets)
 {
@@ -204,16 +188,10 @@ __global__ __launch_bounds__(RLD_THREADS) __attribute__((amdgpu_waves_per_eu(RLD
     const int b = blockIdx.x % nblk;
     const RldBlk blk = blks[b];
     if ((u32)(blockIdx.x / nblk) >= blk.n_tiles) return;
-    RLD_STAMP(0);
-#ifdef RLD_NOTICKET                                     // A/B build: the tile index from the grid position (relies on in-order dispatch)
-    if (tid == 0) sh.tile = blockIdx.x / nblk;
-#else
     if (tid == 0) sh.tile = atomicAdd(tickets + blk.ticket, 1u);
-#endif
     sh.fsm[tid] = g_rld_fsm.v[tid];
     if (tid < 2) *(uint4 *)(sh.in + RLD_TILE + 16 * tid) = make_uint4(0, 0, 0, 0);
     lds_barrier();
-    RLD_STAMP(1);
     const int k = (int)sh.tile;
     const u64 n = blk.n;
     const u64 pos = (u64)k * RLD_TILE + (u64)tid * RLD_BPL;
@@ -248,10 +226,6 @@ __global__ __launch_bounds__(RLD_THREADS) __attribute__((amdgpu_waves_per_eu(RLD
     }
     const u32 vm = nvalid >= 32 ? 0xFFFFFFFFu : ((1u << nvalid) - 1u);
     const u32 z = zmask32(w) & vm;
-#ifdef RLD_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    RLD_STAMP(2);
-#endif
 
     // ---- this lane's transition map and token starts for each entry state, ordered scan over lanes and waves --------
     // A wave without a zero byte (text-like data: nearly every wave): every byte is a literal once the state is S0, which
@@ -293,7 +267,6 @@ __global__ __launch_bounds__(RLD_THREADS) __attribute__((amdgpu_waves_per_eu(RLD
         if (lane == 0) fex = FN_IDENT;
     }
     lds_barrier();
-    RLD_STAMP(3);
     u32 wcar = FN_IDENT, ftile = FN_IDENT;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -309,9 +282,7 @@ __global__ __launch_bounds__(RLD_THREADS) __attribute__((amdgpu_waves_per_eu(RLD
                 if (fn_const(ftile)) desc_store(dst + (size_t)k * RLD_DSTRIDE, DESC_PREFIX, ftile & 3);
                 else desc_store(dst + (size_t)k * RLD_DSTRIDE, DESC_AGG, ftile);
             }
-#ifndef RLD_ABL_NOLB
             sin = fn_const(fprev) ? (fprev & 3u) : lookback_state(dst, k, blk.err);
-#endif
         }
         if (tid == 0) {
             desc_store(dst + (size_t)k * RLD_DSTRIDE, DESC_PREFIX, fn_apply(ftile, sin));
@@ -319,15 +290,10 @@ __global__ __launch_bounds__(RLD_THREADS) __attribute__((amdgpu_waves_per_eu(RLD
         }
     }
     lds_barrier();
-    RLD_STAMP(4);
 
     // ---- literal / escape masks, per-byte output lengths ------------------------------------------------------------
     // (uniform) a tile of waves without zero bytes that is entered at a token start: its output is its input
-#ifndef RLD_NOPLAIN
     const bool plain = sh.state_in == 0u && (sh.wplain[0] & sh.wplain[1] & sh.wplain[2] & sh.wplain[3]) != 0u;
-#else                                                  // A/B builds (tools/dbg)
-    const bool plain = false;
-#endif
     u32 Lm = 0xFFFFFFFFu, E = 0u, lenw[8], len = RLD_BPL;
     if (!plain) {
         const u32 s_in = fn_apply(fpre, sh.state_in);
@@ -369,7 +335,6 @@ __global__ __launch_bounds__(RLD_THREADS) __attribute__((amdgpu_waves_per_eu(RLD
     const u32 ilen = wave_incl_scan_add<u32>(len);
     if (lane == 63) sh.wlen[wv] = ilen;
     lds_barrier();
-    RLD_STAMP(5);
     u32 lbase = 0, ltot = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -410,7 +375,6 @@ __global__ __launch_bounds__(RLD_THREADS) __attribute__((amdgpu_waves_per_eu(RLD
                 u32 p = p0;
                 const u32 p_end = p0 + len;
                 const u32 dump = (u32)offsetof(RldShared, dump) + 4u * (u32)tid;
-#ifndef RLD_ABL_NOLIT                                   // (A/B builds, wrong output: tools/dbg/rld_stamps.py)
 #pragma unroll
                 for (int i = 0; i < RLD_BPL / 4; ++i) {
                     smem[p < p_end ? p : dump] = (u8)w[i];          p = add_byte<0>(p, lenw[i]);
@@ -418,12 +382,8 @@ __global__ __launch_bounds__(RLD_THREADS) __attribute__((amdgpu_waves_per_eu(RLD
                     smem[p < p_end ? p : dump] = (u8)(w[i] >> 16);  p = add_byte<2>(p, lenw[i]);
                     smem[p < p_end ? p : dump] = (u8)(w[i] >> 24);  p = add_byte<3>(p, lenw[i]);
                 }
-#endif
             }
             u32 g = 0;                                  // bytes of the runs so far
-#ifdef RLD_ABL_NOFILL
-            if (0)
-#endif
             for (u32 e = E; e; e &= e - 1) {            // runs: the lane's escapes in order
                 const u32 j = (u32)__builtin_ctz(e);
                 const u32 sym = smem[in_off + j + 1], c0 = smem[in_off + j + 2], c = c0 ? c0 : 1u;
@@ -434,11 +394,7 @@ __global__ __launch_bounds__(RLD_THREADS) __attribute__((amdgpu_waves_per_eu(RLD
         if (done == 0 && wv == 0) {
             u64 O0 = 0;
             if (k > 0) {
-#ifndef RLD_ABL_NOLB
                 O0 = lookback_sum<RLD_DSTRIDE, RLD_SLEEP>(dsum, k, blk.err, true, lb_first);
-#else
-                O0 = (u64)k * 8192u;
-#endif
             }
             if (tid == 0) {
                 desc_store(dsum + (size_t)k * RLD_DSTRIDE, DESC_PREFIX, O0 + ltot);
@@ -447,7 +403,6 @@ __global__ __launch_bounds__(RLD_THREADS) __attribute__((amdgpu_waves_per_eu(RLD
         }
         lds_barrier();                                // the image is complete (and, the first time, O has arrived)
         if (done == 0) {
-            RLD_STAMP(6);
             O = sh.O;
             const u64 Oend = O + ltot;
             if (Oend > (u64)SHAFA_RLE_DECODE_MAX) { if (tid == 0) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE); }
@@ -459,9 +414,6 @@ __global__ __launch_bounds__(RLD_THREADS) __attribute__((amdgpu_waves_per_eu(RLD
         u8 *gout = blk.out + O + done;
         const u32 mis = (u32)((uintptr_t)gout & 15u), nbytes = nxt - done;
         const u64 gidx = O + done;                      // index of image byte 0 in the block's output
-#ifdef RLD_ABL_NOSTORE
-        if (ltot == 0xFFFFFFFFu)
-#endif
         for (u32 u = tid; 16 * u < mis + nbytes; u += RLD_THREADS) {
             const u32 s0 = src_off + 16 * u - mis, sb = s0 & ~3u, sf = s0 & 3u;
             const u32 d0 = *(const u32 *)__builtin_assume_aligned(smem + sb, 4), d1 = *(const u32 *)__builtin_assume_aligned(smem + sb + 4, 4),
@@ -484,18 +436,8 @@ __global__ __launch_bounds__(RLD_THREADS) __attribute__((amdgpu_waves_per_eu(RLD
         if (done >= ltot) break;
         lds_barrier();                                // the image is read out before the next round writes it
     }
-#ifdef RLD_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    RLD_STAMP(7);
-#endif
 }
 
-#ifdef RLD_STAMPS
-extern "C" int shafa_rld_read_stamps(unsigned long long *dst, int n)
-{
-    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(rld_stamp_buf), (size_t)n * 8) == hipSuccess ? 0 : 9;
-}
-#endif
 
 
 }  // namespace

@@ -1328,12 +1328,8 @@ __device__ __forceinline__ bool scan_single(const lds_u8 *tab, const u16 *lt, co
 // What a wave's lanes share while they load and walk 64 strips from byte `wave_off` of the block's stream (lane = strip =
 // column).  The phase's words are fetched by lane PAIRS: pair px loads strips px and px + 32, 32 contiguous bytes per
 // pair and load, and stores them into those strips' columns.
-#ifndef SC_QUAD
 #define SC_QUAD 0
-#endif
-#ifndef SC_NT
 #define SC_NT 0
-#endif
 struct ScanIO {
     const u8 *in;
     u64 in_n;

@@ -147,13 +147,9 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restri
             // hand-over words of this parity were last read two iterations ago.
             lds_barrier();
             const u32 n3 = sh.tick5[par];
-#ifndef E5_ABL_NOSTORE                                 // timing ablations (tools/dbg): wrong output
             // (a tile that did not fit its window was never placed and its block is encoded again: nothing to store, and
             // reading p_T bits of a window that holds cap_bits would run past the workgroup's LDS)
             if (wv >= E5_STORE_W0 && have_p && p_T <= cap_bits)
-#else
-            if (wv >= E5_STORE_W0 && have_p && bp->n == 12345)
-#endif
                 store_window5(pwin, bp->out, bp->out_cap, bp->err, sh.prefix5[par], p_T, !ragged && p_tile == nfull - 1,
                               tid - 64 * E5_STORE_W0, NT - 64 * E5_STORE_W0);
             u32 c_T = 0;
@@ -176,9 +172,6 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restri
                 const u32 fin = __builtin_amdgcn_alignbit(tail, 0u, E);
                 u32 c = (u32)__builtin_amdgcn_update_dpp(0, (int)fin, 0x138, 0xf, 0xf, false);
                 if (lane == 0) c = __builtin_amdgcn_alignbit(sh.tail5[par][wv ? wv - 1 : 0], 0u, e);
-#ifdef E5_ABL_NOEMIT
-                if (bp->n == 12345)
-#endif
                 if (fits) {
 #pragma unroll
                     for (int k = 0; k < UNITS; ++k) {

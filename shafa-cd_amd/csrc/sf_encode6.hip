@@ -40,31 +40,16 @@ namespace {
 constexpr u32 T6_TILE = 32768;                         // symbols per tile = per histogram of the sidecar (SHAFA_TILE_BYTES)
 constexpr int T6_SUB = 4;                              // sub-tiles per tile
 constexpr int T6_NT = 256;                             // lanes: 32 symbols each per sub-tile
-#ifndef E6_WPS
 #define E6_WPS 5                                       // workgroups per CU the register allocation aims at
-#endif
 
-#ifdef E6_STAMPS
-// diagnostic build only (tools/dbg/e6stamps.py): per workgroup {start, inputs arrived, end} in 100 MHz ticks, and where it ran
-constexpr u32 E6_NSTAMP = 1u << 16;
-__device__ unsigned long long e6_stamp_buf[E6_NSTAMP * 4];
-#define E6_STAMP(slot) do { if (tid == 0 && _sid < E6_NSTAMP) e6_stamp_buf[_sid * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define E6_STAMP(slot)
-#endif
 
 struct E6Static {
-#ifndef E6_STRIDE32_LOADS
     uint4 stage[T6_NT / 64][128];// per wave: 2 KiB of input on its way from load order to symbol order
-#endif
     u64 lut[256];                // {code (low dword), len (high dword)}; a symbol without a code: len = 1 << 16
     u32 dump[64];                // where the stores of lanes that have nothing to store go (one word per lane)
     u32 wtot[2][4];              // per wave: bits of its string (parity of the sub-tile)
     u32 tail[2][4];              // per wave: the last 32 bits of its string
     u32 ltail[T6_SUB];           // the last 32 bits of every sub-tile's string
-#ifdef E6_PAD_LDS
-    u32 pad_lds[E6_PAD_LDS / 4]; // occupancy experiments (tools/dbg)
-#endif
 };
 
 // ---- tile bit totals: the sidecar's histograms times the code lengths ---------------------------------------------------
@@ -164,17 +149,8 @@ __device__ __forceinline__ void e6_store_pieces(u32 lds, u8 *o, u32 p0, u32 np, 
         e5_u32x4 a0 = e5_lds_read128(lds + 16u * p), a1 = a0;
         if (two) a1 = e5_lds_read128(lds + 16u * p2);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1) : : "memory");
-#ifndef E6_ABL_NOSTORE
-#ifdef E6_PLAIN_STORE
-        gstore_off<uint4>(o, 16u * p, e6_swap(a0));
-        if (two) gstore_off<uint4>(o, 16u * p2, e6_swap(a1));
-#else
         gstore_nt_off<uint4>(o, 16u * p, e6_swap(a0));
         if (two) gstore_nt_off<uint4>(o, 16u * p2, e6_swap(a1));
-#endif
-#else
-        if (a0.x == 0x12345u && a1.y == 0x777u) gstore_nt_off<uint4>(o, 16u * p, e6_swap(a0));
-#endif
     }
 }
 
@@ -193,12 +169,6 @@ __global__ __launch_bounds__(T6_NT, E6_WPS) void sfe6_kernel(const EncBlk *__res
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u8 *in = bp->in + (u64)t * T6_TILE;
-#ifdef E6_STAMPS
-    const u32 _sid = blockIdx.y * gridDim.x + blockIdx.x;
-    E6_STAMP(0);
-    if (tid == 0 && _sid < E6_NSTAMP)
-        e6_stamp_buf[_sid * 4 + 3] = ((u64)__builtin_amdgcn_s_getreg(63508) << 32) | (u32)__builtin_amdgcn_s_getreg(63492);   // XCC_ID, HW_ID
-#endif
 
     // ---- everything this workgroup ever loads, requested at once ---------------------------------------------------
     // Fully coalesced non-temporal loads: of its 2 KiB of every sub-tile a wave loads piece (16 bytes) l and piece 64 + l
@@ -208,25 +178,16 @@ __global__ __launch_bounds__(T6_NT, E6_WPS) void sfe6_kernel(const EncBlk *__res
     TileIn5 tin[T6_SUB];
 #pragma unroll
     for (int k = 0; k < T6_SUB; ++k) {
-#ifndef E6_STRIDE32_LOADS
         tin[k].v[0] = gload_nt_off<uint4>(in, (u32)k * 8192u + (u32)wv * 2048u + (u32)lane * 16u);
         tin[k].v[1] = gload_nt_off<uint4>(in, (u32)k * 8192u + (u32)wv * 2048u + 1024u + (u32)lane * 16u);
-#else
-        load_tile5<T6_NT>(in, (u32)k, tid, tin[k]);
-#endif
     }
     const u64 lut_e = gload<u64>((const u64 *)bp->lut + tid);
     u32 pv = 0;                                        // wave 0, lanes 0..31: symbol (tile start - 1 - lane)
     if (wv == 0 && t > 0 && lane < 32) pv = gload_off<u8>(in - 32, 31u - (u32)lane);
     const u64 *tp = toff + bp->desc_base + t;
-#ifndef E6_ABL_NOCOMP
     const u64 Bv = gload<u64>(tp), Ev = gload<u64>(tp + 1);
-#else                                                  // timing ablation: every lane's string is 208 bits of its input words
-    const u64 Bv = (u64)t * 212992ull + (u64)(tp == nullptr), Ev = Bv + 212992ull;
-#endif
     sh.lut[tid] = lut_e;
     __syncthreads();                                   // the one wait for global memory (the barrier drains vmcnt)
-    E6_STAMP(1);
 
     const u32 B_lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)Bv), B_hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(Bv >> 32));
     const u32 E_lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)Ev), E_hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(Ev >> 32));
@@ -261,7 +222,6 @@ __global__ __launch_bounds__(T6_NT, E6_WPS) void sfe6_kernel(const EncBlk *__res
         u32 *win = dynwin + par * wstride;
         Oct oct[4];
         u32 tot = 0, incl = 0, tail = 0, absent = 0;
-#ifndef E6_STRIDE32_LOADS
         {   // pieces l and 64 + l of the wave's 2 KiB -> pieces 2 l and 2 l + 1 (same wave: LDS operations of one wave execute
             // in order; the wave barriers keep the compiler from moving the reads above the writes)
             uint4 *stg = sh.stage[wv];
@@ -276,21 +236,8 @@ __global__ __launch_bounds__(T6_NT, E6_WPS) void sfe6_kernel(const EncBlk *__res
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
         }
-#endif
-#ifndef E6_ABL_NOCOMP
         tile_octs5<NW, L16>(sh.lut, tin[k], oct, tot, incl, tail, absent);
-#else
-        {
-            const u32 w[8] = {tin[k].v[0].x, tin[k].v[0].y, tin[k].v[0].z, tin[k].v[0].w, tin[k].v[1].x, tin[k].v[1].y, tin[k].v[1].z, tin[k].v[1].w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { oct[q].r0 = w[2 * q]; oct[q].r1 = w[2 * q + 1] & 0xFFFFFu; oct[q].r2 = 0; oct[q].r3 = 0; oct[q].ll = 52u; }
-            tot = 208u; incl = 208u * (u32)(lane + 1); tail = w[7];
-        }
-#endif
         if (absent) set_error(bp->err, SHAFA_FILE_UNRECOGNIZABLE);          // data symbol without a code (output undefined, in bounds)
-#ifdef E6_PAD_LDS
-        if (n == 12345) sh.pad_lds[tid] = tot;
-#endif
         if (lane == 63) {
             sh.wtot[par][wv] = incl;
             sh.tail[par][wv] = tail;
@@ -329,9 +276,6 @@ __global__ __launch_bounds__(T6_NT, E6_WPS) void sfe6_kernel(const EncBlk *__res
                 const u32 prev = wv ? sh.tail[par][wv - 1] : (k ? sh.ltail[k - 1] : lead);
                 c = __builtin_amdgcn_alignbit(prev, 0u, e);
             }
-#ifdef E6_ABL_NOEMIT                                   // timing ablations (tools/dbg): wrong output
-            if (n == 12345)
-#endif
             {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -341,21 +285,8 @@ __global__ __launch_bounds__(T6_NT, E6_WPS) void sfe6_kernel(const EncBlk *__res
             }
             if (k == T6_SUB - 1 && tid == T6_NT - 1) win[e >> 5] = c;      // the tile's final partial dword (the block's last bytes)
         };
-#if defined(E6_ORDER_PLACE_FIRST)
-        place_it();
         leave();
-#elif defined(E6_ORDER_SPLIT)                          // waves 0, 1: store then place; waves 2, 3: place then store
-        if (wv < 2) { leave(); place_it(); } else { place_it(); leave(); }
-#else
-#ifdef E6_PRIO
-        __builtin_amdgcn_s_setprio(E6_PRIO);
-#endif
-        leave();
-#ifdef E6_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         place_it();
-#endif
     }
     lds_barrier();
     {
@@ -373,17 +304,10 @@ __global__ __launch_bounds__(T6_NT, E6_WPS) void sfe6_kernel(const EncBlk *__res
                 gstore_off<u8>(o, 16u * np + 4u * cnt + ((u32)tid - 8u), (u8)(pbuf[4u * np + cnt] >> (24u - 8u * ((u32)tid - 8u))));
         } else if (tid == 0) set_error(bp->err, SHAFA_OUTSIDE_MODULE);   // the sidecar is not this block's
     }
-    E6_STAMP(2);
 }
 
 }  // namespace
 
-#ifdef E6_STAMPS
-extern "C" int shafa_e6_read_stamps(unsigned long long *dst, int n)
-{
-    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(e6_stamp_buf), (size_t)n * 8) == hipSuccess ? 0 : 9;
-}
-#endif
 
 // Blocks whose codes are <= 16 bits, tables 256 x u64 {code, len}; blk.thist = the block's tile histograms, blk.desc_base =
 // its first entry in d_tbits / d_toff (n_tiles + 1 entries per block), blk.n_tiles = ceil(n / 32768).
@@ -393,11 +317,7 @@ int sfenc6_launch(hipStream_t st, const EncBlk *dblk, int count, u32 max_tiles, 
     static int tail_attr_by_dev[MAXDEV];
     static std::mutex mu;
     if (lmax < 1 || lmax > 16 || count <= 0) return SHAFA_OUTSIDE_MODULE;
-#ifdef E6_CAP_BITS                                     // occupancy experiments (tools/dbg): buffers smaller than the worst case, unchecked
-    const u32 wstride = (256u * (lmax < E6_CAP_BITS ? lmax : E6_CAP_BITS) + 8u + 3u) & ~3u;
-#else
     const u32 wstride = (256u * lmax + 8u + 3u) & ~3u;               // dwords per buffer: 127 + 8192 lmax bits, the final dword
-#endif
     const size_t dyn = (size_t)wstride * 2 * 4;
     hipLaunchKernelGGL(sfe6_dot, dim3((max_tiles + 63) / 64, (u32)count), dim3(256), 0, st, dblk, d_tbits);
     hipLaunchKernelGGL(sfe6_scan, dim3((u32)count), dim3(1024), 0, st, dblk, (const u32 *)d_tbits, d_toff);

@@ -14,9 +14,7 @@ namespace {
 // once per 32 KiB instead of once per 8 KiB and spreads the window stores over fifteen waves instead of three.
 constexpr int E4_GUARD = 8;                            // dwords in front of the window: an oct writes up to 4 dwords before its last one
 constexpr u32 E4_NONE = 0xFFFFFFFFu;
-#ifndef E4_WPS
 #define E4_WPS 4                                       // waves per SIMD the register allocation aims at
-#endif
 
 struct E4Static {
     u64 lut[256];                // {code (low dword), len (high dword)}; a symbol without a code: len = 1 << 16
@@ -320,9 +318,7 @@ __device__ __forceinline__ void store_window5(const u32 *pwin, u8 *out, u64 out_
 // where round 2's atomic-OR windows took 32 look-ups, 16 ds_or_b32 and a zeroing pass (`place`, kept for the ragged-tail
 // kernels, whose strings may be shorter than a dword).
 // =====================================================================================================================
-#ifndef E5_STORE_W0
 #define E5_STORE_W0 1                                  // the waves E5_STORE_W0 .. NWV-1 store the resolved window
-#endif
 struct TileIn5 {
     uint4 v[2];                  // lane t holds bytes [32 t, 32 t + 32) of the tile
 };
@@ -331,20 +327,12 @@ template <int NT>
 __device__ __forceinline__ void load_tile5(const u8 *in, u32 tile, int tid, TileIn5 &t)
 {
     const u8 *tb = in + (u64)tile * (32u * NT);
-#ifdef E5_LOADTEST                                     // timing experiment only (wrong symbol order): fully coalesced loads
-    t.v[0] = gload_nt_off<uint4>(tb, (u32)tid * 16u);
-    t.v[1] = gload_nt_off<uint4>(tb, (u32)tid * 16u + 16u * NT);
-#elif defined(E5_NTLOAD)
-    t.v[0] = gload_nt_off<uint4>(tb, (u32)tid * 32u);
-    t.v[1] = gload_nt_off<uint4>(tb, (u32)tid * 32u + 16u);
-#else
     // 32 bytes per lane = two 16-byte loads at a 32-byte lane stride: each instruction uses half of every cache line it
     // touches, the other half is the second instruction's.  Default (L1-allocating) policy: with `nt` the second
     // instruction fetches the lines again (measured: 4.05 ms per 8 GiB with nt, 3.72 plain, 3.66 with a fully coalesced
     // but wrong symbol order).
     t.v[0] = gload_off<uint4>(tb, (u32)tid * 32u);
     t.v[1] = gload_off<uint4>(tb, (u32)tid * 32u + 16u);
-#endif
 }
 
 // Codes of up to 32 bits (class 2: a real file's rare bytes at -b M): the unit is a QUAD, the 4 symbols of one input

@@ -177,6 +177,21 @@ def _replay_and_check(case, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["many_default_rle", "full_skewed_blocks_m", "full_zipfmod_M_forced_rle"])
+def test_cli_with_a_full_nodes_slot_count(case, tmp_path, monkeypatch):
+    """SHAFA_DEVICES=0,0,0,0,0,0,0,0: the C host spreads its pipe slots over the listed devices, three per device — 24 slots,
+    eight H2D streams' worth of bookkeeping, the ordered retire across all of them — as on a full 8-GPU node, here on the one
+    GPU there is.  Same files, byte for byte, as the reference (groups of small blocks, a ragged -b m file, 64 MiB blocks)."""
+    monkeypatch.setenv("SHAFA_DEVICES", "0,0,0,0,0,0,0,0")
+    work = scratch_dir(tmp_path, case)
+    try:
+        _replay_and_check(case, work)
+    finally:
+        if work != str(tmp_path):
+            shutil.rmtree(work, ignore_errors=True)
+
+
+@pytest.mark.gpu
 def test_cli_device_list_errors_are_reported(tmp_path):
     """SHAFA_DEVICES naming a GPU the node does not have (or garbage) is an error message and exit 1 before any module
     runs — not a silent fall-back to device 0; a valid list works; Module T alone ignores the variable (it touches no GPU)."""
