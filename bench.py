@@ -305,6 +305,19 @@ def host_path_leg(args, pkg, torch, dev, d_in):
             times[name] = time.perf_counter() - t0
             if rr.returncode != 0:
                 raise RuntimeError(f"shafa -m {name}: rc {rr.returncode} {rr.stderr[-200:]}")
+        # the default run, `shafa z -b M` (f, t and c in one process, shafa.c:293-298): one upload per block (host/modules.c
+        # shafa_ftc_compress, layer 3 SHAFA_OP_FTC) against the same three modules as separate passes in one process (SHAFA_FTC=0)
+        shaf0 = hashlib.sha256(open(p + ".shaf", "rb").read()).hexdigest()
+        for name, ftc in (("ftc_one_upload", "2"), ("ftc_three_passes", "0")):
+            for q in (".shaf", ".cod", ".freq", ".rle", ".rle.freq", ".rle.cod", ".rle.shaf"):
+                if os.path.exists(p + q):
+                    os.remove(p + q)
+            t0 = time.perf_counter()
+            rr = subprocess.run([cli, p, "-b", flag], capture_output=True, text=True, env=dict(env, SHAFA_FTC=ftc), timeout=600)
+            times[name] = time.perf_counter() - t0
+            if rr.returncode != 0:
+                raise RuntimeError(f"shafa z -b {flag} (SHAFA_FTC={ftc}): rc {rr.returncode} {rr.stderr[-200:]}")
+            assert hashlib.sha256(open(p + ".shaf", "rb").read()).hexdigest() == shaf0, "default run: .shaf differs from -m f / t / c"
         os.remove(p)
         t0 = time.perf_counter()
         rr = subprocess.run([cli, p + ".shaf", "-m", "d"], capture_output=True, text=True, env=env, timeout=600)

@@ -235,9 +235,13 @@ enum shafa_pipe_op {
     SHAFA_OP_SF_ENCODE = 3,      /* compress_to_buffer (c.c:91-237)                                   */
     SHAFA_OP_SF_DECODE = 4,      /* create_tree + shafa_block_decompressor (d.c:565-569)              */
     SHAFA_OP_RLE_DECODE = 5,     /* rle_block_decompressor (d.c:116-197)                              */
-    SHAFA_OP_SF_RLE_DECODE = 6   /* process_shafa_decomp with RLE (d.c:558-590), fused on the device  */
+    SHAFA_OP_SF_RLE_DECODE = 6,  /* process_shafa_decomp with RLE (d.c:558-590), fused on the device  */
+    SHAFA_OP_FTC = 7             /* Modules F and C on ONE residency of the block, Module T on the host in between:
+                                    see "F -> T -> C" below                                                            */
 };
-#define SHAFA_PIPE_INPUT_HIST 1  /* with SHAFA_OP_RLE_ENCODE: also the histogram of the input (-c f)  */
+#define SHAFA_PIPE_INPUT_HIST 1  /* with SHAFA_OP_RLE_ENCODE / SHAFA_OP_FTC: also the histogram of the input (-c f)  */
+#define SHAFA_PIPE_FTC_RLE 2     /* SHAFA_OP_FTC: run block_compression (the block may be encoded from its RLE bytes) */
+#define SHAFA_PIPE_FTC_PLAIN 4   /* SHAFA_OP_FTC: the block may be encoded as it is (tile histograms of the input)    */
 
 typedef struct shafa_pipe_result {
     const uint8_t *out;          /* the slot's pinned result buffer (valid until the slot is reused)  */
@@ -265,6 +269,21 @@ int shafa_pipe_submit(shafa_pipe *p, int slot, int op, size_t in_n, const shafa_
 /* Wait for the slot's block, fetch its result into the pinned output buffer, mark the slot idle.
  * Returns the block's _modules_error number. */
 int shafa_pipe_wait(shafa_pipe *p, int slot, shafa_pipe_result *res);
+
+/* ---- F -> T -> C on one residency (the default `shafa file -b m|M`, shafa.c:293-298 with 157-198) ----------------------
+ * The reference's default run reads a block in Module F, writes its .rle, and reads that again in Module C.  Here the block
+ * is uploaded ONCE:
+ *   shafa_pipe_submit(p, slot, SHAFA_OP_FTC, in_n, NULL, 0, 0, flags)   F on the device: with SHAFA_PIPE_FTC_RLE
+ *        block_compression + make_freq of the RLE bytes (shafa_hipd_rle_encode_tiles: the 32 KiB tile histograms of the RLE
+ *        bytes stay on the device), with SHAFA_PIPE_FTC_PLAIN / SHAFA_PIPE_INPUT_HIST make_freq of the input and its tile
+ *        histograms (block 0, whose RLE size decides for the file, f.c:250-258, asks for both)
+ *   shafa_pipe_wait(p, slot, &res)          res.out / out_n = the RLE bytes (for the .rle file), res.freq / freq_in; the
+ *        slot stays reserved: the caller builds the block's codes (Module T) from the histogram of what will be encoded
+ *   shafa_pipe_ftc_encode(p, slot, use_rle, &table, out_cap)   Module C from the bytes already on the device
+ *        (shafa_hipd_sf_encode_tiles with the tile histograms of stage one)
+ *   shafa_pipe_wait(p, slot, &res)          res.out / out_n = the .shaf payload (a second pinned buffer: the RLE bytes of
+ *        the first wait stay valid until the slot is reused); the slot is idle again. */
+int shafa_pipe_ftc_encode(shafa_pipe *p, int slot, int use_rle, const shafa_code_table *table, size_t out_cap);
 
 /* ---- Groups: several consecutive blocks of a file in one slot -------------------------------------------------------------
  * One launch per block costs the submitting thread ~0.1 ms whatever the block's size, which is all of a file's time at the

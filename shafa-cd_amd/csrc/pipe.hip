@@ -35,6 +35,12 @@ struct Slot {
     size_t h_in_cap, h_out_cap;
     u8 *d_in, *d_out, *d_mid;  // device: input, result, SF-decoded bytes of the fused decode
     size_t d_in_cap, d_out_cap, d_mid_cap;
+    // SHAFA_OP_FTC: tile histograms of the RLE bytes / of the input, the .shaf payload on the device and on the host
+    u8 *d_th_rle, *d_th_in, *d_out2, *h_out2;
+    size_t d_th_rle_cap, d_th_in_cap, d_out2_cap, h_out2_cap;
+    int stage;                 // SHAFA_OP_FTC: 0 = idle, 1 = F submitted / retired (the slot stays reserved), 2 = C submitted
+    int ftc_flags;
+    size_t rle_n;              // SHAFA_OP_FTC: size of the RLE bytes (known after the first wait)
     u64 *d_small;              // [0..255] hist of the result / input, [256..511] hist of the input (-c f), [512] size, [513] mid size
     u64 *h_small;              // pinned mirror
     int op;
@@ -75,25 +81,25 @@ namespace {
 // where the link does two directions.  A copy KERNEL that reads the size on the device — exact, no host — was measured
 // too: its 1-2 ms on a hardware queue hold back the barrier packets of the other slots' copies, 28-34 GiB/s.)
 // the first nbytes of the slot's result, behind the kernels queued so far, on the device's D2H stream
-int pipe_payload(Slot &s, size_t nbytes)
+int pipe_payload(Slot &s, size_t nbytes, bool second = false)
 {
     if (!nbytes) return SHAFA_SUCCESS;
     HIP_TRY(hipEventRecord(s.ev_k, s.st));
     HIP_TRY(hipStreamWaitEvent(s.st_d2h, s.ev_k, 0));
-    HIP_TRY(hipMemcpyAsync(s.h_out, s.d_out, nbytes, hipMemcpyDeviceToHost, s.st_d2h));
+    HIP_TRY(hipMemcpyAsync(second ? s.h_out2 : s.h_out, second ? s.d_out2 : s.d_out, nbytes, hipMemcpyDeviceToHost, s.st_d2h));
     HIP_TRY(hipEventRecord(s.ev_out, s.st_d2h));
     s.out_queued = true;
     return SHAFA_SUCCESS;
 }
 
-int pipe_prefetch(Slot &s, size_t pred, size_t cap)
+int pipe_prefetch(Slot &s, size_t pred, size_t cap, bool second = false)
 {
     s.copied = 0;
     if (!pred) return SHAFA_SUCCESS;
     size_t nbytes = pred + pred / 32 + 4096;
     if (nbytes > cap) nbytes = cap;
-    if (nbytes > s.h_out_cap) nbytes = s.h_out_cap;
-    const int rc = pipe_payload(s, nbytes);
+    if (nbytes > (second ? s.h_out2_cap : s.h_out_cap)) nbytes = second ? s.h_out2_cap : s.h_out_cap;
+    const int rc = pipe_payload(s, nbytes, second);
     if (rc) return rc;
     s.copied = nbytes;
     return SHAFA_SUCCESS;
@@ -146,6 +152,25 @@ int slot_submit(Slot &s, const shafa_code_table *table, const size_t pred)
         if ((rc = rleenc_launch(s.batch, s.st, 1, s.d_in, off0, in_n, s.d_out, off0, ocap, d_size, s.d_small))) return rc;
         HIP_TRY(hipMemcpyAsync(s.h_small, s.d_small, 514 * sizeof(u64), hipMemcpyDeviceToHost, s.st));
         if ((rc = pipe_prefetch(s, pred, cap))) return rc;
+        break;
+    }
+    case SHAFA_OP_FTC: {                                                         // stage one: Module F, the block stays
+        const u64 th0[1] = {0};
+        if (s.ftc_flags & SHAFA_PIPE_FTC_RLE) {
+            const size_t cap = (2 * s.in_n + 3 + 15) & ~(size_t)15;             // f.c:244 worst case
+            if ((rc = grow_dev(&s.d_out, &s.d_out_cap, cap))) return rc;
+            if ((rc = grow_pinned(&s.h_out, &s.h_out_cap, cap))) return rc;
+            if ((rc = grow_dev(&s.d_th_rle, &s.d_th_rle_cap, shafa_hip_tile_hist_bytes(cap)))) return rc;
+            const u64 ocap[1] = {cap};
+            if ((rc = rleenc_launch(s.batch, s.st, 1, s.d_in, off0, in_n, s.d_out, off0, ocap, d_size, s.d_small, s.d_th_rle, th0))) return rc;
+        }
+        if (s.ftc_flags & (SHAFA_PIPE_FTC_PLAIN | SHAFA_PIPE_INPUT_HIST)) {
+            if ((rc = grow_dev(&s.d_th_in, &s.d_th_in_cap, shafa_hip_tile_hist_bytes(s.in_n)))) return rc;
+            u64 *d_f = (s.ftc_flags & SHAFA_PIPE_FTC_RLE) ? s.d_small + 256 : s.d_small;   // as HIST / RLE_ENCODE put them
+            if ((rc = hist_launch_dev(s.batch, s.st, 1, s.d_in, off0, in_n, nullptr, d_f, s.d_th_in, th0))) return rc;
+        }
+        HIP_TRY(hipMemcpyAsync(s.h_small, s.d_small, 514 * sizeof(u64), hipMemcpyDeviceToHost, s.st));
+        if ((s.ftc_flags & SHAFA_PIPE_FTC_RLE) && (rc = pipe_prefetch(s, pred, s.d_out_cap))) return rc;
         break;
     }
     case SHAFA_OP_SF_ENCODE: {
@@ -405,6 +430,10 @@ void shafa_pipe_destroy(shafa_pipe *p)
         if (s.d_in) hipFree(s.d_in);
         if (s.d_out) hipFree(s.d_out);
         if (s.d_mid) hipFree(s.d_mid);
+        if (s.d_th_rle) hipFree(s.d_th_rle);
+        if (s.d_th_in) hipFree(s.d_th_in);
+        if (s.d_out2) hipFree(s.d_out2);
+        if (s.h_out2) hipHostFree(s.h_out2);
         if (s.d_small) hipFree(s.d_small);
         if (s.h_small) hipHostFree(s.h_small);
         if (s.d_gsmall) hipFree(s.d_gsmall);
@@ -428,7 +457,7 @@ int shafa_pipe_slot_device(const shafa_pipe *p, int slot) { return (p && slot >=
 
 uint8_t *shafa_pipe_in(shafa_pipe *p, int slot, size_t bytes)
 {
-    if (!p || slot < 0 || slot >= p->n_slots || p->slots[slot].busy) return nullptr;
+    if (!p || slot < 0 || slot >= p->n_slots || p->slots[slot].busy || p->slots[slot].stage) return nullptr;
     Slot &s = p->slots[slot];
     if (grow_pinned(&s.h_in, &s.h_in_cap, bytes ? bytes : 1)) return nullptr;
     return s.h_in;
@@ -439,12 +468,15 @@ int shafa_pipe_submit(shafa_pipe *p, int slot, int op, size_t in_n, const shafa_
 {
     if (!p || slot < 0 || slot >= p->n_slots) return SHAFA_OUTSIDE_MODULE;
     Slot &s = p->slots[slot];
-    if (s.busy || in_n > s.h_in_cap) return SHAFA_OUTSIDE_MODULE;
+    if (s.busy || s.stage || in_n > s.h_in_cap) return SHAFA_OUTSIDE_MODULE;
+    if (op == SHAFA_OP_FTC && !(flags & (SHAFA_PIPE_FTC_RLE | SHAFA_PIPE_FTC_PLAIN))) return SHAFA_OUTSIDE_MODULE;
     s.op = op;
     s.in_n = in_n;
     s.n_symbols = n_symbols;
     s.out_cap = out_cap;
     s.want_in_hist = (flags & SHAFA_PIPE_INPUT_HIST) != 0;
+    s.ftc_flags = flags;
+    s.stage = op == SHAFA_OP_FTC ? 1 : 0;
     s.busy = true;
     s.copied = 0;
     s.out_queued = false;
@@ -466,10 +498,28 @@ int shafa_pipe_wait(shafa_pipe *p, int slot, shafa_pipe_result *res)
         const hipError_t e = hipEventSynchronize(s.ev_out);
         if (e != hipSuccess && !s.rc && !rc) rc = shafa_set_hip_error(e, "shafa_pipe_wait");
     }
-    if (s.rc) return s.rc;
-    if (rc) return rc;
+    if (s.rc || rc) { s.stage = 0; return s.rc ? s.rc : rc; }
     res->out = s.h_out;
+    if (s.op == SHAFA_OP_FTC && s.stage == 2) {          // Module C's payload; the slot is idle again
+        s.stage = 0;
+        res->out = s.h_out2;
+        const size_t sz = (size_t)s.h_small[513];
+        if (sz > s.out_cap || sz > s.h_out2_cap) return SHAFA_LACK_OF_MEMORY;
+        if (sz > s.copied) {
+            HIP_TRY(hipMemcpyAsync(s.h_out2 + s.copied, s.d_out2 + s.copied, sz - s.copied, hipMemcpyDeviceToHost, s.st));
+            HIP_TRY(hipStreamSynchronize(s.st));
+        }
+        p->last_out[SHAFA_OP_SF_ENCODE] = sz;
+        res->out_n = sz;
+        return SHAFA_SUCCESS;
+    }
     switch (s.op) {
+    case SHAFA_OP_FTC:                                   // Module F's results; the slot stays reserved for shafa_pipe_ftc_encode
+        memcpy(res->freq, s.h_small, 256 * sizeof(u64));
+        if (s.ftc_flags & SHAFA_PIPE_FTC_RLE) memcpy(res->freq_in, s.h_small + 256, 256 * sizeof(u64));
+        s.rle_n = (s.ftc_flags & SHAFA_PIPE_FTC_RLE) ? (size_t)s.h_small[512] : 0;
+        if (!(s.ftc_flags & SHAFA_PIPE_FTC_RLE)) { res->out_n = 0; return SHAFA_SUCCESS; }
+        break;
     case SHAFA_OP_HIST:
         memcpy(res->freq, s.h_small, 256 * sizeof(u64));
         return SHAFA_SUCCESS;
@@ -501,11 +551,38 @@ int shafa_pipe_wait(shafa_pipe *p, int slot, shafa_pipe_result *res)
     return SHAFA_SUCCESS;
 }
 
+int shafa_pipe_ftc_encode(shafa_pipe *p, int slot, int use_rle, const shafa_code_table *table, size_t out_cap)
+{
+    if (!p || slot < 0 || slot >= p->n_slots || !table) return SHAFA_OUTSIDE_MODULE;
+    Slot &s = p->slots[slot];
+    if (s.busy || s.stage != 1 || s.op != SHAFA_OP_FTC) return SHAFA_OUTSIDE_MODULE;
+    if (use_rle ? !(s.ftc_flags & SHAFA_PIPE_FTC_RLE) : !(s.ftc_flags & (SHAFA_PIPE_FTC_PLAIN | SHAFA_PIPE_INPUT_HIST)))
+        return SHAFA_OUTSIDE_MODULE;                       // stage one did not leave that form's tile histograms
+    s.stage = 2;
+    s.busy = true;
+    s.copied = 0;
+    s.out_queued = false;
+    s.out_cap = out_cap;
+    s.rc = [&]() -> int {                                  // errors are reported by shafa_pipe_wait, in block order
+        int rc;
+        DeviceGuard dg(s.device);
+        if ((rc = batch_enter(s.batch, s.st))) return rc;
+        if ((rc = grow_dev(&s.d_out2, &s.d_out2_cap, out_cap + 16))) return rc;
+        if ((rc = grow_pinned(&s.h_out2, &s.h_out2_cap, out_cap ? out_cap : 16))) return rc;
+        const u64 off0[1] = {0}, n[1] = {use_rle ? (u64)s.rle_n : (u64)s.in_n}, ocap[1] = {out_cap};
+        if ((rc = sfenc_launch(s.batch, s.st, 1, use_rle ? s.d_out : s.d_in, off0, n, table, s.d_out2, off0, ocap, s.d_small + 513,
+                               use_rle ? s.d_th_rle : s.d_th_in, off0))) return rc;
+        HIP_TRY(hipMemcpyAsync(s.h_small + 513, s.d_small + 513, sizeof(u64), hipMemcpyDeviceToHost, s.st));
+        return pipe_prefetch(s, p->last_out[SHAFA_OP_SF_ENCODE], out_cap, true);
+    }();
+    return SHAFA_SUCCESS;
+}
+
 int shafa_pipe_submit_group(shafa_pipe *p, int slot, int op, int nblocks, const shafa_pipe_block *blocks, int flags)
 {
     if (!p || slot < 0 || slot >= p->n_slots || !blocks || nblocks <= 0 || nblocks > PIPE_GROUP_MAX) return SHAFA_OUTSIDE_MODULE;
     Slot &s = p->slots[slot];
-    if (s.busy) return SHAFA_OUTSIDE_MODULE;
+    if (s.busy || s.stage || op == SHAFA_OP_FTC) return SHAFA_OUTSIDE_MODULE;
     s.op = op;
     s.want_in_hist = (flags & SHAFA_PIPE_INPUT_HIST) != 0;
     s.busy = true;

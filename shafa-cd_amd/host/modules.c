@@ -648,6 +648,16 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
 
 /* ------------------------------------------------------------------ Module T (t.c:246-445) */
 
+static void t_summary(uint64_t n_blocks, const uint64_t *sizes, double ms, const char *p_cod)      /* t.c:219-243 */
+{
+    if (!SHAFA_VERBOSE) return;
+    printf("Module:T (Calculation of symbol codes)\nNumber of blocks: %lu\n"
+           "Size of blocks analyzed in the symbol file: ", (unsigned long)n_blocks);
+    for (uint64_t i = 0; i + 1 < n_blocks; ++i) printf("%lu/", (unsigned long)sizes[i]);
+    if (n_blocks) printf("%lu bytes\n", (unsigned long)sizes[n_blocks - 1]);
+    printf("Module runtime (milliseconds): %f\nGenerated file %s\n", ms, p_cod);
+}
+
 _modules_error get_shafa_codes(const char *path)
 {
     const double t0 = now_ms();
@@ -688,13 +698,7 @@ _modules_error get_shafa_codes(const char *path)
     }
     if (!err && out) fputs("@0", out);                                          /* t.c:395-396 */
     if (out) fclose(out);
-    if (!err && SHAFA_VERBOSE) {
-        printf("Module:T (Calculation of symbol codes)\nNumber of blocks: %lu\n"
-               "Size of blocks analyzed in the symbol file: ", (unsigned long)n_blocks);
-        for (uint64_t i = 0; i + 1 < n_blocks; ++i) printf("%lu/", (unsigned long)sizes[i]);
-        if (n_blocks) printf("%lu bytes\n", (unsigned long)sizes[n_blocks - 1]);
-        printf("Module runtime (milliseconds): %f\nGenerated file %s\n", now_ms() - t0, p_cod);
-    }
+    if (!err) t_summary(n_blocks, sizes, now_ms() - t0, p_cod);
     free(cod); free(sizes); free(p_cod); free(t.buf);
     return (_modules_error)err;
 }
@@ -738,6 +742,16 @@ static uint64_t peek_block_size(const text_t *t, size_t max_payload)
     uint64_t size = 0;
     char *skip = NULL;
     return read_block(&q, &size, &skip, max_payload) ? size : 0;
+}
+
+static void c_summary(uint64_t n_blocks, const uint64_t *in_sizes, const uint64_t *out_sizes, double ms, const char *p_shaf)   /* c.c:282-303 */
+{
+    if (!SHAFA_VERBOSE) return;
+    printf("Module: C (Symbol codes' codification)\nNumber of blocks: %lu\n", (unsigned long)n_blocks);
+    for (uint64_t i = 0; i < n_blocks; ++i)
+        printf("Size before/after & compression rate (Block %lu): %lu/%lu -> %d%%\n", (unsigned long)i,
+               (unsigned long)in_sizes[i], (unsigned long)out_sizes[i], (int)(((float)out_sizes[i] / in_sizes[i]) * 100));
+    printf("Module runtime (milliseconds): %f\nGenerated file %s\n", ms, p_shaf);
 }
 
 _modules_error shafa_compress(char **path)
@@ -837,20 +851,172 @@ _modules_error shafa_compress(char **path)
     if (out >= 0) close(out);
     close(in);
     if (!err) {
-        if (SHAFA_VERBOSE) {
-            printf("Module: C (Symbol codes' codification)\nNumber of blocks: %lu\n", (unsigned long)n_blocks);
-            for (uint64_t i = 0; i < n_blocks; ++i)
-                printf("Size before/after & compression rate (Block %lu): %lu/%lu -> %d%%\n", (unsigned long)i,
-                       (unsigned long)in_sizes[i], (unsigned long)out_sizes[i],
-                       (int)(((float)out_sizes[i] / in_sizes[i]) * 100));
-            printf("Module runtime (milliseconds): %f\nGenerated file %s\n", now_ms() - t0, p_shaf);
-        }
+        c_summary(n_blocks, in_sizes, out_sizes, now_ms() - t0, p_shaf);
         free(*path);
         *path = p_shaf;
         p_shaf = NULL;
     }
     free(p_shaf); free(in_sizes); free(t.buf);
     return (_modules_error)err;
+}
+
+/* ------------------------------------------------------------------ F -> T -> C on one residency of every block
+ * The default `shafa file` (shafa.c:293-298) runs freq_rle_compress, get_shafa_codes and shafa_compress one after the other:
+ * every block is read twice (by F, and as .rle by C) and crosses the link twice.  When the three modules run in one process on
+ * blocks of 2 MiB or more, this driver does their work with ONE upload per block (layer 3: SHAFA_OP_FTC): F on the device,
+ * the block's histogram back (2 KB), Module T here, then Module C from the bytes that are still on the device.  Every file is
+ * what the three modules write — .rle, .rle.freq and / or .freq, .cod, .shaf, in that order per block — and the three
+ * summaries are printed in module order at the end.
+ * Returns SHAFA_FTC_NOT_TAKEN (nothing touched) when the run is not one it takes, and also on ANY error: the caller then runs
+ * the three modules, whose files (rewritten from scratch), messages and exit code are the reference's. */
+int shafa_ftc_compress(char **path, bool force_rle, bool force_freq, unsigned long block_size)
+{
+    if (NO_MULTITHREAD || block_size < (2u << 20)) return SHAFA_FTC_NOT_TAKEN;
+    const double t0 = now_ms();
+    const int in = open(*path, O_RDONLY);
+    if (in < 0) return SHAFA_FTC_NOT_TAKEN;
+    const in_budget whole = budget_of(in);
+    uint64_t bs = block_size, last = 0;
+    const uint64_t size_f = whole.bounded ? whole.size : 0;
+    const uint64_t n_blocks = shafa_block_count(size_f, &bs, &last);
+    if (size_f < SHAFA_1KiB || !n_blocks || bs < (2u << 20)) { close(in); return SHAFA_FTC_NOT_TAKEN; }
+
+    int err = SHAFA_SUCCESS;
+    char *p_rle = shafa_add_ext(*path, SHAFA_RLE_EXT);
+    char *p_rle_freq = p_rle ? shafa_add_ext(p_rle, SHAFA_FREQ_EXT) : NULL;
+    char *p_freq = shafa_add_ext(*path, SHAFA_FREQ_EXT);
+    char *p_cod = NULL, *p_shaf = NULL;                 /* named once block 0 has decided: X[.rle].cod / .shaf */
+    uint64_t *sizes = malloc(n_blocks * 4 * sizeof(uint64_t));
+    uint64_t *rle_sizes = sizes ? sizes + n_blocks : NULL, *enc_in = sizes ? sizes + 2 * n_blocks : NULL,
+             *enc_out = sizes ? sizes + 3 * n_blocks : NULL;
+    char *cod = malloc(SHAFA_COD_BLOCK_MAX + 2);
+    shafa_pipe_result *res = malloc(sizeof(*res));
+    FILE *f_rle_freq = NULL, *f_freq = NULL, *f_cod = NULL;
+    int f_rle = -1, f_shaf = -1;
+    bool use_rle = true;
+    shafa_pipe *pipe = NULL;
+    if (!p_rle || !p_rle_freq || !p_freq || !sizes || !cod || !res) err = SHAFA_LACK_OF_MEMORY;
+    if (!err) err = pipe_get(pipe_depth(n_blocks), &pipe);
+    const uint64_t depth = pipe ? (uint64_t)shafa_pipe_slots(pipe) : 1;
+    double t_f = 0, t_t = 0;                            /* time spent in the F and T parts (the C summary gets the rest) */
+
+    /* sub1: blocks whose F stage was submitted; ret1: whose F stage was retired (T done, C stage submitted); ret2: done.
+       Block 0 goes alone until its RLE size has decided for the file (f.c:250-258). */
+    uint64_t sub1 = 0, ret1 = 0, ret2 = 0, tk_rle[PIPE_SLOTS] = {0}, tk_shaf[PIPE_SLOTS] = {0};
+    writer_t wr_rle, wr_shaf;
+    writer_start(&wr_rle);
+    writer_start(&wr_shaf);
+    while (!err && ret2 < n_blocks) {
+        if (sub1 < n_blocks && sub1 - ret2 < depth && (sub1 == 0 || ret1 > 0)) {
+            const uint64_t n = (sub1 + 1 == n_blocks) ? last : bs;
+            const int slot = (int)(sub1 % depth);
+            uint8_t *buf = shafa_pipe_in(pipe, slot, n);
+            if (!buf) { err = SHAFA_LACK_OF_MEMORY; break; }
+            sizes[sub1] = n;
+            if (!par_io(in, buf, n, (off_t)(sub1 * bs), false)) { err = SHAFA_FILE_STREAM_FAILED; break; }
+            int flags;
+            if (sub1 == 0) flags = SHAFA_PIPE_FTC_RLE | SHAFA_PIPE_FTC_PLAIN | SHAFA_PIPE_INPUT_HIST;
+            else if (use_rle) flags = SHAFA_PIPE_FTC_RLE | (force_freq ? SHAFA_PIPE_INPUT_HIST : 0);
+            else flags = SHAFA_PIPE_FTC_PLAIN;
+            if ((err = writer_wait(&wr_rle, tk_rle[slot])) || (err = writer_wait(&wr_shaf, tk_shaf[slot]))) break;
+            err = shafa_pipe_submit(pipe, slot, SHAFA_OP_FTC, n, NULL, 0, 0, flags);
+            ++sub1;
+            continue;
+        }
+        if (ret1 < sub1) {                              /* F's results of block ret1; its codes; its C stage */
+            const uint64_t bk = ret1, n = sizes[bk];
+            const int slot = (int)(bk % depth);
+            const double ta = now_ms();
+            if ((err = shafa_pipe_wait(pipe, slot, res))) break;
+            if (bk == 0) {                              /* f.c:250-295 */
+                use_rle = shafa_rle_worthwhile(n, res->out_n, force_rle);
+                char head[48];
+                off_t o0 = 0;
+                if (use_rle) {
+                    f_rle = out_open(p_rle, NULL, &o0);
+                    f_rle_freq = fopen(p_rle_freq, "wb");
+                    if (f_rle < 0 || !f_rle_freq) { err = SHAFA_FILE_INACCESSIBLE; break; }
+                    writer_target(&wr_rle, f_rle, 0);
+                    if (fprintf(f_rle_freq, "@R@%lu", (unsigned long)n_blocks) < 4) { err = SHAFA_FILE_STREAM_FAILED; break; }
+                }
+                if (!use_rle || force_freq) {
+                    f_freq = fopen(p_freq, "wb");
+                    if (!f_freq) { err = SHAFA_FILE_INACCESSIBLE; break; }
+                    if (fprintf(f_freq, "@N@%lu", (unsigned long)n_blocks) < 4) { err = SHAFA_FILE_STREAM_FAILED; break; }
+                }
+                const char *stem = use_rle ? p_rle : *path;
+                p_cod = shafa_add_ext(stem, SHAFA_CODES_EXT);
+                p_shaf = shafa_add_ext(stem, SHAFA_SHAFA_EXT);
+                f_cod = p_cod ? fopen(p_cod, "wb") : NULL;
+                snprintf(head, sizeof(head), "@%lu", (unsigned long)n_blocks);                 /* c.c:351 */
+                f_shaf = p_shaf ? out_open(p_shaf, head, &o0) : -1;
+                if (!p_cod || !p_shaf) { err = SHAFA_LACK_OF_MEMORY; break; }
+                if (!f_cod || f_shaf < 0) { err = SHAFA_FILE_INACCESSIBLE; break; }
+                writer_target(&wr_shaf, f_shaf, o0);
+                if (fprintf(f_cod, "@%c@%lu", use_rle ? 'R' : 'N', (unsigned long)n_blocks) < 3) { err = SHAFA_FILE_STREAM_FAILED; break; }   /* t.c:302 */
+            }
+            const bool last_blk = bk + 1 == n_blocks;
+            const bool ran_rle = bk == 0 || use_rle;    /* stage one's layout: freq = of the RLE bytes, freq_in = of the input */
+            const uint64_t *freq_enc = use_rle ? res->freq : (ran_rle ? res->freq_in : res->freq);
+            if (use_rle) {
+                rle_sizes[bk] = res->out_n;
+                tk_rle[slot] = writer_push(&wr_rle, NULL, res->out, res->out_n);
+                if ((err = put_freq_block(f_rle_freq, res->out_n, res->freq, last_blk))) break;
+            }
+            if (!use_rle || force_freq)                 /* make_freq of the original, f.c:325 */
+                if ((err = put_freq_block(f_freq, n, ran_rle ? res->freq_in : res->freq, last_blk))) break;
+            const double tb = now_ms();
+            t_f += tb - ta;
+            /* Module T (t.c:335-361) on the histogram of the bytes that are encoded */
+            const uint64_t enc_n = use_rle ? res->out_n : n;
+            shafa_code_table tab;
+            shafa_sf_build_codes(freq_enc, &tab);
+            const size_t cn = shafa_cod_format(&tab, cod);
+            if (fprintf(f_cod, "@%lu@", (unsigned long)enc_n) < 2 || fwrite(cod, 1, cn, f_cod) != cn) { err = SHAFA_FILE_STREAM_FAILED; break; }
+            if (last_blk && fputs("@0", f_cod) < 0) { err = SHAFA_FILE_STREAM_FAILED; break; }      /* t.c:395-396 */
+            t_t += now_ms() - tb;
+            /* Module C (c.c:91-237) from the bytes on the device */
+            unsigned lmax = 0;
+            for (int q = 0; q < 256; ++q) lmax = tab.len[q] > lmax ? tab.len[q] : lmax;
+            enc_in[bk] = enc_n;
+            err = shafa_pipe_ftc_encode(pipe, slot, use_rle, &tab, (size_t)((enc_n * (uint64_t)lmax + 7) / 8) + 16);
+            ++ret1;
+            continue;
+        }
+        {                                               /* Module C's payload of block ret2 (c.c:256-258) */
+            const int slot = (int)(ret2 % depth);
+            if ((err = shafa_pipe_wait(pipe, slot, res))) break;
+            enc_out[ret2] = res->out_n;
+            char hdr[40];
+            snprintf(hdr, sizeof(hdr), "@%lu@", (unsigned long)res->out_n);
+            tk_shaf[slot] = writer_push(&wr_shaf, hdr, res->out, res->out_n);
+            ++ret2;
+        }
+    }
+    {
+        const int e1 = writer_stop(&wr_rle), e2 = writer_stop(&wr_shaf);
+        if (!err) err = e1 ? e1 : e2;
+    }
+    pipe_put(pipe, err);
+    free(res); free(cod);
+    if (f_rle >= 0) close(f_rle);
+    if (f_shaf >= 0) close(f_shaf);
+    if (f_rle_freq && fclose(f_rle_freq) && !err) err = SHAFA_FILE_STREAM_FAILED;
+    if (f_freq && fclose(f_freq) && !err) err = SHAFA_FILE_STREAM_FAILED;
+    if (f_cod && fclose(f_cod) && !err) err = SHAFA_FILE_STREAM_FAILED;
+    close(in);
+    if (!err) {
+        const double total = now_ms() - t0;
+        const bool wrote_freq = !use_rle || force_freq;
+        f_summary(n_blocks, sizes, size_f, rle_sizes, t_f, use_rle ? p_rle : NULL, wrote_freq ? p_freq : NULL, use_rle ? p_rle_freq : NULL);
+        t_summary(n_blocks, enc_in, t_t, p_cod);
+        c_summary(n_blocks, enc_in, enc_out, total - t_f - t_t, p_shaf);
+        free(*path);
+        *path = p_shaf;
+        p_shaf = NULL;
+    }
+    free(p_rle); free(p_rle_freq); free(p_freq); free(p_cod); free(p_shaf); free(sizes);
+    return err ? SHAFA_FTC_NOT_TAKEN : SHAFA_SUCCESS;
 }
 
 /* ------------------------------------------------------------------ Module D (d.c:232-388, 628-834) */

@@ -63,14 +63,25 @@ static bool parse_args(int argc, char *const argv[], options *o, const char **fi
 static int run_modules(const options *o, char **file)
 {
     int err;
-    if (o->f) {
+    /* f, t and c in one process (the default run, shafa.c:293-298): one upload per block where the blocks are large;
+       SHAFA_FTC=0 keeps the three separate passes */
+    bool ftc_done = false;
+    if (o->f && o->t && o->c) {
+        const char *e = getenv("SHAFA_FTC");
+        if (!(e && *e == '0')) ftc_done = shafa_ftc_compress(file, o->force_rle, o->force_freq, o->block_size) == SHAFA_SUCCESS;
+        if (e && *e == '2' && !ftc_done) {             /* (tests: the one-upload driver must have done the run) */
+            fputs("SHAFA_FTC=2: the F -> T -> C driver did not take this run\n", stderr);
+            return SHAFA_OUTSIDE_MODULE;
+        }
+    }
+    if (o->f && !ftc_done) {
         err = freq_rle_compress(file, o->force_rle, o->force_freq, o->block_size);
         if (err) {
             fputs("Module f: Something went wrong while compressing with RLE or creating frequencies' table...\n", stderr);
             return err;
         }
     }
-    if (o->t) {
+    if (o->t && !ftc_done) {
         if (!o->f) {                       /* -m t alone works on X.freq and strips the suffix */
             if (!shafa_has_ext(*file, SHAFA_FREQ_EXT)) {
                 fprintf(stderr, "Module t: Wrong extension... Should end in %s\n", SHAFA_FREQ_EXT);
@@ -84,7 +95,7 @@ static int run_modules(const options *o, char **file)
         err = get_shafa_codes(*file);
         if (err) { fputs("Module t: Something went wrong...\n", stderr); return err; }
     }
-    if (o->c) {
+    if (o->c && !ftc_done) {
         if (o->f && !o->t) {
             fputs("Module c: Can't execute module 'c' after 'f' without 't'...\n", stderr);
             return SHAFA_OUTSIDE_MODULE;

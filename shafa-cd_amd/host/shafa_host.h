@@ -65,6 +65,12 @@ bool shafa_rle_worthwhile(uint64_t n0, uint64_t rle0, bool force_rle);
 /* d.h:14 */ _modules_error shafa_decompress(char **path, bool decompress_rle);
 /* d.h:22 */ _modules_error rle_decompress(char **path);
 
+/* F, T and C of the default run with one upload per block (blocks of 2 MiB or more, all three modules in one process):
+ * the same files and summaries as the three calls above.  SHAFA_FTC_NOT_TAKEN: not such a run, or something failed — the
+ * caller runs the three modules (which rewrite every file and report the error as the reference does). */
+#define SHAFA_FTC_NOT_TAKEN (-1)
+int shafa_ftc_compress(char **path, bool force_rle, bool force_freq, unsigned long block_size);
+
 /* The module drivers keep one block pipeline (streams, pinned and device buffers) between calls of a process; this
  * releases it (no reference counterpart: the reference allocates per block). */
 void shafa_host_release(void);

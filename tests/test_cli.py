@@ -192,6 +192,23 @@ def test_cli_with_a_full_nodes_slot_count(case, tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["2", "0"])
+@pytest.mark.parametrize("case", ["full_zipf_M", "full_skewed_blocks_m", "full_uniform_m", "full_single_run_M"])
+def test_cli_default_run_one_upload_per_block(case, mode, tmp_path, monkeypatch):
+    """`shafa file -b m|M` runs f, t and c in one process (shafa.c:293-298): host/modules.c shafa_ftc_compress does them with ONE
+    upload per block (layer 3 SHAFA_OP_FTC: F on the device, T on the host, C from the bytes still on the device).
+    SHAFA_FTC=2: that driver must have done the run; SHAFA_FTC=0: the three separate passes.  Either way every file and
+    summary is the reference's (RLE accepted and rejected by block 0, a ragged last block, a single-run block)."""
+    monkeypatch.setenv("SHAFA_FTC", mode)
+    work = scratch_dir(tmp_path, case)
+    try:
+        _replay_and_check(case, work)
+    finally:
+        if work != str(tmp_path):
+            shutil.rmtree(work, ignore_errors=True)
+
+
+@pytest.mark.gpu
 def test_cli_device_list_errors_are_reported(tmp_path):
     """SHAFA_DEVICES naming a GPU the node does not have (or garbage) is an error message and exit 1 before any module
     runs — not a silent fall-back to device 0; a valid list works; Module T alone ignores the variable (it touches no GPU)."""
