@@ -1,27 +1,19 @@
 // sf_decode.hip — Module D hot path: Shannon-Fano (prefix-code) decode on gfx950.
 //
-// Replaces create_tree + shafa_block_decompressor (reference d.c:466-551): a bit-serial tree walk
-// that stops after block_size symbols.  The .shaf format has no sync markers, so decoding a 64 MiB
-// block in parallel needs the codeword boundaries first.  They are found EXACTLY (no speculation):
+// Replaces create_tree + shafa_block_decompressor (reference d.c:466-551): a bit-serial tree walk that stops after
+// block_size symbols.  The .shaf format has no sync markers, so decoding a 64 MiB block in parallel needs the codeword
+// boundaries first:   next(p) = p + len(code that starts at bit p)   is a function graph over the stream's bit positions,
+// the true boundaries are the path from bit 0.  The stream is cut into 256-bit chunks (256 chunks = one 8 KiB tile); a
+// chunk's ENTRY is the offset of the first code that starts in it (< Lmax), its COUNT the number of codes that start in it.
+// Every launch goes   entries + counts  ->  sfd_offsets (scan of the tile counts)  ->  symbol pass:
 //
-//   next(p) = p + len(code that starts at bit p)     for every bit position p of the stream
+//   code class (per launch)                 entries + counts                                   symbols
+//   complete, Lmax <= 16 (Module T's)       sfd_scan (speculative, verified exactly; here)     sfd_wstage (here)
+//                                           else exact: sfd_sync16 .. sfd_countfsm (sfd_dp.hpp)
+//   complete, 16 < Lmax <= 32               sfd_scan<.., 2>, else sfd_sync32 / sfd_countfsm32  sfd_wstage<2>
+//   anything else (hand-made .cod)          sfd_sync / sfd_tiles / sfd_count (sfd_generic.hpp) sfd_write
 //
-// is a function graph; the true boundaries are the path from bit 0.  The stream is cut into 256-bit
-// chunks (one per lane, 256 chunks = one 8 KiB tile).  For a chunk starting at bit s the "entry" is
-// d = (first boundary >= s) - s, always < Lmax (max code length).  A backward dynamic programme over
-// the chunk's 256 bit positions gives exit(p) = entry of the NEXT chunk when p is a boundary, i.e.
-// the chunk's transition map T: entry -> next entry, for all Lmax entries at once, at a cost that does
-// not depend on Lmax or on how well the code self-synchronises (near-fixed-length codes of uniform
-// data never do).  Maps are then chased: lanes -> waves -> tiles -> block, which yields every chunk's
-// true entry; each chunk decodes its own symbols from there (count pass, scan, write pass).
-//
-//   sfd_sync    : DP per chunk, chunk maps + tile maps            (reads the stream once)
-//   sfd_tiles   : per block, chase the tile maps -> tile entries
-//   sfd_count   : chunk entries from the chunk maps, decode + count symbols per chunk
-//   sfd_offsets : per block, exclusive scan of tile counts -> output offsets (and "too short" check)
-//   sfd_write   : decode again and store the symbols
-//
-// Codes longer than the 11-bit LUT fall back to a bit-serial trie walk (any length up to 255).
+// This file: the two kernels the time goes to on ordinary data (sfd_scan, sfd_wstage), sfd_offsets, and the launcher.
 // Algorithmic HBM bytes per block: sf_n read + n_symbols written.
 #include <type_traits>
 #include "common.hpp"
@@ -35,1138 +27,11 @@
 
 #include <stdlib.h>
 
+#include "sfd_common.hpp"
+#include "sfd_dp.hpp"
+#include "sfd_generic.hpp"
+
 namespace {
-
-constexpr int DEC_THREADS = 256;
-constexpr int CH_BYTES = 32;                       // chunk = 256 bits per lane
-constexpr int CH_BITS = CH_BYTES * 8;
-constexpr int DTILE = DEC_THREADS * CH_BYTES;      // 8 KiB of stream per tile
-constexpr int HALO_WORDS = 16;                     // 64 bytes past the tile (windows + trie walks)
-constexpr int DATA_WORDS = DTILE / 4 + HALO_WORDS;
-constexpr int LUT_MAXK = 11;
-constexpr int LUT2_MAX = 4096;                     // level-2 entries kept in LDS (8 KiB)
-constexpr int SPEC_MINW = 1;                       // narrowest window of the counting table of sfd_spec (1 = the longest code's
-                                                   // length; measured on Lmax = 10 data: 11 bits no gain, 12 bits 3 % slower:
-                                                   // fewer steps, but an 8 KiB table costs two workgroups per CU)
-constexpr int SYM3_MINW = 1;                       // narrowest window of the three-symbols table of sfd_wstage (1 = the longest
-                                                   // code; 12 on Lmax = 10 data: 14 % fewer look-ups, but a 16 KiB table leaves
-                                                   // four workgroups per CU instead of six: decode 10.1 -> 11.1 ms)
-constexpr int SYM3_MAXK = 12;                      // widest window of the three-codes table of sfd_wstage: 16 KiB
-constexpr int LDS_DATA = (DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
-constexpr int LONG_PFX = 128;                      // codes longer than SYM3_MAXK bits, grouped by their first SYM3_MAXK bits
-constexpr int LONG_BYTES = 16 + LONG_PFX * 2 + LONG_PFX * 16 * 2;   // [n u16 x8 pad][pfx u16 x128][ent u16 x128x16]
-// codes of 13..32 bits: [n u16 x8 pad][pfx u16 x128][root u16 x128][nodes {child0, child1} u16 x2 x256]; child = node | 0x8000|sym
-constexpr int LONG32_BYTES = 16 + LONG_PFX * 2 + LONG_PFX * 2 + 256 * 4 + LONG_PFX * 2;   // + root13 u16 x128 (13-bit prefixes)
-constexpr int LEN_MAXK = 13;                       // length-only LUT of the packed DP: 8 KiB
-
-struct DecBlk {
-    const u8 *in;
-    u8 *out;
-    u64 in_n;
-    u64 n_sym;
-    int *err;
-    const u16 *lut;        // level 1, 2^K entries: sym | len << 8 ; 0x8000 | (nb-1) << 12 | base = level-2
-                           //   group (next nb bits index lut2[base..]) ; 0 = go to the trie
-    const u16 *lut2;       // level 2 (codes of K+1 .. K+8 bits): sym | len << 8 ; 0 = go to the trie
-    const u8 *lenlut;      // 2^K1 entries: len only (DP of the packed path); 0 = longer than K1 bits
-    u16 *cnt3;             // sfd_scan's tables, 2^KW bytes each: [total bits | codes << 5 of the whole codes (at most 7) in a
-                           // window] then [length of the window's first code]
-    u32 *sym3;             // 2^K3 entries: sym0 | sym1 << 8 | sym2 << 16 | total bits << 24 (6 bits) | n << 30
-    u8 *pairlut;           // 2^(K1+1) entries: (len(p)-1) | (len(p+1)-1) << 4 from a K1+1-bit window (complete codes)
-    const u16 *lut13;      // 2^K1 entries: sym | len << 8, single level (only when Lmax <= 13), else NULL
-    const u32 *trie;       // pairs {child0, child1}: 0x80000000|sym = leaf, 0xFFFFFFFF = missing
-    u32 K;
-    u32 K1;
-    u32 lmax;
-    u32 tile_base;         // first tile of this block in the per-tile arrays
-    u32 n_tiles;
-    u32 n_l2;              // level-2 entries
-    u32 n_states;          // internal trie nodes = states of the counting automaton (<= 255 for a complete code)
-    u32 KW;                // window of sfd_spec's counting tables (spec_window(K1), or 12 for 13-bit tables whose 13-bit codes are few)
-    u32 *fsm4;             // [state][nibble]: next state * 64 | codes completed << 16   (complete codes; sfd_tables)
-    u32 *fsm1;             // [state][bit]   : same, for one bit
-    const u8 *lenlut32;    // 2^13 entries: len <= 13, or 128 + k = internal node root13[k] of long32 (16 < Lmax <= 32 launches)
-    const u16 *long32;     // LONG32_BYTES: sorted 12-bit prefixes of the codes of 13..32 bits + their sub-tries
-    const u16 *longtab;    // LONG_BYTES: sorted 12-bit prefixes of the codes of 13..16 bits + 16 entries sym | len << 8 each
-    u32 *run_dp;           // speculative launches: *run_dp != 0 <=> the block needs the exact (DP) kernels: it was not
-                           //   tried speculatively or did not verify; NULL: no speculation, the DP kernels always run
-};
-
-// window of the code-counting table of sfd_spec: wider than the longest code when that is short (more bits per look-up)
-__host__ __device__ __forceinline__ u32 spec_window(u32 K1) { return K1 < (u32)SPEC_MINW ? (u32)SPEC_MINW : K1; }
-// window of the three-symbols table of sfd_wstage
-__host__ __device__ __forceinline__ u32 sym3_window(u32 K1)
-{
-    const u32 k = K1 < (u32)SYM3_MINW ? (u32)SYM3_MINW : K1;
-    return k < (u32)SYM3_MAXK ? k : (u32)SYM3_MAXK;
-}
-
-// the exact kernels of a launch that also runs the speculative ones: skip the blocks that verified
-__device__ __forceinline__ bool dp_skipped(const DecBlk &blk)
-{
-    return blk.run_dp && __hip_atomic_load(blk.run_dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-}
-// the same question before the block record is copied (the usual answer is "skipped": read one pointer, not the record)
-__device__ __forceinline__ bool dp_skipped_early(const DecBlk *p)
-{
-    u32 *const rd = p->run_dp;
-    return rd && __hip_atomic_load(rd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-}
-
-// stream words are kept big-endian in LDS, one pad word per 8 (chunk stride 9 words: no bank conflicts)
-__device__ __forceinline__ u32 widx(u32 w) { return w + (w >> 3); }
-
-struct Code { u32 len; u32 sym; bool ok; };
-
-// length (and symbol) of the code that starts at tile-local bit position p
-__device__ __forceinline__ Code code_at(const u32 *data, const u16 *lut, const u32 *trie, u32 K, u32 p,
-                                        bool trie_only = false)
-{
-    const u32 w = p >> 5, r = p & 31;
-    const u64 two = ((u64)data[widx(w)] << 32) | data[widx(w + 1)];
-    const u32 win = (u32)((two << r) >> 32);
-    u32 e = trie_only ? 0u : lut[win >> (32 - K)];
-    Code c;
-    if (e & 0x8000u) {                              // codes of K+1..K+8 bits: one more table
-        const u32 nb = ((e >> 12) & 7u) + 1;
-        e = lut[(1u << LUT_MAXK) + (e & 0xFFFu) + ((win << K) >> (32 - nb))];
-    }
-    if (e) { c.len = e >> 8; c.sym = e & 0xFF; c.ok = true; return c; }
-    // slow path: walk the trie bit by bit (codes longer than K bits, or an incomplete tree)
-    u32 node = 0, q = p, depth = 0;
-    for (;;) {
-        const u32 bit = (data[widx(q >> 5)] >> (31 - (q & 31))) & 1u;
-        const u32 nx = trie[2 * node + bit];
-        ++q; ++depth;
-        if (nx == 0xFFFFFFFFu) { c.len = 1; c.sym = 0; c.ok = false; return c; }
-        if (nx & 0x80000000u) { c.len = depth; c.sym = nx & 0xFF; c.ok = true; return c; }
-        node = nx;
-        if (depth >= 255) { c.len = 1; c.sym = 0; c.ok = false; return c; }
-    }
-}
-
-// stage one tile (+halo) of the stream into LDS as big-endian words; bytes past in_n read as zero
-__device__ __forceinline__ void load_tile(u32 *data, const DecBlk &blk, u32 tile, u32 t = threadIdx.x)
-{
-    // all of a lane's pieces are requested before the first is used (three loads in flight, not three round trips)
-    const u64 base = (u64)tile * DTILE;
-    constexpr u32 UNITS = DATA_WORDS / 4, NIT = (UNITS + DEC_THREADS - 1) / DEC_THREADS;
-    uint4 v[NIT];
-#pragma unroll
-    for (u32 it = 0; it < NIT; ++it) {
-        const u32 i = t + it * DEC_THREADS;
-        const u64 off = base + (u64)i * 16;
-        v[it] = make_uint4(0, 0, 0, 0);
-        if (i < UNITS && off + 16 <= blk.in_n) v[it] = gload<uint4>(blk.in + off);
-    }
-#pragma unroll
-    for (u32 it = 0; it < NIT; ++it) {
-        const u32 i = t + it * DEC_THREADS;
-        if (i >= UNITS) break;
-        const u64 off = base + (u64)i * 16;
-        u32 w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
-        if (off < blk.in_n && off + 16 > blk.in_n) {    // the piece the stream ends in
-            const int nv = (int)(blk.in_n - off);
-#pragma unroll
-            for (int q = 0; q < 16; ++q)
-                if (q < nv) w[q >> 2] |= (u32)gload<u8>(blk.in + off + q) << (8 * (q & 3));
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) data[widx(4 * i + q)] = bswap32(w[q]);
-    }
-}
-
-__device__ __forceinline__ void load_lut(u16 *lut, const DecBlk &blk)
-{
-    const u32 n32 = (1u << blk.K) / 2;            // K >= 1
-    for (u32 i = threadIdx.x; i < (n32 ? n32 : 1); i += DEC_THREADS)
-        ((u32 *)lut)[i] = gload<u32>((const u32 *)blk.lut + i);
-    u32 *l2 = (u32 *)(lut + (1u << LUT_MAXK));
-    for (u32 i = threadIdx.x; i < (blk.n_l2 + 1) / 2; i += DEC_THREADS) l2[i] = gload<u32>((const u32 *)blk.lut2 + i);
-}
-
-// ------------------------------------------------------------------------------------------------
-// sfd_sync: chunk maps (global, [tile][d][chunk]) and tile maps ([tile][d])
-// dynamic LDS: data[DATA_WORDS*9/8+8] u32 | ring[R*256] u8 | lut[2^K] u16 | wfn[4*R] u8
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(DEC_THREADS) void sfd_sync(const DecBlk *__restrict__ blks, u32 R, u32 l2cap,
-                                                        u8 *__restrict__ chunkfn, u8 *__restrict__ tilefn)
-{
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const DecBlk blk = blks[blockIdx.y];
-    const u32 tile = blockIdx.x;
-    if (tile >= blk.n_tiles) return;
-    u32 *data = (u32 *)smem;
-    u8 *ring = smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4;
-    u16 *lut = (u16 *)(ring + (size_t)R * DEC_THREADS);
-    u8 *wfn = (u8 *)(lut + (1u << LUT_MAXK) + l2cap);
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 lmax = blk.lmax, K = blk.K, Rm = R - 1;
-
-    load_tile(data, blk, tile);
-    load_lut(lut, blk);
-    __syncthreads();
-
-    // backward DP over the chunk's bit positions: ring[(p mod R)][tid] = exit(p)
-    const u32 cbase = tid * CH_BITS;
-    for (int p = CH_BITS - 1; p >= 0; --p) {
-        const Code c = code_at(data, lut, blk.trie, K, cbase + (u32)p);
-        const u32 nx = (u32)p + c.len;
-        u32 x;
-        if (nx >= (u32)CH_BITS) x = nx - CH_BITS;
-        else x = ring[((nx & Rm) << 8) + tid];
-        ring[(((u32)p & Rm) << 8) + tid] = (u8)x;
-    }
-    __syncthreads();
-
-    // chunk maps to global: rows d < lmax, 256 bytes each (coalesced)
-    u8 *cf = chunkfn + ((size_t)(blk.tile_base + tile) * R << 8);
-    for (u32 i = tid; i < lmax * (DEC_THREADS / 4); i += DEC_THREADS)
-        ((u32 *)cf)[i] = ((const u32 *)ring)[i];
-
-    // wave maps: lane d chases entry d through the wave's 64 chunks (d < lmax, in groups of 64)
-    for (u32 d0 = 0; d0 < lmax; d0 += 64) {
-        const u32 d = d0 + lane;
-        u32 v = d < lmax ? d : 0;
-        for (u32 c = 0; c < 64; ++c) v = ring[(v << 8) + wv * 64 + c];
-        if (d < lmax) wfn[wv * R + d] = (u8)v;
-    }
-    __syncthreads();
-    // tile map = wave 0 then 1, 2, 3
-    u8 *tf = tilefn + (size_t)(blk.tile_base + tile) * R;
-    for (u32 d = tid; d < lmax; d += DEC_THREADS) {
-        u32 v = d;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) v = wfn[w * R + v];
-        tf[d] = (u8)v;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// sfd_tiles: per block, chase the tile maps from entry 0 -> entry of every tile
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(DEC_THREADS) void sfd_tiles(const DecBlk *__restrict__ blks, u32 R,
-                                                         const u8 *__restrict__ tilefn, u8 *__restrict__ tile_entry)
-{
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];   // 256 * R bytes of maps + 256 entries
-    __shared__ u8 segmap[8 * 32], segent[8];
-    if (dp_skipped_early(blks + blockIdx.x)) return;    // the block's speculative entries verified
-    const DecBlk blk = blks[blockIdx.x];
-    u8 *maps = smem;
-    u8 *ent = smem + (size_t)R * DEC_THREADS;
-    const u32 tid = threadIdx.x;
-    u32 v = 0;                                   // carried by thread 0
-    for (u32 t0 = 0; t0 < blk.n_tiles; t0 += DEC_THREADS) {
-        const u32 nt = (blk.n_tiles - t0 < (u32)DEC_THREADS) ? blk.n_tiles - t0 : (u32)DEC_THREADS;
-        const u8 *src = tilefn + (size_t)(blk.tile_base + t0) * R;
-        for (u32 i = tid; i < nt * R / 4; i += DEC_THREADS) ((u32 *)maps)[i] = ((const u32 *)src)[i];
-        __syncthreads();
-        if (R == 32) {
-            // thread (sg, d) follows entry d through segment sg (32 tiles), thread 0 links the 8 segments, then one
-            // thread per segment walks it from its real entry: 32 + 8 + 32 dependent reads instead of 256
-            const u32 sg = tid >> 5, d = tid & 31u, lo = sg * 32 < nt ? sg * 32 : nt, hi = lo + 32 < nt ? lo + 32 : nt;
-            u32 x = d;
-            for (u32 t = lo; t < hi; ++t) x = maps[t * R + (x & 31u)];
-            segmap[sg * 32 + d] = (u8)x;
-            __syncthreads();
-            if (tid == 0) {
-                for (u32 q = 0; q < 8; ++q) { segent[q] = (u8)v; v = segmap[q * 32 + (v & 31u)]; }
-            }
-            __syncthreads();
-            if (d == 0) {
-                u32 y = segent[sg];
-                for (u32 t = lo; t < hi; ++t) { ent[t] = (u8)y; y = maps[t * R + (y & 31u)]; }
-            }
-        } else if (tid == 0) {
-            for (u32 t = 0; t < nt; ++t) { ent[t] = (u8)v; v = maps[t * R + v]; }
-        }
-        __syncthreads();
-        if (tid < nt) tile_entry[blk.tile_base + t0 + tid] = ent[tid];
-        __syncthreads();
-    }
-}
-
-// ================================================================================================
-// Packed path (every block of the launch has Lmax <= 16): a chunk map is 16 nibbles in one u64,
-// the DP ring lives in registers, code lengths come from a byte LUT of up to 13 index bits.
-// ================================================================================================
-
-// code length at tile-local bit p by trie walk (codes longer than the LUT index, or missing branch: 1)
-__device__ __noinline__ u32 slow_len(const u32 *data, const u32 *trie, u32 p)
-{
-    u32 node = 0, q = p, depth = 0;
-    for (;;) {
-        const u32 bit = (data[widx(q >> 5)] >> (31 - (q & 31))) & 1u;
-        const u32 nx = trie[2 * node + bit];
-        ++q; ++depth;
-        if (nx == 0xFFFFFFFFu) return 1;
-        if (nx & 0x80000000u) return depth;
-        node = nx;
-        if (depth >= 255) return 1;
-    }
-}
-
-__device__ __forceinline__ u32 nib(u64 m, u32 v) { return (u32)(m >> (4 * v)) & 15u; }
-
-// ring = (ring << 4) | nibble (sh4 >> 2) of ring; only bits 2..5 of sh4 matter.  v_bfi merges the and + or.
-__device__ __forceinline__ u64 ring_push(u64 ring, u32 sh4)
-{
-    const u32 x = (u32)(ring >> (sh4 & 60u));
-    const u64 up = ring << 4;
-    u32 lo;
-    asm("v_bfi_b32 %0, 15, %1, %2" : "=v"(lo) : "v"(x), "v"((u32)up));
-    return (up & 0xFFFFFFFF00000000ull) | lo;
-}
-
-// packed 16-entry maps: (a then b)[d] = b[a[d]]
-__device__ __forceinline__ u64 map_compose(u64 a, u64 b)
-{
-    u64 r = 0;
-#pragma unroll
-    for (int d = 0; d < 16; ++d) r |= (u64)nib(b, nib(a, (u32)d)) << (4 * d);
-    return r;
-}
-
-// Quarter chase over one wave's 64 chunk maps (LDS, wave-private slice `cmw`): lane (q = lane >> 4, d = lane & 15)
-// follows entry d through the 16 chunks of quarter q.  Returns Q_q[d]; when HIST, *hist gets the entry seen at each
-// of the 16 chunks (nibble c).  16 dependent LDS reads instead of 64, all 64 lanes busy.
-template <bool HIST>
-__device__ __forceinline__ u32 quarter_chase(const u64 *cmw, u64 *hist)
-{
-    const u32 lane = lane_id();
-    const u64 *src = cmw + (lane >> 4) * 16;
-    u32 v = lane & 15u, hlo = 0, hhi = 0;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        if (HIST) { if (c < 8) hlo |= v << (4 * c); else hhi |= v << (4 * (c - 8)); }
-        v = nib(src[c], v);
-    }
-    if (HIST) *hist = ((u64)hhi << 32) | hlo;
-    return v;
-}
-// wave map from the four quarter maps held one value per lane (lanes d < 16 return W[d])
-__device__ __forceinline__ u32 wave_map_of(u32 qv)
-{
-    u32 v = lane_id() & 15u;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v = __shfl(qv, q * 16 + (int)v, 64);
-    return v;
-}
-
-// code of 13..16 bits at the head of `win32` (next stream bit at the MSB): binary search of its first 12 bits in
-// the sorted prefix list, then 4 more bits index the group.  Returns sym | len << 8, 0 when there is none.
-__device__ __forceinline__ u32 long_code(const u16 *lt, u32 win32)
-{
-    const u32 n = lt[0], key = win32 >> 20;
-    const u16 *pfx = lt + 8, *ent = lt + 8 + LONG_PFX;
-    u32 lo = 0, hi = n;
-    while (lo < hi) {
-        const u32 mid = (lo + hi) >> 1;
-        if (pfx[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    return (lo < n && pfx[lo] == key) ? ent[lo * 16 + ((win32 >> 16) & 15u)] : 0u;
-}
-
-// code of 13..32 bits at the head of `win32`: binary search of its first 12 bits, then a walk of the sub-trie.
-// Returns sym | len << 8, 0 when there is none.
-__device__ __forceinline__ u32 long_code32(const u16 *lt, u32 win32)
-{
-    const u32 n = lt[0], key = win32 >> 20;
-    const u16 *pfx = lt + 8, *root = lt + 8 + LONG_PFX, *nodes = lt + 8 + 2 * LONG_PFX;
-    u32 lo = 0, hi = n;
-    while (lo < hi) {
-        const u32 mid = (lo + hi) >> 1;
-        if (pfx[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    if (lo >= n || pfx[lo] != key) return 0u;
-    u32 node = root[lo];
-    for (u32 depth = (u32)SYM3_MAXK; depth < 32; ++depth) {
-        const u32 c = nodes[2 * node + ((win32 >> (31 - depth)) & 1u)];
-        if (c & 0x8000u) return (c & 0xFFu) | ((depth + 1) << 8);
-        node = c;
-    }
-    return 0u;
-}
-
-// copy a device table (16-byte aligned, padded to 16 bytes in the workspace) into LDS
-__device__ __forceinline__ void fill_lds16(void *dst, const void *src, u32 bytes)
-{
-    for (u32 i = threadIdx.x; i < (bytes + 15) / 16; i += blockDim.x)
-        ((uint4 *)dst)[i] = gload<uint4>((const uint4 *)src + i);
-}
-
-// sfd_tables: one workgroup per block expands the host tables (complete codes, Lmax <= 13) into
-//   pairlut: the two-positions-per-lookup length table of the DP, and
-//   cnt3 / sym3: up to three whole codes per K1-bit window for the symbol passes.
-__global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restrict__ blks)
-{
-    const DecBlk blk = blks[blockIdx.x];
-    if (!blk.n_tiles) return;
-    // gridDim.y workgroups share a block's tables (an entry is a chain of up to fifteen dependent look-ups in global
-    // memory: one workgroup per block took 45 us for 12-bit tables, as long as the symbol pass of a small launch)
-    const u32 T0 = threadIdx.x + blockIdx.y * DEC_THREADS, TS = DEC_THREADS * gridDim.y;
-    const u32 K1 = blk.K1, mask = (1u << K1) - 1;
-    for (u32 i = T0; blk.pairlut && i < (2u << K1); i += TS)
-        blk.pairlut[i] = (u8)((blk.lenlut[i >> 1] - 1u) | ((blk.lenlut[i & mask] - 1u) << 4));
-    const u32 K3 = sym3_window(K1);
-    const u32 KW = blk.KW, maskw = (1u << KW) - 1;               // the counting window may be wider than the longest code, or
-    for (u32 i = T0; i <= maskw; i += TS) {                      // one bit narrower than the 13-bit table (host: sfdec_launch)
-        u32 pos = 0, n = 0, l0 = 0;
-        for (; n < 7; ++n) {
-            const u32 wv = (i << pos) & maskw;                   // window shifted left, zero filled
-            const u32 L = blk.lut13[KW >= K1 ? wv >> (KW - K1) : wv << (K1 - KW)] >> 8;
-            if (L == 0 || L > KW - pos) break;                   // longer than the window / would use bits outside it
-            if (n == 0) l0 = L;
-            pos += L;
-        }
-        const u32 j = __builtin_bitreverse32(i) >> (32 - KW);    // sfd_spec reads its windows LSB first
-        ((u8 *)blk.cnt3)[j] = (u8)(pos | (n << 5));              // bits in the low five: the sum of a fetch's entries is the next look-up's shift
-        ((u8 *)blk.cnt3)[(1u << KW) + j] = (u8)l0;
-    }
-    for (u32 i = T0; i < (1u << K3); i += TS) {   // K3-bit window; n = 0: first code is longer
-        u32 pos = 0, n = 0, syms = 0;
-        for (; n < 3; ++n) {
-            const u32 e = blk.lut13[K3 >= K1 ? (((i << pos) & ((1u << K3) - 1u)) >> (K3 - K1)) : (((i << (K1 - K3)) << pos) & mask)];
-            const u32 L = e >> 8;
-            if (L == 0 || L > K3 - pos) break;
-            syms |= (e & 0xFFu) << (8 * n);
-            pos += L;
-        }
-        blk.sym3[__builtin_bitreverse32(i) >> (32 - K3)] = syms | (pos << 24) | (n << 30);    // sfd_wstage reads its windows LSB first
-    }
-    // counting automaton: state = internal trie node (0 = root = between two codes); consuming a nibble (or a bit)
-    // moves to the next state and completes 0..4 codes.  next state is stored as the byte offset of its row.
-    for (u32 i = T0; i < blk.n_states * 16; i += TS) {
-        u32 node = i >> 4, done = 0;
-        for (int b = 3; b >= 0; --b) {
-            const u32 c = blk.trie[2 * node + ((i >> b) & 1u)];
-            if (c & 0x80000000u) { ++done; node = 0; } else node = c;
-        }
-        blk.fsm4[i] = (node * 64u) | (done << 16);
-    }
-    for (u32 i = T0; i < blk.n_states * 2; i += TS) {
-        const u32 c = blk.trie[i];
-        blk.fsm1[i] = (c & 0x80000000u) ? (1u << 16) : (c * 64u);
-    }
-}
-
-// sfd_sync16: dynamic LDS: data | lenlut[2^13] u8 (PAIR: pairlut[2^14]) | cmap[256] u64 | wmb[64] u8
-// K1T: the launch's common table width when every block has it (12 or 13: window offsets become constants, a
-// pair window that lies inside one stream word is then a single v_bfe), 0 = per block at run time.
-template <bool PAIR, bool LONG, int K1T = 0>
-__global__ __launch_bounds__(DEC_THREADS) void sfd_sync16(const DecBlk *__restrict__ blks,
-                                                          u64 *__restrict__ chunkfn, u64 *__restrict__ tilefn, u32 tpw)
-{
-    // static LDS: constant addresses fold into the ds_read offset field (no per-lookup address add)
-    // (the chunk maps of a wave live in that wave's own rows of the stream frame, which it is done with by then: with a
-    // separate 2 KiB for them the pair-table form is 27.8 KB, just above the 26 KiB that let six workgroups share a CU)
-    __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + (PAIR ? 2 : 1) * (1 << LEN_MAXK) + 64 + (LONG ? LONG_BYTES : 0)];
-    if (dp_skipped_early(blks + blockIdx.y)) return;
-    const DecBlk blk = blks[blockIdx.y];
-    if (blockIdx.x * tpw >= blk.n_tiles) return;
-    u32 *data = (u32 *)smem;
-    u8 *lenlut = smem + LDS_DATA;
-    u8 *wmb = lenlut + (PAIR ? 2u : 1u) * (1u << LEN_MAXK);
-    const u16 *lt = (const u16 *)(wmb + 64);
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // wave wv's rows are frame words [576 wv, 576 wv + 576); the wave before reads only the first of them (its last
-    // lane's look-ahead word), at the start of its own pass
-    u64 *cmapw = (u64 *)(data + 576u * wv + 16u);
-    const u32 K1 = K1T ? (u32)K1T : blk.K1;
-
-    if (LONG) {                                        // blocks of the launch without long codes: empty list
-        if (blk.longtab) fill_lds16((void *)lt, blk.longtab, LONG_BYTES);
-        else if (tid == 0) *(u16 *)lt = 0;
-    }
-    fill_lds16(lenlut, PAIR ? (const void *)blk.pairlut : (const void *)blk.lenlut, PAIR ? (2u << K1) : (1u << K1));
-    const u32 tile_end = (blockIdx.x + 1) * tpw < blk.n_tiles ? (blockIdx.x + 1) * tpw : blk.n_tiles;
-    for (u32 tile = blockIdx.x * tpw; tile < tile_end; ++tile) {      // one table load serves tpw tiles
-    __syncthreads();                                   // previous tile's LDS reads are done
-    load_tile(data, blk, tile);
-    __syncthreads();
-
-    // backward DP; nibble j of `ring` = exit(p + 1 + j).  Positions 256..271 (the next chunk's first
-    // bits) have exit = their offset, which is the initial ring.
-    u64 ring = 0xFEDCBA9876543210ull;
-    const u32 cw = tid * (CH_BITS / 32);
-    u32 w1 = data[widx(cw + 8)];
-    if (PAIR) {
-        const u32 sh = 31 - K1;                        // K1+1-bit window: positions r and r+1
-        for (int wi = 7; wi >= 0; --wi) {
-            const u32 w0 = data[widx(cw + wi)];
-            u32 e[16];
-#pragma unroll
-            for (int q = 15; q >= 0; --q) {
-                if (K1T && 2 * q + K1T + 1 <= 32) {              // the K1+1-bit window lies inside w0: one bit-field extract
-                    e[q] = lenlut[__builtin_amdgcn_ubfe(w0, 32 - 2 * q - (K1T + 1), K1T + 1)];
-                } else {
-                    const u32 win = q ? __builtin_amdgcn_alignbit(w0, w1, 32 - 2 * q) : w0;
-                    e[q] = lenlut[win >> sh];
-                }
-            }
-#pragma unroll
-            for (int q = 15; q >= 0; --q) {
-                ring = ring_push(ring, e[q] >> 2);            // position 2q+1 (shift = 4 * high nibble)
-                ring = ring_push(ring, e[q] << 2);            // position 2q   (shift = 4 * low nibble)
-            }
-            w1 = w0;
-        }
-    } else {
-        const u32 sh = 32 - K1;
-        for (int wi = 7; wi >= 0; --wi) {
-            const u32 w0 = data[widx(cw + wi)];
-            u32 len[32];
-#pragma unroll
-            for (int r = 31; r >= 0; --r) {
-                const u32 win = r ? __builtin_amdgcn_alignbit(w0, w1, 32 - r) : w0;
-                len[r] = lenlut[win >> sh];
-            }
-#pragma unroll
-            for (int r = 31; r >= 0; --r) {
-                u32 l = len[r];
-                if (__builtin_expect(l == 0, 0)) {
-                    if (LONG) {                        // 14..16 bits: resolved from LDS (complete code: always found)
-                        const u32 win = r ? __builtin_amdgcn_alignbit(w0, w1, 32 - r) : w0;
-                        l = long_code(lt, win) >> 8;
-                        l = l ? l : 1u;
-                    } else {
-                        l = slow_len(data, blk.trie, (cw + wi) * 32 + r);
-                    }
-                }
-                const u32 x = nib(ring, l - 1);
-                ring = (ring << 4) | x;
-            }
-            w1 = w0;
-        }
-    }
-    // ring nibble d = exit(d) = this chunk's map
-    chunkfn[((size_t)blk.tile_base + tile) * DEC_THREADS + tid] = ring;
-    cmapw[lane] = ring;                                // wave-private: no barrier needed before the chase
-    {
-        const u32 w = wave_map_of(quarter_chase<false>(cmapw, nullptr));
-        if (lane < 16) wmb[wv * 16 + lane] = (u8)w;
-    }
-    __syncthreads();
-    if (tid < 16) {
-        u32 v = tid;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) v = wmb[w * 16 + v];
-        u64 m = (u64)v << (4 * tid);
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) m |= __shfl_xor(m, d, 64);
-        if (tid == 0) tilefn[(size_t)blk.tile_base + tile] = m;
-    }
-    }
-}
-
-// ================================================================================================
-// Complete codes with 16 < Lmax <= 32 (rare bytes of real files at -b M).  Entry offsets reach 31, so chunk maps
-// are 32 bytes (the byte-map plumbing of the generic path: sfd_tiles, [tile][d][chunk] layout), but the heavy loops
-// are the fast ones: the DP keeps the low nibble of every exit in the register ring plus one bit per position for
-// "exit >= 16"; a code longer than 16 bits at some bit position (rare: its probability) is followed forward to
-// the end of the chunk instead of being looked up in the ring.
-// ================================================================================================
-__device__ __forceinline__ u32 tile_bit_limit(const DecBlk &blk, u32 tile);
-
-__device__ __forceinline__ u32 win32_at(const u32 *data, u32 p)
-{
-    const u32 w = p >> 5, r = p & 31;
-    const u32 w0 = data[widx(w)], w1 = data[widx(w + 1)];
-    return r ? __builtin_amdgcn_alignbit(w0, w1, 32 - r) : w0;
-}
-
-// length of a code longer than 13 bits: `esc` = 128 + k from lenlut32 names the trie node reached after 13 bits
-__device__ __forceinline__ u32 sync32_long_len(const u16 *lt, u32 esc, u32 win)
-{
-    const u16 *nodes = lt + 8 + 2 * LONG_PFX, *root13 = nodes + 512;
-    u32 node = root13[esc - 128u];
-    for (u32 depth = 13; depth < 32; ++depth) {
-        const u32 c = nodes[2 * node + ((win >> (31 - depth)) & 1u)];
-        if (c & 0x8000u) return depth + 1;
-        node = c;
-    }
-    return 1u;
-}
-
-// static LDS: data | maps[32][256] u8 | lenlut[2^13] u8 | long32 | wfn[4][32] u8
-__global__ __launch_bounds__(DEC_THREADS) void sfd_sync32(const DecBlk *__restrict__ blks, u8 *__restrict__ chunkfn,
-                                                          u8 *__restrict__ tilefn, u32 tpw)
-{
-    constexpr u32 R = 32;
-    __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + R * DEC_THREADS + (1 << LEN_MAXK) + LONG32_BYTES + 4 * R + 64];
-    if (dp_skipped_early(blks + blockIdx.y)) return;    // the block's speculative entries verified
-    const DecBlk blk = blks[blockIdx.y];
-    if (blockIdx.x * tpw >= blk.n_tiles) return;
-    u32 *data = (u32 *)smem;
-    u8 *maps = smem + LDS_DATA;
-    u8 *lenlut = maps + R * DEC_THREADS;
-    const u16 *lt = (const u16 *)(lenlut + (1 << LEN_MAXK));
-    u8 *wfn = (u8 *)lt + LONG32_BYTES;
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 K1 = blk.K1, lmax = blk.lmax, sh = 32 - K1;
-
-    if (blk.long32) fill_lds16((void *)lt, blk.long32, LONG32_BYTES);
-    else if (tid == 0) *(u16 *)lt = 0;
-    fill_lds16(lenlut, blk.lenlut32, 1u << K1);
-    const u32 tile_end = (blockIdx.x + 1) * tpw < blk.n_tiles ? (blockIdx.x + 1) * tpw : blk.n_tiles;
-    for (u32 tile = blockIdx.x * tpw; tile < tile_end; ++tile) {
-    __syncthreads();                                   // previous tile's LDS reads are done
-    load_tile(data, blk, tile);
-    __syncthreads();
-
-    // ring nibble j / hb bit j = low nibble / "exit >= 16" of position p + 1 + j; positions 256 + j exit at j
-    // ring2 nibble j = low nibble of position p + 17 + j (codes of 17..32 bits look there)
-    u64 ring = 0xFEDCBA9876543210ull, ring2 = 0xFEDCBA9876543210ull, mapB = 0;
-    u32 hb = 0xFFFF0000u, hbB = 0;
-    const u32 cw = tid * (CH_BITS / 32);
-    u32 w1 = data[widx(cw + 8)];
-    for (int wi = 7; wi >= 0; --wi) {
-        const u32 w0 = data[widx(cw + wi)];
-        u32 len[32];
-#pragma unroll
-        for (int r = 31; r >= 0; --r) {
-            const u32 win = r ? __builtin_amdgcn_alignbit(w0, w1, 32 - r) : w0;
-            len[r] = lenlut[win >> sh];
-        }
-#pragma unroll
-        for (int r = 31; r >= 0; --r) {
-            u32 l = len[r];
-            u32 xlo;
-            if (__builtin_expect(l >= 128, 0)) {       // longer than 13 bits (rare): walk the sub-trie; 17..32 bits look in ring2
-                l = sync32_long_len(lt, l, r ? __builtin_amdgcn_alignbit(w0, w1, 32 - r) : w0);
-                xlo = l > 16 ? nib(ring2, l - 17) : nib(ring, l - 1);
-            } else {
-                xlo = nib(ring, l - 1);
-            }
-            const u32 xhi = (hb >> (l - 1)) & 1u;
-            ring2 = (ring2 << 4) | (u32)(ring >> 60);
-            ring = (ring << 4) | xlo;
-            hb = (hb << 1) | xhi;
-            if (wi == 0 && r == 16) { mapB = ring; hbB = hb; }     // exits of positions 16..31
-        }
-        w1 = w0;
-    }
-    // the 32 exits of this chunk as bytes: maps[d][tid]
-#pragma unroll
-    for (int d = 0; d < 16; ++d) {
-        maps[((u32)d << 8) + tid] = (u8)(nib(ring, (u32)d) | (((hb >> d) & 1u) << 4));
-        maps[((u32)(d + 16) << 8) + tid] = (u8)(nib(mapB, (u32)d) | (((hbB >> d) & 1u) << 4));
-    }
-    __syncthreads();
-
-    // chunk maps to global: rows d < lmax, 256 bytes each (coalesced)
-    u8 *cf = chunkfn + ((size_t)(blk.tile_base + tile) * R << 8);
-    for (u32 i = tid; i < lmax * (DEC_THREADS / 4); i += DEC_THREADS)
-        ((u32 *)cf)[i] = ((const u32 *)maps)[i];
-    // wave maps: two halves of 32 chunks, lane (h, d) follows entry d through half h; then joined
-    {
-        const u32 h = lane >> 5, d = lane & 31u;
-        u32 v = d;
-        for (u32 c = 0; c < 32; ++c) v = maps[((v & 31u) << 8) + wv * 64 + h * 32 + c];
-        const u32 v2 = (u32)__shfl((int)v, 32 + (int)(__shfl((int)v, (int)d, 64) & 31), 64);   // second half applied to the first
-        if (lane < 32) wfn[wv * R + d] = (u8)v2;
-    }
-    __syncthreads();
-    u8 *tf = tilefn + (size_t)(blk.tile_base + tile) * R;
-    if (tid < lmax) {
-        u32 v = tid;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) v = wfn[w * R + (v & 31u)];
-        tf[tid] = (u8)v;
-    }
-    }
-}
-
-// counting automaton with 32-entry byte maps.  static LDS: data | maps[32][256] | fsm4 | fsm1 | wfn[4][32] | went[4][2] | ent[256] | wsum[4]
-__global__ __launch_bounds__(DEC_THREADS) void sfd_countfsm32(const DecBlk *__restrict__ blks,
-                                                              const u8 *__restrict__ chunkfn,
-                                                              const u8 *__restrict__ tile_entry,
-                                                              u8 *__restrict__ chunk_entry, u16 *__restrict__ chunk_cnt,
-                                                              u32 *__restrict__ tile_cnt, u32 tpw)
-{
-    constexpr u32 R = 32;
-    __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + R * DEC_THREADS + 16384 + 2048 + 4 * R + 16 + DEC_THREADS + 64];
-    if (dp_skipped_early(blks + blockIdx.y)) return;    // the block's speculative entries verified
-    const DecBlk blk = blks[blockIdx.y];
-    if (blockIdx.x * tpw >= blk.n_tiles) return;
-    u32 *data = (u32 *)smem;
-    u8 *maps = smem + LDS_DATA;
-    const u8 *f4 = maps + R * DEC_THREADS;
-    const u8 *f1 = f4 + 16384;
-    u8 *wfn = (u8 *)f1 + 2048;
-    u8 *went = wfn + 4 * R;
-    u8 *ent = went + 16;
-    u32 *wsum = (u32 *)(ent + DEC_THREADS);
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 lmax = blk.lmax;
-
-    fill_lds16((void *)f4, blk.fsm4, blk.n_states * 64);
-    fill_lds16((void *)f1, blk.fsm1, blk.n_states * 8);
-    const u32 tile_end = (blockIdx.x + 1) * tpw < blk.n_tiles ? (blockIdx.x + 1) * tpw : blk.n_tiles;
-    for (u32 tile = blockIdx.x * tpw; tile < tile_end; ++tile) {
-    const size_t gt = (size_t)blk.tile_base + tile;
-    __syncthreads();
-    load_tile(data, blk, tile);
-    {
-        const u8 *cf = chunkfn + (gt * R << 8);
-        for (u32 i = tid; i < lmax * (DEC_THREADS / 4); i += DEC_THREADS) ((u32 *)maps)[i] = ((const u32 *)cf)[i];
-    }
-    __syncthreads();
-    // half maps (lane (h, d) follows entry d through 32 chunks), wave maps, wave / half entries, chunk entries
-    const u32 h = lane >> 5, d = lane & 31u;
-    u32 hv = d;
-    for (u32 c = 0; c < 32; ++c) hv = maps[((hv & 31u) << 8) + wv * 64 + h * 32 + c];
-    {
-        const u32 v2 = (u32)__shfl((int)hv, 32 + (int)(__shfl((int)hv, (int)d, 64) & 31), 64);
-        if (lane < 32) wfn[wv * R + d] = (u8)v2;
-    }
-    __syncthreads();
-    {
-        u32 e = tile_entry[gt];
-        for (u32 w = 0; w < wv; ++w) e = wfn[w * R + (e & 31u)];         // entry of this wave
-        const u32 e1 = (u32)__shfl((int)hv, (int)(e & 31u), 64);                  // entry of its second half
-        if (lane == 0 || lane == 32) {
-            u32 v = lane ? e1 : e;
-            for (u32 c = 0; c < 32; ++c) {
-                ent[wv * 64 + h * 32 + c] = (u8)v;
-                v = maps[((v & 31u) << 8) + wv * 64 + h * 32 + c];
-            }
-        }
-    }
-    __syncthreads();
-    const u32 entry = ent[tid];
-    const u32 limit = tile_bit_limit(blk, tile);
-    const bool last = limit < (u32)(DTILE + HALO_WORDS * 4) * 8;
-    const u32 cw = tid * (CH_BITS / 32), cbase = tid * CH_BITS;
-    u32 st = 0, cnt = 0, p = entry;
-    auto bit_step = [&](u32 q) {
-        const u32 bit = (data[widx(q >> 5)] >> (31 - (q & 31))) & 1u;
-        const u32 e = *(const u32 *)(f1 + (st >> 3) + bit * 4);
-        st = e & 0xFFFFu;
-        cnt += e >> 16;
-    };
-    if (!last) {
-        while (p & 3) { bit_step(cbase + p); ++p; }    // p <= 32 afterwards
-        const u32 j0 = p >> 2;                          // first whole nibble (0..8): word 0, or the start of word 1
-#pragma unroll
-        for (int wi = 0; wi < 8; ++wi) {
-            const u32 w = data[widx(cw + wi)];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const u32 nib4 = j < 7 ? (w >> (26 - 4 * j)) & 0x3Cu : (w << 2) & 0x3Cu;
-                const u32 e = *(const u32 *)(f4 + st + nib4);
-                if (wi == 0) {                          // nibbles before the entry belong to the previous chunk
-                    if ((u32)j >= j0) { st = e & 0xFFFFu; cnt += e >> 16; }
-                } else {
-                    st = e & 0xFFFFu;
-                    cnt += e >> 16;
-                }
-            }
-        }
-        cnt += st != 0;
-    } else {
-        const u32 stop = cbase + CH_BITS < limit ? cbase + CH_BITS : limit;
-        u32 q = cbase + p;
-        for (; q < stop; ++q) bit_step(q);
-        if (st != 0 && q == cbase + CH_BITS) {
-            const u32 before = cnt;
-            for (; q < limit && cnt == before; ++q) bit_step(q);
-        }
-    }
-    chunk_entry[gt * DEC_THREADS + tid] = (u8)entry;
-    chunk_cnt[gt * DEC_THREADS + tid] = (u16)cnt;
-    const u32 tot = wave_reduce_add<u32>(cnt);
-    if (lane == 0) wsum[wv] = tot;
-    __syncthreads();
-    if (tid == 0) tile_cnt[gt] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    }
-}
-
-// sfd_tiles16: per block, the entry offset of every tile.  Batches of 4096 tile maps in LDS; thread (s, d)
-// follows entry d through segment s (1/16 of the batch), thread 0 links the 16 segments, then one thread per
-// segment walks it again from its real entry: 2 * 256 + 16 dependent LDS reads per batch instead of 4096.
-constexpr int TB = 4096;
-__global__ __launch_bounds__(DEC_THREADS) void sfd_tiles16(const DecBlk *__restrict__ blks,
-                                                           const u64 *__restrict__ tilefn, u8 *__restrict__ tile_entry)
-{
-    __shared__ u64 maps[TB];
-    __shared__ u8 ent[TB];
-    __shared__ u8 segmap[16 * 16], segent[16];
-    __shared__ u32 carry;
-    if (dp_skipped_early(blks + blockIdx.x)) return;
-    const DecBlk blk = blks[blockIdx.x];
-    const u32 tid = threadIdx.x, sg = tid >> 4, d = tid & 15u;
-    if (tid == 0) carry = 0;
-    for (u32 t0 = 0; t0 < blk.n_tiles; t0 += TB) {
-        const u32 nt = (blk.n_tiles - t0 < (u32)TB) ? blk.n_tiles - t0 : (u32)TB;
-        const u32 seg = (nt + 15) / 16;
-        for (u32 i = tid; i < nt; i += DEC_THREADS) maps[i] = tilefn[(size_t)blk.tile_base + t0 + i];
-        __syncthreads();
-        const u32 lo = sg * seg < nt ? sg * seg : nt, hi = lo + seg < nt ? lo + seg : nt;
-        {
-            u32 v = d;
-            for (u32 i = lo; i < hi; ++i) v = nib(maps[i], v);
-            segmap[sg * 16 + d] = (u8)v;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            u32 e = carry;
-            for (u32 q = 0; q < 16; ++q) { segent[q] = (u8)e; e = segmap[q * 16 + e]; }
-            carry = e;
-        }
-        __syncthreads();
-        if (d == 0) {
-            u32 v = segent[sg];
-            for (u32 i = lo; i < hi; ++i) { ent[i] = (u8)v; v = nib(maps[i], v); }
-        }
-        __syncthreads();
-        for (u32 i = tid; i < nt; i += DEC_THREADS) tile_entry[blk.tile_base + t0 + i] = ent[i];
-        __syncthreads();
-    }
-}
-
-// decode the chunk's own symbols starting at bit `entry`; Sink(sym, ok) per symbol.  Returns the count.
-// Only codes that end inside the stream (tile-local bit `limit`) are symbols: zero padding past the
-// last byte must not be counted, or a truncated stream would go unnoticed.
-template <typename Sink>
-__device__ __forceinline__ u32 decode_chunk(const u32 *data, const u16 *lut, const DecBlk &blk, u32 cbase,
-                                            u32 entry, u32 limit, u32 max_syms, Sink sink)
-{
-    // 64-bit bit buffer, next stream bit at the MSB, >= 32 valid bits before every look-up
-    u32 p = entry, cnt = 0;
-    u32 pos = cbase + p;
-    u32 wnext = (pos >> 5) + 2;
-    u64 buf = ((((u64)data[widx(pos >> 5)]) << 32) | data[widx((pos >> 5) + 1)]) << (pos & 31);
-    int avail = 64 - (int)(pos & 31);
-    const u32 K = blk.K;
-    while (p < (u32)CH_BITS && cnt < max_syms) {
-        const u32 win = (u32)(buf >> 32);
-        u32 e = lut[win >> (32 - K)];
-        if (e & 0x8000u) {                              // codes of K+1..K+8 bits: one more table
-            const u32 nb = ((e >> 12) & 7u) + 1;
-            e = lut[(1u << LUT_MAXK) + (e & 0xFFFu) + ((win << K) >> (32 - nb))];
-        }
-        u32 len = e >> 8, sym = e & 0xFF;
-        bool ok = true;
-        if (__builtin_expect(e == 0, 0)) {              // longer code or missing branch: trie walk
-            const Code c = code_at(data, lut, blk.trie, K, cbase + p);
-            len = c.len; sym = c.sym; ok = c.ok;
-        }
-        if (cbase + p + len > limit) break;
-        sink(sym, ok);
-        p += len;
-        ++cnt;
-        if (__builtin_expect(len > 31, 0)) {            // rebuild the buffer after a very long code
-            pos = cbase + p;
-            wnext = (pos >> 5) + 2;
-            buf = ((((u64)data[widx(pos >> 5)]) << 32) | data[widx((pos >> 5) + 1)]) << (pos & 31);
-            avail = 64 - (int)(pos & 31);
-        } else {
-            buf <<= len;
-            avail -= (int)len;
-            if (avail < 32) {
-                buf |= (u64)data[widx(wnext)] << (32 - avail);
-                avail += 32;
-                ++wnext;
-            }
-        }
-    }
-    return cnt;
-}
-
-// tile-local bit index of the end of the stream (clamped to the staged window)
-__device__ __forceinline__ u32 tile_bit_limit(const DecBlk &blk, u32 tile)
-{
-    const u64 start = (u64)tile * DTILE;
-    const u64 left = blk.in_n > start ? blk.in_n - start : 0;
-    const u64 cap = (u64)DTILE + HALO_WORDS * 4;
-    return (u32)((left < cap ? left : cap) * 8);
-}
-
-// ------------------------------------------------------------------------------------------------
-// sfd_count: chunk entries (from the chunk maps) + symbols per chunk and per tile
-// dynamic LDS: data | maps[R*256] | lut | went[4] wfn[4*R] | ent[256]
-// ------------------------------------------------------------------------------------------------
-template <bool PACKED>
-__global__ __launch_bounds__(DEC_THREADS) void sfd_count(const DecBlk *__restrict__ blks, u32 R, u32 l2cap,
-                                                         const u8 *__restrict__ chunkfn,
-                                                         const u8 *__restrict__ tile_entry,
-                                                         u8 *__restrict__ chunk_entry, u16 *__restrict__ chunk_cnt,
-                                                         u32 *__restrict__ tile_cnt)
-{
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const DecBlk blk = blks[blockIdx.y];
-    const u32 tile = blockIdx.x;
-    if (tile >= blk.n_tiles) return;
-    u32 *data = (u32 *)smem;
-    u8 *maps = smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4;      // PACKED: 256 u64, else R*256 u8
-    u16 *lut = (u16 *)(maps + (PACKED ? (size_t)DEC_THREADS * 8 : (size_t)R * DEC_THREADS));
-    u8 *wfn = (u8 *)(lut + (1u << LUT_MAXK) + l2cap);                      // PACKED: 4 u64
-    u8 *ent = wfn + (PACKED ? 32 : 4 * R);
-    u32 *wsum = (u32 *)(ent + DEC_THREADS);
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 lmax = blk.lmax;
-    const size_t gt = (size_t)blk.tile_base + tile;
-
-    load_tile(data, blk, tile);
-    load_lut(lut, blk);
-    if (PACKED) {
-        ((u64 *)maps)[tid] = ((const u64 *)chunkfn)[gt * DEC_THREADS + tid];
-    } else {
-        const u8 *cf = chunkfn + (gt * R << 8);
-        for (u32 i = tid; i < lmax * (DEC_THREADS / 4); i += DEC_THREADS) ((u32 *)maps)[i] = ((const u32 *)cf)[i];
-    }
-    __syncthreads();
-
-    // wave maps (as in sfd_sync), then wave entries from the tile entry, then every chunk's entry
-    if (PACKED) {
-        const u64 *cm = (const u64 *)maps;
-        u64 *wm = (u64 *)wfn;
-        if (lane < 16) {
-            u32 v = lane;
-            for (u32 c = 0; c < 64; ++c) v = nib(cm[wv * 64 + c], v);
-            u64 m = (u64)v << (4 * lane);
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) m |= __shfl_xor(m, d, 64);
-            if (lane == 0) wm[wv] = m;
-        }
-        __syncthreads();
-        if (lane == 0) {
-            u32 v = tile_entry[gt];
-            for (u32 w = 0; w < wv; ++w) v = nib(wm[w], v);
-            for (u32 c = 0; c < 64; ++c) {
-                ent[wv * 64 + c] = (u8)v;
-                v = nib(cm[wv * 64 + c], v);
-            }
-        }
-    } else {
-        for (u32 d0 = 0; d0 < lmax; d0 += 64) {
-            const u32 d = d0 + lane;
-            u32 v = d < lmax ? d : 0;
-            for (u32 c = 0; c < 64; ++c) v = maps[(v << 8) + wv * 64 + c];
-            if (d < lmax) wfn[wv * R + d] = (u8)v;
-        }
-        __syncthreads();
-        if (lane == 0) {
-            u32 v = tile_entry[gt];
-            for (u32 w = 0; w < wv; ++w) v = wfn[w * R + v];
-            for (u32 c = 0; c < 64; ++c) {
-                ent[wv * 64 + c] = (u8)v;
-                v = maps[(v << 8) + wv * 64 + c];
-            }
-        }
-    }
-    __syncthreads();
-
-    const u32 entry = ent[tid];
-    const u32 cnt = decode_chunk(data, lut, blk, tid * CH_BITS, entry, tile_bit_limit(blk, tile), 0xFFFFFFFFu, [](u32, bool) {});
-    chunk_entry[gt * DEC_THREADS + tid] = (u8)entry;
-    chunk_cnt[gt * DEC_THREADS + tid] = (u16)cnt;
-    const u32 tot = wave_reduce_add<u32>(cnt);
-    if (lane == 0) wsum[wv] = tot;
-    __syncthreads();
-    if (tid == 0) tile_cnt[gt] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-// ================================================================================================
-// Fast symbol passes (every block of the launch has Lmax <= 13): one LUT level, and an inner loop with
-// a single rare branch.  The generic loops above spend ~150 issue slots per symbol on divergent
-// control flow (level-2 test, trie fallback, end-of-stream test, refill); these spend ~25.
-// ================================================================================================
-
-// bit reader over the staged tile: 64-bit buffer, next stream bit at the MSB, >= 32 valid bits
-struct BitBuf {
-    u64 buf;
-    int avail;
-    u32 wnext;
-    __device__ __forceinline__ void init(const u32 *data, u32 pos)
-    {
-        wnext = (pos >> 5) + 2;
-        buf = ((((u64)data[widx(pos >> 5)]) << 32) | data[widx((pos >> 5) + 1)]) << (pos & 31);
-        avail = 64 - (int)(pos & 31);
-    }
-    __device__ __forceinline__ u32 peek32() const { return (u32)(buf >> 32); }
-    __device__ __forceinline__ void skip(const u32 *data, u32 len)        // len <= 31
-    {
-        buf <<= len;
-        avail -= (int)len;
-        if (avail < 32) {
-            buf |= (u64)data[widx(wnext)] << (32 - avail);
-            avail += 32;
-            ++wnext;
-        }
-    }
-};
-
-// entry offset of every chunk of the tile: quarter chase with history, wave maps through LDS, then each lane
-// picks its nibble.  cm = the tile's 256 chunk maps (LDS), hist = 256 u64 (LDS), wmb = 64 bytes (LDS).
-__device__ __forceinline__ u32 chunk_entry_of(const u64 *cm, u64 *hist, u8 *wmb, u32 tile_entry_v, u32 tid = threadIdx.x)
-{
-    const u32 lane = tid & 63, wv = tid >> 6, q = lane >> 4;
-    u64 h;
-    const u32 qv = quarter_chase<true>(cm + wv * 64, &h);
-    hist[tid] = h;                                              // tid == wv*64 + q*16 + d
-    const u32 w = wave_map_of(qv);
-    if (lane < 16) wmb[wv * 16 + lane] = (u8)w;
-    __syncthreads();
-    u32 e = tile_entry_v;
-    for (u32 w2 = 0; w2 < wv; ++w2) e = wmb[w2 * 16 + e];       // entry of this wave
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {                               // entry of this lane's quarter
-        const u32 nx = __shfl(qv, k * 16 + (int)e, 64);
-        if ((u32)k < q) e = nx;
-    }
-    return nib(hist[wv * 64 + q * 16 + e], lane & 15u);
-}
-
-// sfd_count13: dynamic LDS: data | cmap[256] u64 | lenlut[2^13] u8 | hist[256] u64 | wmb[64] u8 | wsum[4]
-template <bool LAST>
-__device__ __forceinline__ u32 count13_loop(const u32 *data, const u8 *lenlut, u32 sh, const u32 *trie, u32 cbase,
-                                            u32 entry, u32 limit)
-{
-    u32 p = entry, cnt = 0;
-    BitBuf bb;
-    bb.init(data, cbase + p);
-    while (p < (u32)CH_BITS) {
-        u32 len = lenlut[bb.peek32() >> sh];
-        if (__builtin_expect(len == 0, 0)) len = slow_len(data, trie, cbase + p);      // incomplete table only
-        if (LAST && cbase + p + len > limit) break;
-        p += len;
-        ++cnt;
-        if (__builtin_expect(len > 31, 0)) bb.init(data, cbase + p); else bb.skip(data, len);
-    }
-    return cnt;
-}
-
-__global__ __launch_bounds__(DEC_THREADS) void sfd_count13(const DecBlk *__restrict__ blks,
-                                                           const u64 *__restrict__ chunkfn,
-                                                           const u8 *__restrict__ tile_entry,
-                                                           u8 *__restrict__ chunk_entry, u16 *__restrict__ chunk_cnt,
-                                                           u32 *__restrict__ tile_cnt, u32 tpw)
-{
-    __shared__ __attribute__((aligned(16))) u8 smem[LDS_DATA + DEC_THREADS * 16 + (1 << LEN_MAXK) + 64 + 16 + 64];
-    const DecBlk blk = blks[blockIdx.y];
-    if (blockIdx.x * tpw >= blk.n_tiles) return;
-    u32 *data = (u32 *)smem;
-    u64 *cm = (u64 *)(smem + LDS_DATA);
-    u8 *lenlut = (u8 *)(cm + DEC_THREADS);
-    u64 *hist = (u64 *)(lenlut + (1u << LEN_MAXK));
-    u8 *wmb = (u8 *)(hist + DEC_THREADS);
-    u32 *wsum = (u32 *)(wmb + 64);
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 K1 = blk.K1;
-
-    fill_lds16(lenlut, (const void *)blk.lenlut, 1u << K1);
-    const u32 tile_end = (blockIdx.x + 1) * tpw < blk.n_tiles ? (blockIdx.x + 1) * tpw : blk.n_tiles;
-    for (u32 tile = blockIdx.x * tpw; tile < tile_end; ++tile) {
-    const size_t gt = (size_t)blk.tile_base + tile;
-    __syncthreads();                                   // previous tile's LDS reads are done
-    load_tile(data, blk, tile);
-    cm[tid] = chunkfn[gt * DEC_THREADS + tid];
-    __syncthreads();
-    const u32 entry = chunk_entry_of(cm, hist, wmb, tile_entry[gt]);
-    const u32 limit = tile_bit_limit(blk, tile);
-    const bool last = limit < (u32)(DTILE + HALO_WORDS * 4) * 8;          // the stream ends inside this window
-    const u32 cnt = last ? count13_loop<true>(data, lenlut, 32 - K1, blk.trie, tid * CH_BITS, entry, limit)
-                         : count13_loop<false>(data, lenlut, 32 - K1, blk.trie, tid * CH_BITS, entry, limit);
-    chunk_entry[gt * DEC_THREADS + tid] = (u8)entry;
-    chunk_cnt[gt * DEC_THREADS + tid] = (u16)cnt;
-    const u32 tot = wave_reduce_add<u32>(cnt);
-    if (lane == 0) wsum[wv] = tot;
-    __syncthreads();
-    if (tid == 0) tile_cnt[gt] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    }
-}
-
-// sfd_countfsm: symbol counts with the nibble automaton (complete codes, Lmax <= 16).  Every lane takes exactly 64
-// table steps for its 256 bits whatever the code lengths are: no bit-buffer bookkeeping, no divergence between
-// lanes, ~4 VALU instructions per nibble.  static LDS: data | cmap[256] u64 | fsm4[256*16] u32 | fsm1[256*2] u32 |
-// hist[256] u64 | wmb[64] | wsum[4]
-template <int SUBS>
-__global__ __launch_bounds__(DEC_THREADS * SUBS) __attribute__((amdgpu_waves_per_eu(8, 8))) void sfd_countfsm(const DecBlk *__restrict__ blks,
-                                                                   const u64 *__restrict__ chunkfn,
-                                                                   const u8 *__restrict__ tile_entry,
-                                                                   u8 *__restrict__ chunk_entry, u16 *__restrict__ chunk_cnt,
-                                                                   u32 *__restrict__ tile_cnt, u32 tpw)
-{
-    // SUBS groups of 256 lanes, one tile each, share the automaton tables (the chain of 64 dependent look-ups per
-    // lane is latency bound: waves per CU is what counts)
-    constexpr int PER_SUB = LDS_DATA + DEC_THREADS * 16 + 64 + 16;
-    __shared__ __attribute__((aligned(16))) u8 smem[SUBS * PER_SUB + 16384 + 2048 + 64];
-    if (dp_skipped_early(blks + blockIdx.y)) return;
-    const DecBlk blk = blks[blockIdx.y];
-    const u32 first_tile = blockIdx.x * tpw * SUBS;
-    if (first_tile >= blk.n_tiles) return;
-    const u32 sub = threadIdx.x >> 8, tid = threadIdx.x & 255u, lane = tid & 63, wv = tid >> 6;
-    u8 *mine = smem + sub * PER_SUB;
-    u32 *data = (u32 *)mine;
-    u64 *cm = (u64 *)(mine + LDS_DATA);
-    u64 *hist = cm + DEC_THREADS;
-    u8 *wmb = (u8 *)(hist + DEC_THREADS);
-    u32 *wsum = (u32 *)(wmb + 64);
-    const u8 *f4 = smem + SUBS * PER_SUB;
-    const u8 *f1 = f4 + 16384;
-
-    fill_lds16((void *)f4, blk.fsm4, blk.n_states * 64);
-    fill_lds16((void *)f1, blk.fsm1, blk.n_states * 8);
-    for (u32 it = 0; it < tpw && first_tile + it * SUBS < blk.n_tiles; ++it) {
-    const u32 tile = first_tile + it * SUBS + sub;
-    const bool active = tile < blk.n_tiles;            // uniform per 256-lane group
-    const size_t gt = (size_t)blk.tile_base + (active ? tile : first_tile);
-    __syncthreads();                                   // previous tile's LDS reads are done
-    load_tile(data, blk, active ? tile : first_tile, tid);
-    cm[tid] = chunkfn[gt * DEC_THREADS + tid];
-    __syncthreads();
-    const u32 entry = chunk_entry_of(cm, hist, wmb, tile_entry[gt], tid);
-    const u32 limit = tile_bit_limit(blk, tile);
-    const bool last = limit < (u32)(DTILE + HALO_WORDS * 4) * 8;          // the stream ends inside this window
-    const u32 cw = tid * (CH_BITS / 32), cbase = tid * CH_BITS;
-    u32 st = 0, cnt = 0, p = entry;
-    auto bit_step = [&](u32 q) {                        // consume tile-local bit q
-        const u32 bit = (data[widx(q >> 5)] >> (31 - (q & 31))) & 1u;
-        const u32 e = *(const u32 *)(f1 + (st >> 3) + bit * 4);
-        st = e & 0xFFFFu;
-        cnt += e >> 16;
-    };
-    if (!last) {
-        while (p & 3) { bit_step(cbase + p); ++p; }    // up to the next nibble boundary (p <= 16 afterwards)
-        const u32 j0 = p >> 2;                          // first whole nibble of word 0 (0..4)
-#pragma unroll
-        for (int wi = 0; wi < 8; ++wi) {
-            const u32 w = data[widx(cw + wi)];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const u32 nib4 = j < 7 ? (w >> (26 - 4 * j)) & 0x3Cu : (w << 2) & 0x3Cu;
-                const u32 e = *(const u32 *)(f4 + st + nib4);
-                if (wi == 0 && j < 4) {                 // nibbles before the entry belong to the previous chunk
-                    if ((u32)j >= j0) { st = e & 0xFFFFu; cnt += e >> 16; }
-                } else {
-                    st = e & 0xFFFFu;
-                    cnt += e >> 16;
-                }
-            }
-        }
-        cnt += st != 0;                                 // the code in progress at bit 256 started in this chunk
-    } else {
-        // last tile of the block: bit by bit; only codes that end inside the stream are symbols
-        const u32 stop = cbase + CH_BITS < limit ? cbase + CH_BITS : limit;
-        u32 q = cbase + p;
-        for (; q < stop; ++q) bit_step(q);
-        if (st != 0 && q == cbase + CH_BITS) {          // finish the code in progress (it started in this chunk)
-            const u32 before = cnt;
-            for (; q < limit && cnt == before; ++q) bit_step(q);
-        }
-    }
-    if (active) {
-        chunk_entry[gt * DEC_THREADS + tid] = (u8)entry;
-        chunk_cnt[gt * DEC_THREADS + tid] = (u16)cnt;
-    }
-    const u32 tot = wave_reduce_add<u32>(cnt);
-    if (lane == 0) wsum[wv] = tot;
-    __syncthreads();
-    if (active && tid == 0) tile_cnt[gt] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    }
-}
 
 // ================================================================================================
 // Speculative chunk entries for self-synchronising codes (complete codes, Lmax <= 32), verified exactly.
@@ -1729,82 +594,6 @@ __global__ __launch_bounds__(DEC_THREADS) __attribute__((amdgpu_waves_per_eu(FIX
     }
 }
 
-// sfd_write13: the symbol pass for incomplete codes of <= 13 bits (one code per look-up, direct stores; complete
-// codes take sfd_wstage).  static LDS: SUBS x data | lut13[2^13] u16 | SUBS x wsum[4]
-// A workgroup is SUBS groups of 256 lanes, each decoding its own tile, sharing one copy of the table: the loop is
-// latency bound (dependent LDS look-ups), so what counts is waves per CU, and the table is what limits them.
-template <int SUBS>
-__global__ __launch_bounds__(DEC_THREADS * SUBS) void sfd_write13(const DecBlk *__restrict__ blks,
-                                                                  const u8 *__restrict__ chunk_entry,
-                                                                  const u16 *__restrict__ chunk_cnt,
-                                                                  const u64 *__restrict__ tile_off, u32 tpw)
-{
-    constexpr int TAB = 2 << LEN_MAXK;
-    __shared__ __attribute__((aligned(16))) u8 smem[SUBS * LDS_DATA + TAB + SUBS * 16 + 64];
-    const DecBlk blk = blks[blockIdx.y];
-    const u32 first_tile = blockIdx.x * tpw * SUBS;
-    if (first_tile >= blk.n_tiles) return;
-    const u32 sub = threadIdx.x >> 8, tid = threadIdx.x & 255u, lane = tid & 63, wv = tid >> 6;
-    u32 *data = (u32 *)(smem + sub * LDS_DATA);
-    u16 *lut = (u16 *)(smem + SUBS * LDS_DATA);
-    u32 *wsum = (u32 *)(smem + SUBS * LDS_DATA + TAB) + sub * 4;
-    const u32 K1 = blk.K1;
-    if (tile_off[(size_t)blk.tile_base + first_tile] >= blk.n_sym) return;   // all padding / past the end
-    fill_lds16(lut, (const void *)blk.lut13, 2u << K1);
-    bool bad = false;
-    for (u32 it = 0; it < tpw && first_tile + it * SUBS < blk.n_tiles; ++it) {
-    const u32 tile = first_tile + it * SUBS + sub;
-    const size_t gt = (size_t)blk.tile_base + tile;
-    bool active = tile < blk.n_tiles;                   // uniform per 256-lane group
-    const u64 toff = active ? tile_off[gt] : 0ull;
-    active = active && toff < blk.n_sym;                // the rest is padding / past the end
-    __syncthreads();                                    // previous tile's LDS reads are done
-    u32 entry = 0, cnt = 0;
-    if (active) {
-        load_tile(data, blk, tile, tid);
-        entry = chunk_entry[gt * DEC_THREADS + tid];
-        cnt = chunk_cnt[gt * DEC_THREADS + tid];
-    }
-    const u32 incl = wave_incl_scan_add<u32>(cnt);
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
-    if (!active) continue;
-    u32 base = 0;
-    for (u32 w = 0; w < wv; ++w) base += wsum[w];
-    const u64 first = toff + base + incl - cnt;         // global index of this chunk's first symbol
-    const u64 nsym = blk.n_sym;
-    u32 want = first >= nsym ? 0u : (nsym - first < (u64)cnt ? (u32)(nsym - first) : cnt);
-    u8 *op = blk.out + first;
-    const u32 cbase = tid * CH_BITS, sh = 32 - K1;
-    u32 p = entry, na = 0;
-    u64 acc = 0;
-    BitBuf bb;
-    bb.init(data, cbase + p);
-    while (want) {                                      // exactly the symbols counted by sfd_count13
-        const u32 e = lut[bb.peek32() >> sh];
-        u32 len = e >> 8, sym = e & 0xFF;
-        if (__builtin_expect(e == 0, 0)) {              // incomplete table only
-            const Code c = code_at(data, lut, blk.trie, 0, cbase + p, true);
-            len = c.len; sym = c.sym; bad |= !c.ok;
-        }
-        p += len;
-        --want;
-        acc |= (u64)sym << na;
-        na += 8;
-        if (na == 64) {                                 // eight symbols per store (any byte alignment)
-            gstore<u64>(op, acc);
-            op += 8;
-            acc = 0;
-            na = 0;
-        }
-        if (__builtin_expect(len > 31, 0)) bb.init(data, cbase + p); else bb.skip(data, len);
-    }
-    na >>= 3;
-    for (u32 q = 0; q < na; ++q) gstore<u8>(op + q, (u8)(acc >> (8 * q)));
-    }
-    if (bad) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
-}
-
 // ------------------------------------------------------------------------------------------------
 // sfd_wstage: the symbol pass for complete codes (three codes per look-up), staged through LDS.
 // A lane decodes one chunk from its entry, exactly the symbols counted for it.  The workgroup's symbols are one
@@ -2085,257 +874,12 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_offsets(const DecBlk *__restr
     if (tid == 0 && carry < blk.n_sym) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);   // ran out of bits
 }
 
-// ------------------------------------------------------------------------------------------------
-// sfd_write: decode every chunk from its entry and store the symbols (index < n_sym only)
-// dynamic LDS: data | lut | wsum
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(DEC_THREADS) void sfd_write(const DecBlk *__restrict__ blks, u32 l2cap,
-                                                         const u8 *__restrict__ chunk_entry,
-                                                         const u16 *__restrict__ chunk_cnt,
-                                                         const u64 *__restrict__ tile_off)
-{
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const DecBlk blk = blks[blockIdx.y];
-    const u32 tile = blockIdx.x;
-    if (tile >= blk.n_tiles) return;
-    u32 *data = (u32 *)smem;
-    u16 *lut = (u16 *)(smem + (size_t)(DATA_WORDS + DATA_WORDS / 8 + 8) * 4);
-    u32 *wsum = (u32 *)(lut + (1u << LUT_MAXK) + l2cap);
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const size_t gt = (size_t)blk.tile_base + tile;
-    const u64 toff = tile_off[gt];
-    if (toff >= blk.n_sym) return;                      // the whole tile is padding / past the end
-
-    load_tile(data, blk, tile);
-    load_lut(lut, blk);
-    const u32 entry = chunk_entry[gt * DEC_THREADS + tid];
-    const u32 cnt = chunk_cnt[gt * DEC_THREADS + tid];
-    const u32 incl = wave_incl_scan_add<u32>(cnt);
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
-    u32 base = 0;
-    for (u32 w = 0; w < wv; ++w) base += wsum[w];
-    const u64 first = toff + base + incl - cnt;         // global index of this chunk's first symbol
-
-    // symbols of this chunk that fall inside the block (the stream's padding decodes to extra ones)
-    const u64 nsym = blk.n_sym;
-    const u32 want = first >= nsym ? 0u : (nsym - first < (u64)cnt ? (u32)(nsym - first) : cnt);
-    u8 *op = blk.out + first;
-    u32 acc = 0, na = 0;
-    bool bad = false;
-    decode_chunk(data, lut, blk, tid * CH_BITS, entry, tile_bit_limit(blk, tile), want, [&](u32 sym, bool ok) {
-        bad |= !ok;
-        acc |= sym << (8 * na);
-        if (++na == 4) {                                // four symbols per store (any byte alignment)
-            gstore<u32>(op, acc);
-            op += 4;
-            acc = 0;
-            na = 0;
-        }
-    });
-    for (u32 q = 0; q < na; ++q) gstore<u8>(op + q, (u8)(acc >> (8 * q)));
-    if (bad) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
 // host: validate the table (prefix-free), build LUT + trie, launch the five kernels
 // ------------------------------------------------------------------------------------------------
-namespace {
-struct HostTab {
-    std::vector<u32> trie;     // pairs
-    std::vector<u16> lut, lut2, lut13;
-    std::vector<u8> lenlut;
-    std::vector<u16> longtab;  // LONG_BYTES / 2 entries when 12 < Lmax <= 16 and the code is complete
-    std::vector<u16> long32;   // LONG32_BYTES / 2 entries when 12 < Lmax <= 32 and the code is complete
-    std::vector<u8> lenlut32;  // lenlut with escape ids 128 + k for the 13-bit prefixes of longer codes (with long32)
-    u32 K, K1, lmax;
-    bool ok, empty, complete, complete16, complete32;
-};
-
-void build_host_tab(const shafa_code_table &t, HostTab &h)
-{
-    h.trie.assign(2, 0xFFFFFFFFu);
-    h.ok = true;
-    h.complete = false;
-    h.complete16 = false;
-    h.complete32 = false;
-    h.lmax = 0;
-    for (int s = 0; s < 256; ++s) h.lmax = t.len[s] > h.lmax ? t.len[s] : h.lmax;
-    h.empty = h.lmax == 0;
-    h.K = h.lmax < (u32)LUT_MAXK ? (h.lmax ? h.lmax : 1) : (u32)LUT_MAXK;
-    h.lut.assign((size_t)1 << h.K, 0);
-    h.K1 = h.lmax < (u32)LEN_MAXK ? (h.lmax ? h.lmax : 1) : (u32)LEN_MAXK;
-    h.lenlut.assign(((size_t)1 << h.K1) + 4, 0);
-    h.lut13.assign(((size_t)1 << h.K1) + 2, 0);        // codes of <= K1 bits; 0 = longer
-    auto code_of = [&](int s) {
-        u64 code = 0;       // only the first 32 bits are ever needed here
-        const u32 L = t.len[s] < 32 ? t.len[s] : 32;
-        for (u32 q = 0; q < L; ++q) code = (code << 1) | ((t.bits[s][q >> 3] >> (7 - (q & 7))) & 1u);
-        return (u32)code;   // first min(len,32) bits, right-aligned
-    };
-    for (int s = 0; s < 256 && h.ok; ++s) {
-        const u32 L = t.len[s];
-        if (!L) continue;
-        u32 node = 0;
-        for (u32 q = 0; q < L; ++q) {
-            const u32 bit = (t.bits[s][q >> 3] >> (7 - (q & 7))) & 1u;
-            u32 &slot = h.trie[2 * node + bit];
-            if (q == L - 1) {
-                if (slot != 0xFFFFFFFFu) { h.ok = false; break; }          // duplicate / prefix of another
-                slot = 0x80000000u | (u32)s;
-            } else {
-                if (slot == 0xFFFFFFFFu) {
-                    slot = (u32)(h.trie.size() / 2);
-                    h.trie.push_back(0xFFFFFFFFu);
-                    h.trie.push_back(0xFFFFFFFFu);
-                } else if (slot & 0x80000000u) { h.ok = false; break; }     // passes through a leaf
-                node = h.trie[2 * node + bit];
-            }
-        }
-        if (h.ok && L <= h.K) {
-            const u32 code = code_of(s);
-            const u32 lo = code << (h.K - L), cnt = 1u << (h.K - L);
-            for (u32 i = 0; i < cnt; ++i) h.lut[lo + i] = (u16)(s | (L << 8));
-        }
-        if (h.ok && L <= h.K1) {
-            const u32 code = code_of(s);
-            const u32 lo = code << (h.K1 - L), cnt = 1u << (h.K1 - L);
-            memset(h.lenlut.data() + lo, (int)L, cnt);
-            if (!h.lut13.empty())
-                for (u32 i = 0; i < cnt; ++i) h.lut13[lo + i] = (u16)(s | (L << 8));
-        }
-    }
-    if (!h.ok) return;
-    h.complete = h.lmax <= (u32)LEN_MAXK;               // every K1-bit window starts a code: pair table usable
-    for (size_t i = 0; h.complete && i < ((size_t)1 << h.K1); ++i) h.complete = h.lenlut[i] != 0;
-    if (h.lmax <= 16) {                                 // prefix-free (checked above) + Kraft sum 1 = complete tree
-        u64 kraft = 0;
-        for (int s = 0; s < 256; ++s) if (t.len[s]) kraft += 1ull << (16 - t.len[s]);
-        h.complete16 = kraft == 65536;
-    }
-    if (h.lmax > (u32)SYM3_MAXK && h.lmax <= 32) {      // complete tree with codes of 13..32 bits
-        u64 kraft = 0;
-        for (int s = 0; s < 256; ++s) if (t.len[s]) kraft += 1ull << (32 - t.len[s]);
-        h.complete32 = kraft == (1ull << 32);
-    }
-    if (h.complete32) {                                 // 12-bit prefixes of the codes of 13..32 bits + their sub-tries
-        h.long32.assign(LONG32_BYTES / 2, 0);
-        struct Item { u32 key, node; };
-        std::vector<Item> roots;
-        // walk the trie to depth SYM3_MAXK
-        std::vector<Item> frontier{{0u, 0u}};
-        for (int depth = 0; depth < SYM3_MAXK; ++depth) {
-            std::vector<Item> next;
-            for (const Item &it : frontier)
-                for (u32 b = 0; b < 2; ++b) {
-                    const u32 c = h.trie[2 * it.node + b];
-                    if (c != 0xFFFFFFFFu && !(c & 0x80000000u)) next.push_back({(it.key << 1) | b, c});
-                }
-            frontier.swap(next);
-        }
-        roots = frontier;                               // internal nodes at depth 12, keys ascending by construction? sort anyway
-        std::sort(roots.begin(), roots.end(), [](const Item &a, const Item &b) { return a.key < b.key; });
-        std::vector<u32> order;                         // sub-trie nodes, renumbered in BFS order
-        std::vector<int> newid(h.trie.size() / 2, -1);
-        if (roots.size() > (size_t)LONG_PFX) h.complete32 = false;
-        for (size_t g = 0; g < roots.size() && h.complete32; ++g) {
-            std::vector<u32> q{roots[g].node};
-            for (size_t qi = 0; qi < q.size(); ++qi) {
-                const u32 nd = q[qi];
-                newid[nd] = (int)order.size();
-                order.push_back(nd);
-                for (u32 b = 0; b < 2; ++b) {
-                    const u32 c = h.trie[2 * nd + b];
-                    if (!(c & 0x80000000u)) q.push_back(c);
-                }
-            }
-        }
-        // BFS numbering above interleaves ids before children are numbered: assign child ids in a second pass
-        if (order.size() > 256) h.complete32 = false;
-        if (h.complete32) {
-            h.long32[0] = (u16)roots.size();
-            h.long32[1] = (u16)order.size();               // sub-trie nodes in use (the passes that walk them keep only those in LDS)
-            for (size_t g = 0; g < roots.size(); ++g) {
-                h.long32[8 + g] = (u16)roots[g].key;
-                h.long32[8 + LONG_PFX + g] = (u16)newid[roots[g].node];
-            }
-            for (size_t i = 0; i < order.size(); ++i)
-                for (u32 b = 0; b < 2; ++b) {
-                    const u32 c = h.trie[2 * order[i] + b];
-                    h.long32[8 + 2 * LONG_PFX + 2 * i + b] = (c & 0x80000000u) ? (u16)(0x8000u | (c & 0xFFu)) : (u16)newid[c];
-                }
-            // 13-bit prefixes of the codes longer than 13 bits: lenlut32 names their trie node
-            if (h.lmax > (u32)LEN_MAXK) {
-                h.lenlut32.assign(h.lenlut.begin(), h.lenlut.end());
-                std::vector<Item> f13{{0u, 0u}};
-                for (int depth = 0; depth < LEN_MAXK; ++depth) {
-                    std::vector<Item> next;
-                    for (const Item &it : f13)
-                        for (u32 b = 0; b < 2; ++b) {
-                            const u32 c = h.trie[2 * it.node + b];
-                            if (c != 0xFFFFFFFFu && !(c & 0x80000000u)) next.push_back({(it.key << 1) | b, c});
-                        }
-                    f13.swap(next);
-                }
-                if (f13.size() > (size_t)LONG_PFX) { h.complete32 = false; h.long32.clear(); h.lenlut32.clear(); }
-                else
-                    for (size_t k = 0; k < f13.size(); ++k) {
-                        h.long32[8 + 2 * LONG_PFX + 512 + k] = (u16)newid[f13[k].node];
-                        h.lenlut32[f13[k].key] = (u8)(128 + k);
-                    }
-            }
-        } else h.long32.clear();
-    }
-    if (h.complete16 && h.lmax > (u32)SYM3_MAXK) {      // codes of 13..16 bits, grouped by their first 12 bits
-        h.longtab.assign(LONG_BYTES / 2, 0);
-        std::vector<u32> keys;
-        for (int s = 0; s < 256; ++s) if (t.len[s] > (u32)SYM3_MAXK) keys.push_back(code_of(s) >> (t.len[s] - SYM3_MAXK));
-        std::sort(keys.begin(), keys.end());
-        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-        if (keys.size() > (size_t)LONG_PFX) { h.complete16 = false; h.longtab.clear(); }
-        else {
-            h.longtab[0] = (u16)keys.size();
-            for (size_t g = 0; g < keys.size(); ++g) h.longtab[8 + g] = (u16)keys[g];
-            for (int s = 0; s < 256; ++s) {
-                const u32 L = t.len[s];
-                if (L <= (u32)SYM3_MAXK) continue;
-                const u32 code = code_of(s), key = code >> (L - SYM3_MAXK);
-                const size_t g = std::lower_bound(keys.begin(), keys.end(), key) - keys.begin();
-                const u32 suf = (code & ((1u << (L - SYM3_MAXK)) - 1)) << (16 - L), cnt = 1u << (16 - L);
-                for (u32 i = 0; i < cnt; ++i) h.longtab[8 + LONG_PFX + g * 16 + suf + i] = (u16)(s | (L << 8));
-            }
-        }
-    }
-    // level 2: group the codes of K+1..K+8 bits by their first K bits
-    for (int s = 0; s < 256; ++s) {
-        const u32 L = t.len[s];
-        if (L <= h.K || L > h.K + 8) continue;
-        const u32 pre = code_of(s) >> (L > 32 ? 32 - h.K : L - h.K);      // L <= K+8 <= 19 here
-        if (h.lut[pre]) continue;                                           // group already built
-        u32 maxl = 0;
-        for (int s2 = 0; s2 < 256; ++s2) {
-            const u32 L2 = t.len[s2];
-            if (L2 > h.K && L2 <= h.K + 8 && (code_of(s2) >> (L2 - h.K)) == pre && L2 > maxl) maxl = L2;
-        }
-        const u32 nb = maxl - h.K;
-        const u32 base = (u32)h.lut2.size();
-        if (base + (1u << nb) > (u32)LUT2_MAX) continue;                    // no room: these codes use the trie
-        h.lut2.resize(base + (1u << nb), 0);
-        for (int s2 = 0; s2 < 256; ++s2) {
-            const u32 L2 = t.len[s2];
-            if (L2 > h.K && L2 <= h.K + nb && (code_of(s2) >> (L2 - h.K)) == pre) {
-                const u32 sub = code_of(s2) & ((1u << (L2 - h.K)) - 1);
-                const u32 lo = sub << (h.K + nb - L2), cnt = 1u << (h.K + nb - L2);
-                for (u32 i = 0; i < cnt; ++i) h.lut2[base + lo + i] = (u16)(s2 | (L2 << 8));
-            }
-        }
-        h.lut[pre] = (u16)(0x8000u | ((nb - 1) << 12) | base);
-    }
-    if (h.lut2.size() & 1) h.lut2.push_back(0);
-}
-}  // namespace
+#include "sfd_host_tables.hpp"
 
 // fn(b) for every block of a launch, on the caller and up to seven helper threads (a helper is worth starting for sixteen
 // blocks or more; blocks are handed out by a counter, so the call does not depend on how many helpers could be started)
@@ -2480,7 +1024,16 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     u32 R = 16;
     while (R < lmax_all) R <<= 1;
     if (g_sfd_path >= 1) pair_all = c16_all = c32_all = false;
-    if (g_sfd_path >= 2 && R < 32) R = 32;
+    // The kernels of a launch, one family per class of codes:
+    //   complete codes of <= 13 bits (what Module T makes)          packed DP sfd_sync16<true> / sfd_countfsm, three codes per look-up
+    //   complete codes of 14..16 bits                               the same, the rare long codes from a small LDS table (long_all)
+    //   complete codes of 17..32 bits (a real file at -b M)          sfd_sync32 / sfd_countfsm32 (mid32)
+    //   anything else (incomplete or > 32 bits: hand-made .cod)      the byte-map kernels sfd_sync / sfd_tiles / sfd_count / sfd_write
+    // and in front of the first three the speculative entries (sfd_scan) for tables that re-synchronise.
+    const bool long_all = R == 16 && !pair_all && c16_all && lmax_all > (u32)LEN_MAXK;
+    const bool packed = R == 16 && ((pair_all && lmax_all <= (u32)LEN_MAXK) || long_all);
+    const bool mid32 = !packed && R == 32 && c32_all;
+    if (!packed && !mid32 && R < 32) R = 32;           // the byte-map kernels keep 32 entries per chunk at least
 
     // workspace layout
     size_t off = 0;
@@ -2494,15 +1047,8 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const size_t o_toff = off; off += (size_t)total_tiles * 8;
     const size_t o_cent = off; off += (size_t)total_tiles * DEC_THREADS; off = (off + 15) & ~(size_t)15;
     const size_t o_ccnt = off; off += (size_t)total_tiles * DEC_THREADS * 2; off = (off + 15) & ~(size_t)15;
-    const bool packed = (R == 16);
-    // 13 < Lmax <= 16, complete codes: same kernels, the rare long codes resolved from a small LDS table
-    const bool long_all = packed && !pair_all && c16_all && lmax_all > (u32)LEN_MAXK;
-    const bool fast13 = (lmax_all <= (u32)LEN_MAXK || long_all);   // LUT symbol passes
-    const bool multi = fast13 && (pair_all || long_all);            // three codes per lookup
-    // 16 < Lmax <= 32, complete codes: 32-entry byte maps with the fast DP / automaton / three-code passes
-    const bool mid32 = !packed && R == 32 && c32_all;
-    const bool need_tabs = pair_all || long_all || mid32;
-    const size_t o_pair = off; off += pair_all ? (size_t)nblocks * (2u << LEN_MAXK) : 0;
+    const bool need_tabs = packed || mid32;
+    const size_t o_pair = off; off += (packed && pair_all) ? (size_t)nblocks * (2u << LEN_MAXK) : 0;
     const size_t o_cnt3 = off; off += need_tabs ? (size_t)nblocks * (2u << LEN_MAXK) : 0;
     const size_t o_sym3 = off; off += need_tabs ? (size_t)nblocks * (4u << LEN_MAXK) : 0;
     const size_t o_fsm4 = off; off += need_tabs ? (size_t)nblocks * 16384 : 0;
@@ -2510,7 +1056,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const size_t o_cfn = off; off += packed ? (size_t)total_tiles * DEC_THREADS * 8 : (size_t)total_tiles * R * DEC_THREADS;
     // speculative entries (complete codes, Lmax <= 32, tables that re-synchronise): per-tile guess / exit / redo flag
     // (long_all and mid32 launches too: a code of more than 13 bits is an escape inside the walk)
-    const bool spec_path = ((packed && fast13 && multi) || mid32) && g_sfd_speculate != 0;
+    const bool spec_path = (packed || mid32) && g_sfd_speculate != 0;
     const int spec_long = mid32 ? 2 : long_all ? 1 : 0;
     // window of sfd_spec's counting tables.  A 13-bit table in a launch with the table of long codes (which holds every code
     // of more than 12 bits, by 12-bit prefix) may count with 12-bit windows: the 13-bit codes become escapes like the 14..16-
@@ -2573,7 +1119,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         e.tile_base = tbase;
         e.run_dp = any_spec ? (u32 *)(dpar + o_rundp) + b : nullptr;
         ((u32 *)(hs + o_rundp))[b] = spec_blk[b] ? 0u : 1u;               // 1: straight to the exact kernels
-        e.pairlut = pair_all ? ws + o_pair + (size_t)b * (2u << LEN_MAXK) : nullptr;
+        e.pairlut = (packed && pair_all) ? ws + o_pair + (size_t)b * (2u << LEN_MAXK) : nullptr;
         e.cnt3 = need_tabs ? (u16 *)(ws + o_cnt3 + (size_t)b * (2u << LEN_MAXK)) : nullptr;
         e.sym3 = need_tabs ? (u32 *)(ws + o_sym3 + (size_t)b * (4u << LEN_MAXK)) : nullptr;
         e.fsm4 = need_tabs ? (u32 *)(ws + o_fsm4 + (size_t)b * 16384) : nullptr;
@@ -2642,7 +1188,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const size_t lds_tiles = (size_t)R * DEC_THREADS + DEC_THREADS;
     if (lds_tiles > 65536 || lds_sync > 65536) {     // long codes (R = 256): more than the default 64 KiB
         HIP_TRY(hipFuncSetAttribute((const void *)sfd_sync, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sync));
-        HIP_TRY(hipFuncSetAttribute((const void *)sfd_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count));
+        HIP_TRY(hipFuncSetAttribute((const void *)sfd_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_count));
         HIP_TRY(hipFuncSetAttribute((const void *)sfd_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_tiles));
     }
     const u32 l2cap = (max_l2 + 8) & ~7u;             // level-2 LDS entries reserved after level 1
@@ -2650,8 +1196,6 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     u32 tpw = 4;                                       // tiles per workgroup of the fast kernels (one table load)
     while (tpw > 1 && (u64)ceil_div_u64(max_tiles, tpw) * nblocks < 2048) tpw >>= 1;     // keep the chip full
     const dim3 grid_f((u32)ceil_div_u64(max_tiles, tpw), (u32)nblocks);
-    constexpr int WSUBS = 2;                           // 256-lane groups per workgroup of sfd_write13
-    const dim3 grid_w((u32)ceil_div_u64(max_tiles, tpw * WSUBS), (u32)nblocks);
     constexpr int CSUBS = 4;                           // 256-lane groups per workgroup of sfd_countfsm
     const dim3 grid_c((u32)ceil_div_u64(max_tiles, tpw * CSUBS), (u32)nblocks);
     // speculative entries: guesses, two rounds of tile repairs, final verdict per block
@@ -2689,44 +1233,29 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const u32 tpw_dp = all_spec ? 256u : tpw;
     const dim3 grid_fd((u32)ceil_div_u64(max_tiles, tpw_dp), (u32)nblocks);
     if (packed) {
-        const size_t lds_count16 = lds_data + DEC_THREADS * 8 + lds_lut + 32 + DEC_THREADS + 64;
-        if (need_tabs) hipLaunchKernelGGL(sfd_tables, dim3((u32)nblocks, 8), dim3(DEC_THREADS), 0, st, dblk);
+        hipLaunchKernelGGL(sfd_tables, dim3((u32)nblocks, 8), dim3(DEC_THREADS), 0, st, dblk);
         if (any_spec) launch_spec();
         const dim3 grid_cd((u32)ceil_div_u64(max_tiles, tpw_dp * CSUBS), (u32)nblocks);
         u32 k1_all = 0;                                // common K1 of the running blocks, 0 when they differ
         for (int b = 0; b < nblocks; ++b)
             if (ntiles[b]) k1_all = (k1_all == 0 || k1_all == tabs[b].K1) ? tabs[b].K1 : 0xFFFFFFFFu;
-        if (pair_all && k1_all == 12)
-            hipLaunchKernelGGL((sfd_sync16<true, false, 12>), grid_fd, dim3(DEC_THREADS), 0, st, dblk,
-                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw_dp);
-        else if (pair_all && k1_all == 13)
-            hipLaunchKernelGGL((sfd_sync16<true, false, 13>), grid_fd, dim3(DEC_THREADS), 0, st, dblk,
-                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw_dp);
-        else if (pair_all)
-            hipLaunchKernelGGL((sfd_sync16<true, false>), grid_fd, dim3(DEC_THREADS), 0, st, dblk,
-                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw_dp);
-        else if (long_all)
+        if (long_all)
             hipLaunchKernelGGL((sfd_sync16<false, true>), grid_fd, dim3(DEC_THREADS), 0, st, dblk,
                                (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw_dp);
+        else if (k1_all == 12)
+            hipLaunchKernelGGL((sfd_sync16<true, false, 12>), grid_fd, dim3(DEC_THREADS), 0, st, dblk,
+                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw_dp);
+        else if (k1_all == 13)
+            hipLaunchKernelGGL((sfd_sync16<true, false, 13>), grid_fd, dim3(DEC_THREADS), 0, st, dblk,
+                               (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw_dp);
         else
-            hipLaunchKernelGGL((sfd_sync16<false, false>), grid_fd, dim3(DEC_THREADS), 0, st, dblk,
+            hipLaunchKernelGGL((sfd_sync16<true, false>), grid_fd, dim3(DEC_THREADS), 0, st, dblk,
                                (u64 *)(ws + o_cfn), (u64 *)(ws + o_tilefn), tpw_dp);
         hipLaunchKernelGGL(sfd_tiles16, grid_b, dim3(DEC_THREADS), 0, st, dblk, (const u64 *)(ws + o_tilefn),
                            ws + o_tent);
-        if (fast13) {
-            if (multi)
-                hipLaunchKernelGGL((sfd_countfsm<CSUBS>), grid_cd, dim3(DEC_THREADS * CSUBS), 0, st, dblk,
-                                   (const u64 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
-                                   (u32 *)(ws + o_tcnt), tpw_dp);
-            else
-                hipLaunchKernelGGL(sfd_count13, grid_fd, dim3(DEC_THREADS), 0, st, dblk,
-                                   (const u64 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
-                                   (u32 *)(ws + o_tcnt), tpw_dp);
-        } else {
-            hipLaunchKernelGGL(sfd_count<true>, grid_t, dim3(DEC_THREADS), lds_count16, st, dblk, R, l2cap,
-                               (const u8 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
-                               (u32 *)(ws + o_tcnt));
-        }
+        hipLaunchKernelGGL((sfd_countfsm<CSUBS>), grid_cd, dim3(DEC_THREADS * CSUBS), 0, st, dblk,
+                           (const u64 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
+                           (u32 *)(ws + o_tcnt), tpw_dp);
     } else if (mid32) {
         hipLaunchKernelGGL(sfd_tables, dim3((u32)nblocks, 8), dim3(DEC_THREADS), 0, st, dblk);
         if (any_spec) launch_spec();
@@ -2739,7 +1268,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         hipLaunchKernelGGL(sfd_sync, grid_t, dim3(DEC_THREADS), lds_sync, st, dblk, R, l2cap, ws + o_cfn, ws + o_tilefn);
         hipLaunchKernelGGL(sfd_tiles, grid_b, dim3(DEC_THREADS), lds_tiles, st, dblk, R, (const u8 *)(ws + o_tilefn),
                            ws + o_tent);
-        hipLaunchKernelGGL(sfd_count<false>, grid_t, dim3(DEC_THREADS), lds_count, st, dblk, R, l2cap,
+        hipLaunchKernelGGL(sfd_count, grid_t, dim3(DEC_THREADS), lds_count, st, dblk, R, l2cap,
                            (const u8 *)(ws + o_cfn), (const u8 *)(ws + o_tent), ws + o_cent, (u16 *)(ws + o_ccnt),
                            (u32 *)(ws + o_tcnt));
     }
@@ -2788,20 +1317,16 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     if (mid32) {
         hipLaunchKernelGGL((sfd_wstage<2, true>), grid_ws, dim3(DEC_THREADS), lds_ws + long_used, st, dblk,
                            (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap, long_used);
-    } else if (fast13) {
-        if (multi && long_all)
+    } else if (packed) {
+        if (long_all)
             hipLaunchKernelGGL((sfd_wstage<1, true>), grid_ws, dim3(DEC_THREADS), lds_ws + long_used, st, dblk,
                                (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap, long_used);
-        else if (multi)
-            if (lmax_all > (u32)SYM3_MAXK)
-                hipLaunchKernelGGL((sfd_wstage<0, true>), grid_ws, dim3(DEC_THREADS), lds_ws, st, dblk,
-                                   (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap, 0u);
-            else
-                hipLaunchKernelGGL((sfd_wstage<0, false>), grid_ws, dim3(DEC_THREADS), lds_ws, st, dblk,
-                                   (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap, 0u);
+        else if (lmax_all > (u32)SYM3_MAXK)
+            hipLaunchKernelGGL((sfd_wstage<0, true>), grid_ws, dim3(DEC_THREADS), lds_ws, st, dblk,
+                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap, 0u);
         else
-            hipLaunchKernelGGL((sfd_write13<WSUBS>), grid_w, dim3(DEC_THREADS * WSUBS), 0, st, dblk,
-                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw);
+            hipLaunchKernelGGL((sfd_wstage<0, false>), grid_ws, dim3(DEC_THREADS), lds_ws, st, dblk,
+                               (const u8 *)(ws + o_cent), (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff), tpw_ws, ws_tab, ws_cap, 0u);
     } else {
         hipLaunchKernelGGL(sfd_write, grid_t, dim3(DEC_THREADS), lds_write, st, dblk, l2cap, (const u8 *)(ws + o_cent),
                            (const u16 *)(ws + o_ccnt), (const u64 *)(ws + o_toff));
