@@ -21,6 +21,7 @@
  */
 #include "shafa_host.h"
 
+#include <errno.h>
 #include <fcntl.h>
 #include <pthread.h>
 #include <sys/stat.h>
@@ -84,22 +85,33 @@ static int pipe_depth(uint64_t n_blocks)
  * tmpfs reads scale with threads (tools/iobench/tmpfs_rw.c on the GPU box: 6.6 GiB/s with one thread, 15 with eight,
  * 21-23 with sixteen).  WRITES of a new file do not: 5.5 GiB/s with one thread and LESS with more (2.8 with eight: the
  * page allocations of one inode serialise) — so a block is written by one thread.  That write path is what bounds the
- * CLI end to end.  --no-multithread: everything inline.  Inputs must be seekable (regular files): a FIFO or
- * /dev/stdin, which the reference's fread loop accepts, is SHAFA_FILE_STREAM_FAILED here (pread: ESPIPE). */
+ * CLI end to end.  --no-multithread: everything inline.  An input that cannot seek (a FIFO, /dev/stdin — the
+ * reference's fread loop accepts them in Module C, c.c:392) is read front to back by one thread (io_all). */
 /* (helper threads only for slices of 8 MiB: a block of -b m or less is read inline — eleven thread starts per small block
  * were pure overhead) */
 enum { IO_THREADS = 12, IO_MIN_SLICE = 8 << 20 };
 typedef struct { int fd; uint8_t *buf; size_t n; off_t off; bool write; bool ok; } io_slice;
 
+/* An input that cannot seek (a FIFO, /dev/stdin: the reference's fread loops take them, c.c:392) is read in order: the drivers
+ * ask for their blocks front to back, so `off` must be where the last read ended. */
+static int seq_fd = -1;
+static off_t seq_pos = 0;
 static bool io_all(int fd, uint8_t *buf, size_t n, off_t off, bool write)
 {
     while (n) {
-        const ssize_t k = write ? pwrite(fd, buf, n, off) : pread(fd, buf, n, off);
+        ssize_t k = write ? pwrite(fd, buf, n, off) : pread(fd, buf, n, off);
+        if (k < 0 && errno == ESPIPE && !write) {
+            if (seq_fd != fd) { seq_fd = fd; seq_pos = 0; }
+            if (off != seq_pos) return false;                   /* not the next byte of the stream */
+            k = read(fd, buf, n);
+            if (k > 0) seq_pos += k;
+        }
         if (k <= 0) return false;                              /* error, or a file shorter than announced */
         buf += k; n -= (size_t)k; off += k;
     }
     return true;
 }
+static bool fd_seeks(int fd) { return lseek(fd, 0, SEEK_CUR) != (off_t)-1 || errno != ESPIPE; }
 static void *io_slice_main(void *arg)
 {
     io_slice *s = arg;
@@ -108,7 +120,7 @@ static void *io_slice_main(void *arg)
 }
 static bool par_io(int fd, const uint8_t *buf, size_t n, off_t off, bool write)
 {
-    size_t parts = (NO_MULTITHREAD || write) ? 1 : n / IO_MIN_SLICE;
+    size_t parts = (NO_MULTITHREAD || write || !fd_seeks(fd)) ? 1 : n / IO_MIN_SLICE;
     if (parts > IO_THREADS) parts = IO_THREADS;
     if (parts <= 1) return io_all(fd, (uint8_t *)buf, n, off, write);
     io_slice sl[IO_THREADS];

@@ -209,6 +209,41 @@ def test_cli_default_run_one_upload_per_block(case, mode, tmp_path, monkeypatch)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case,stem", [("runs_default", "x.rle"), ("full_uniform_m", "u")])
+def test_cli_module_c_reads_a_fifo(case, stem, tmp_path):
+    """The reference's Module C reads its input with fread, front to back (c.c:392): a FIFO works.  Ours reads blocks with
+    pread; an input that cannot seek is read in order instead.  Same .shaf as from the regular file (small blocks in groups,
+    and 8 MiB blocks one per slot)."""
+    import threading
+    import golden.make_golden as mg
+    man = manifest(case)
+    work = scratch_dir(tmp_path, case)
+    try:
+        src = os.path.join(work, "regular")
+        if os.path.exists(os.path.join(GOLD, case, stem)):
+            shutil.copyfile(os.path.join(GOLD, case, stem), src)
+        else:                                           # (a -b m case: Module F's file is the input itself, RLE declined)
+            mg.make_input(man["generators"][stem]).tofile(src)
+        assert sha(src) == man["files"][stem]["sha256"]
+        shutil.copyfile(os.path.join(GOLD, case, stem + ".cod"), os.path.join(work, stem + ".cod"))
+        fifo = os.path.join(work, stem)
+        os.mkfifo(fifo)
+
+        def feed():
+            with open(src, "rb") as f, open(fifo, "wb") as w:
+                shutil.copyfileobj(f, w, 1 << 20)
+        th = threading.Thread(target=feed)
+        th.start()
+        rc, err, _ = run([stem, "-m", "c"], work)
+        th.join()
+        assert rc == 0, err
+        assert sha(os.path.join(work, stem + ".shaf")) == man["files"][stem + ".shaf"]["sha256"]
+    finally:
+        if work != str(tmp_path):
+            shutil.rmtree(work, ignore_errors=True)
+
+
+@pytest.mark.gpu
 def test_cli_device_list_errors_are_reported(tmp_path):
     """SHAFA_DEVICES naming a GPU the node does not have (or garbage) is an error message and exit 1 before any module
     runs — not a silent fall-back to device 0; a valid list works; Module T alone ignores the variable (it touches no GPU)."""
