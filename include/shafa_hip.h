@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SHAFA_HIP_ABI_VERSION 6
+#define SHAFA_HIP_ABI_VERSION 7
 
 /* utils/errors.h:5-16 (_modules_error), same numbers */
 enum shafa_error {

@@ -63,8 +63,8 @@ class PipeBlock(C.Structure):
 
 
 PIPE_GROUP_MAX = 256
-OP_HIST, OP_RLE_ENCODE, OP_SF_ENCODE, OP_SF_DECODE, OP_RLE_DECODE, OP_SF_RLE_DECODE = 1, 2, 3, 4, 5, 6
-PIPE_INPUT_HIST = 1
+OP_HIST, OP_RLE_ENCODE, OP_SF_ENCODE, OP_SF_DECODE, OP_RLE_DECODE, OP_SF_RLE_DECODE, OP_FTC = 1, 2, 3, 4, 5, 6, 7
+PIPE_INPUT_HIST, PIPE_FTC_RLE, PIPE_FTC_PLAIN = 1, 2, 4
 
 
 class ShafaError(RuntimeError):
@@ -128,8 +128,9 @@ def lib():
     L.shafa_pipe_wait.argtypes = [vp, C.c_int, C.POINTER(PipeResult)]
     L.shafa_pipe_submit_group.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(PipeBlock), C.c_int]
     L.shafa_pipe_wait_group.argtypes = [vp, C.c_int, C.c_int, C.POINTER(PipeResult), C.POINTER(C.c_int)]
+    L.shafa_pipe_ftc_encode.argtypes = [vp, C.c_int, C.c_int, tp, C.c_size_t]
     for name in ("shafa_pipe_create", "shafa_pipe_slots", "shafa_pipe_submit", "shafa_pipe_wait", "shafa_pipe_submit_group",
-                 "shafa_pipe_wait_group"):
+                 "shafa_pipe_wait_group", "shafa_pipe_ftc_encode"):
         getattr(L, name).restype = C.c_int
     for name in ("shafa_hip_init", "shafa_hip_hist256", "shafa_hip_rle_encode", "shafa_hip_sf_encode",
                  "shafa_hip_sf_decode", "shafa_hip_rle_decode", "shafa_hipd_batch_create",
@@ -363,6 +364,10 @@ class Pipe:
         out = C.string_at(r.out, r.out_n) if rc == 0 and r.out_n else b""
         return rc, out, r
 
+
+    def ftc_encode(self, slot, use_rle, table, out_cap):
+        """stage two of SHAFA_OP_FTC: Module C from the bytes stage one left on the device (shafa_pipe_ftc_encode)"""
+        _check(lib().shafa_pipe_ftc_encode(self._h, slot, 1 if use_rle else 0, C.byref(table), out_cap), "pipe_ftc_encode")
 
     def submit_group(self, slot, op, datas, tables=None, n_symbols=None, out_caps=None, flags=0):
         """several blocks in one slot: inputs laid out at 16-byte aligned offsets (shafa_pipe_submit_group)"""

@@ -17,7 +17,7 @@
 // rounds of consecutive lanes.  A tile without a zero byte that is entered at a token start is stored straight from its
 // input.
 //
-// What bounds it (profiles/r4_rld_*): a tile's 10-13 us are memory round trips in a row — ticket, load,
+// What bounds it (LABNOTES.md 3.4, profiles/r4_rld_*): a tile's 10-13 us are memory round trips in a row — ticket, load,
 // offset look-back, stores — at seven workgroups per CU (72 VGPRs, 12 KiB image).  The tile descriptors sit 32 bytes apart:
 // agent-scope atomics are served by the memory side, and sixteen descriptors in one cache line made every in-flight tile
 // of a block queue on the same three lines.  Neither fewer barriers, nor persistent workgroups with prefetch, nor a

@@ -11,7 +11,7 @@
 // stored as aligned 16-byte pieces.  (A single chained pass — one read of the input — was built twice, rounds 1 and 2: on inputs that
 // take the mask code it is no faster, a workgroup spends 10 of its 15 us waiting for its ticket, its loads and its two
 // look-backs, and on long runs its general tile code is 40 times slower; it needs the deferred look-backs of a
-// persistent pipeline like sfe4's to pay)
+// persistent pipeline like sfe4's to pay, LABNOTES.md §3.)
 //
 // Algorithmic HBM bytes per block: n read + rle_n written.
 #include "common.hpp"

@@ -625,7 +625,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
     if (tile_off[(size_t)blk.tile_base + first_tile] >= blk.n_sym) return;   // all padding / past the end
     // LONG == 1: the table of the 13..16-bit codes is kept up to the launch's largest group count only (`long_bytes` = header
     // + prefixes + that many groups: a few hundred bytes for a real file's rare symbols, 4.3 KB in full — the difference
-    // decides whether four workgroups share a CU or two)
+    // decides whether four workgroups share a CU or two, LABNOTES.md §3.2)
     const u32 LONGB = LONG ? long_bytes : 0u;           // (LONG == 2: header, prefixes, roots and the sub-trie nodes in use)
     u32 *rows = (u32 *)(smem + 16);
     const u32 tab_off = WS_ROWS_BYTES;
@@ -1060,7 +1060,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const int spec_long = mid32 ? 2 : long_all ? 1 : 0;
     // window of sfd_spec's counting tables.  A 13-bit table in a launch with the table of long codes (which holds every code
     // of more than 12 bits, by 12-bit prefix) may count with 12-bit windows: the 13-bit codes become escapes like the 14..16-
-    // bit ones, 8 KB of tables instead of 16 fit six workgroups on a CU instead of four.  Worth it while the
+    // bit ones, 8 KB of tables instead of 16 fit six workgroups on a CU instead of four (LABNOTES.md §3.2).  Worth it while the
     // 13-bit codes are few (an escape is a binary search that the whole wave waits for): at most eight of them, 0.1 % of the
     // symbols of a block coded near its entropy.
     std::vector<u32> hblk_kw(nblocks, 0);

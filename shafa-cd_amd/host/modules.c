@@ -79,13 +79,13 @@ static int pipe_depth(uint64_t n_blocks)
 
 /* ------------------------------------------------------------------ block I/O
  * A 64 MiB block through one fread / fwrite is a single-threaded copy between the page cache and the pinned buffer:
- * about 12 ms per block, 5 GiB/s end to end, with the GPU pipeline (25-30 GiB/s PCIe-inclusive) waiting.
+ * about 12 ms per block, 5 GiB/s end to end, with the GPU pipeline (25-30 GiB/s PCIe-inclusive, LABNOTES §1.1) waiting.
  * Blocks are therefore moved with pread / pwrite at explicit offsets.  READS are split over a few helper threads for the
  * duration of the call (the reference, too, touches a block from its own thread: multithread.c:126-194): page-cache /
  * tmpfs reads scale with threads (tools/iobench/tmpfs_rw.c on the GPU box: 6.6 GiB/s with one thread, 15 with eight,
  * 21-23 with sixteen).  WRITES of a new file do not: 5.5 GiB/s with one thread and LESS with more (2.8 with eight: the
  * page allocations of one inode serialise) — so a block is written by one thread.  That write path is what bounds the
- * CLI end to end.  --no-multithread: everything inline.  An input that cannot seek (a FIFO, /dev/stdin — the
+ * CLI end to end (LABNOTES §1.1).  --no-multithread: everything inline.  An input that cannot seek (a FIFO, /dev/stdin — the
  * reference's fread loop accepts them in Module C, c.c:392) is read front to back by one thread (io_all). */
 /* (helper threads only for slices of 8 MiB: a block of -b m or less is read inline — eleven thread starts per small block
  * were pure overhead) */

@@ -98,7 +98,7 @@ def scratch_dir(tmp_path, case):
     return str(tmp_path)
 
 
-# Where our host deliberately does NOT do what the reference does (SURVEY.md §9.6, DESIGN.md §3.3): the files on disk are
+# Where our host deliberately does NOT do what the reference does (SURVEY.md §9.6, DESIGN.md §4): the files on disk are
 # still compared with the reference's byte for byte.
 DIVERGENCES = {
     # a last block of ONE byte is a single-symbol block: all codes empty, `@0@` in the .shaf, and the reference's decoder

@@ -92,6 +92,46 @@ def test_pipe_every_op_matches_oracle_with_blocks_in_flight(oracle, shafa):
     pipe.close()
 
 
+def test_pipe_ftc_one_residency_matches_the_three_modules(oracle, shafa):
+    """SHAFA_OP_FTC: Module F on the device (RLE bytes + both histograms, or the plain histogram), Module T on the host from
+    the histogram that came back, Module C from the bytes still on the device (shafa_pipe_ftc_encode) — three blocks in
+    flight, each stage of every block against the oracle's block_compression / make_freq / code table / binary_coding."""
+    blocks = blocks_of(oracle, shafa, 6, 2500000)
+    pipe = shafa.Pipe(3)
+    modes = [shafa.PIPE_FTC_RLE | shafa.PIPE_FTC_PLAIN | shafa.PIPE_INPUT_HIST, shafa.PIPE_FTC_RLE, shafa.PIPE_FTC_PLAIN,
+             shafa.PIPE_FTC_RLE | shafa.PIPE_INPUT_HIST, shafa.PIPE_FTC_PLAIN, shafa.PIPE_FTC_RLE | shafa.PIPE_FTC_PLAIN]
+    use_rle = [True, True, False, True, False, False]
+    for i, b in enumerate(blocks):
+        slot = i % pipe.n_slots
+        pipe.submit(slot, shafa.OP_FTC, b, flags=modes[i])
+        if i >= 2:                                          # keep three slots busy: retire the block two behind, both stages
+            _ftc_finish(oracle, shafa, pipe, blocks, modes, use_rle, i - 2)
+    for i in (len(blocks) - 2, len(blocks) - 1):
+        _ftc_finish(oracle, shafa, pipe, blocks, modes, use_rle, i)
+    pipe.close()
+
+
+def _ftc_finish(oracle, shafa, pipe, blocks, modes, use_rle, i):
+    slot = i % pipe.n_slots
+    b = blocks[i]
+    rc, out, r = pipe.wait(slot)
+    want_rle = oracle.rle_encode(b)
+    if modes[i] & shafa.PIPE_FTC_RLE:
+        assert out == want_rle.tobytes(), f"block {i}: RLE bytes differ"
+        assert list(r.freq) == list(oracle.hist256(want_rle)), f"block {i}: histogram of the RLE bytes"
+        if modes[i] & (shafa.PIPE_FTC_PLAIN | shafa.PIPE_INPUT_HIST):
+            assert list(r.freq_in) == list(oracle.hist256(b)), f"block {i}: histogram of the input"
+    else:
+        assert out == b"" and list(r.freq) == list(oracle.hist256(b)), f"block {i}: plain histogram"
+    src = want_rle if use_rle[i] else b
+    tab = oracle.sf_build(oracle.hist256(src))
+    stab = to_shafa_table(shafa, tab)
+    lmax = int(max(stab.lens()))
+    pipe.ftc_encode(slot, use_rle[i], stab, (src.size * lmax + 7) // 8 + 16)
+    rc, enc, r2 = pipe.wait(slot)
+    assert enc == oracle.sf_encode(src, tab)[1].tobytes(), f"block {i}: .shaf payload differs (use_rle {use_rle[i]})"
+
+
 def test_pipe_errors_surface_at_wait_in_block_order(oracle, shafa):
     s = streams(oracle, shafa)
     good = s["zipf"](50000)
