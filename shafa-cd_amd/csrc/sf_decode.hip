@@ -687,6 +687,15 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
             rows[at + 3] = rev_bytes(v.w);
         }
     };
+    // bytes [lo, hi) of a 16-byte piece, one by one (the ends of a workgroup's run of the output)
+    auto store_bytes = [&](u8 *ga, const uint4 v, const u32 lo, const u32 hi) {
+        const u32 wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (u32 q = 0; q < 16; ++q)
+            if (q >= lo && q < hi) gstore<u8>(ga + q, (u8)(wds[q >> 2] >> (8 * (q & 3))));
+    };
+    u32 carry_n = 0, carry_lo = 0;                      // (uniform) piece 0 of the image holds bytes [carry_lo, carry_n) of the
+    u8 *carry_g = nullptr;                              //   output piece at carry_g, kept from the round before
     prefetch(first_tile);
     for (u32 it = 0; it < tpw; ++it) {
         const u32 tile = first_tile + it;
@@ -718,6 +727,15 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
         for (u32 done = 0; done < tot_c;) {
             u8 *gout = blk.out + toff + done;
             const u32 mis = (u32)((uintptr_t)gout & 15u);
+            if (carry_n && (carry_n != mis || carry_g != gout - mis)) {      // (uniform) the kept piece is not where this round
+                if (tid == 0) {                                              //   starts (cannot happen while tile offsets are a
+                    uint4 *ip = (uint4 *)(smem + img_off);                   //   scan of the counts): it leaves first
+                    store_bytes(carry_g, *ip, carry_lo, carry_n);
+                    *ip = make_uint4(0, 0, 0, 0);
+                }
+                carry_n = 0;
+                lds_barrier();
+            }
             const u32 capw = cap - 32;
             u32 nxt = tot_c;
             if (mis + (tot_c - done) > capw) {          // (uniform) more than the image holds: consecutive lanes that fit
@@ -812,24 +830,38 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                 if (nb8) __hip_atomic_fetch_or((lds_u32 *)(size_t)wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             lds_barrier();
-            const u32 end = mis + (nxt - done);         // image bytes [mis, end) are this round's symbols
-            for (u32 u = tid; 16 * u < end; u += DEC_THREADS) {
+            // Image bytes [mis, end) are this round's symbols.  Whole 16-byte pieces leave as aligned stores; the piece the round
+            // ends in STAYS: it becomes piece 0 of the workgroup's next round or tile, whose output continues exactly there
+            // (tile offsets are a scan of the counts), so inside a workgroup's run of tiles no piece is ever partial.  Only the
+            // run's first piece (bytes in front of it belong to another workgroup) and its last go out byte by byte.
+            const u32 end = mis + (nxt - done);
+            const u32 lo0 = (carry_n == mis && carry_n) ? carry_lo : mis;     // piece 0: bytes [lo0, 16) are this workgroup's
+            const u32 nfull = end >> 4;
+            u8 *const g0 = gout - mis;
+            for (u32 u = tid; u < nfull; u += DEC_THREADS) {
                 uint4 *ip = (uint4 *)(smem + img_off + 16 * u);
                 const uint4 v = *ip;
                 *ip = make_uint4(0, 0, 0, 0);
-                u8 *ga = gout - mis + 16 * u;
-                if (16 * u >= mis && 16 * u + 16 <= end) {
-                    gstore_nt<uint4>(ga, v);
-                } else {
-                    const u32 wds[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (u32 q = 0; q < 16; ++q)
-                        if (16 * u + q >= mis && 16 * u + q < end) gstore<u8>(ga + q, (u8)(wds[q >> 2] >> (8 * (q & 3))));
+                if (u == 0 && lo0) store_bytes(g0, v, lo0, 16u);
+                else gstore_nt<uint4>(g0 + 16 * u, v);
+            }
+            if (tid == 0) {                             // the piece the round ends in moves to the front of the image
+                if ((end & 15u) && nfull) {
+                    uint4 *ip = (uint4 *)(smem + img_off + 16 * nfull);
+                    *(uint4 *)(smem + img_off) = *ip;
+                    *ip = make_uint4(0, 0, 0, 0);
                 }
             }
+            carry_lo = nfull ? 0u : lo0;
+            carry_n = end & 15u;
+            carry_g = g0 + 16 * nfull;
             done = nxt;
-            if (done < tot_c) lds_barrier();          // the image is clean again before the next round's ORs
+            if (done < tot_c) lds_barrier();          // the image is in place again before the next round's ORs
         }
+    }
+    if (tid == 0 && carry_n) {                          // the last piece of the workgroup's run of tiles
+        const uint4 v = *(const uint4 *)(smem + img_off);
+        store_bytes(carry_g, v, carry_lo, carry_n);
     }
     if (bad) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
 }
