@@ -94,18 +94,23 @@ typedef struct { int fd; uint8_t *buf; size_t n; off_t off; bool write; bool ok;
 
 /* An input that cannot seek (a FIFO, /dev/stdin: the reference's fread loops take them, c.c:392) is read in order: the drivers
  * ask for their blocks front to back, so `off` must be where the last read ended. */
-static int seq_fd = -1;
+static int seq_fd = -1, seq_back = -1;          /* seq_back: one byte read too far by a header parser (shaf_read_u64), given back */
 static off_t seq_pos = 0;
+static ssize_t seq_read(int fd, uint8_t *buf, size_t n, off_t off)
+{
+    if (seq_fd != fd) { seq_fd = fd; seq_pos = 0; seq_back = -1; }
+    if (off != seq_pos || !n) return n ? -1 : 0;        /* not the next byte of the stream */
+    ssize_t k;
+    if (seq_back >= 0) { buf[0] = (uint8_t)seq_back; seq_back = -1; k = 1; }
+    else k = read(fd, buf, n);
+    if (k > 0) seq_pos += k;
+    return k;
+}
 static bool io_all(int fd, uint8_t *buf, size_t n, off_t off, bool write)
 {
     while (n) {
         ssize_t k = write ? pwrite(fd, buf, n, off) : pread(fd, buf, n, off);
-        if (k < 0 && errno == ESPIPE && !write) {
-            if (seq_fd != fd) { seq_fd = fd; seq_pos = 0; }
-            if (off != seq_pos) return false;                   /* not the next byte of the stream */
-            k = read(fd, buf, n);
-            if (k > 0) seq_pos += k;
-        }
+        if (k < 0 && errno == ESPIPE && !write) k = seq_read(fd, buf, n, off);
         if (k <= 0) return false;                              /* error, or a file shorter than announced */
         buf += k; n -= (size_t)k; off += k;
     }
@@ -390,6 +395,8 @@ typedef struct {
     uint64_t n_symbols;            /* SF decodes */
     size_t out_cap;                /* SF encode */
     int perr;                      /* the block's own error found on the host: surfaces when the block is retired */
+    uint8_t *staged;               /* the block's bytes, already read (an input that cannot seek: a group's headers and payloads
+                                      alternate in the stream, so prepare() has to take the payload with it); freed once copied */
 } gblk;
 typedef int (*g_prepare_fn)(void *ctx, uint64_t b, gblk *g);       /* an error stops further submissions; it is returned once
                                                                      the blocks before b are retired */
@@ -414,7 +421,7 @@ static int run_groups(shafa_pipe *pipe, int in_fd, uint64_t first, uint64_t end,
                       g_prepare_fn prepare, g_consume_fn consume, void *ctx, writer_t *wr, uint64_t *ticket)
 {
     const uint64_t depth = (uint64_t)shafa_pipe_slots(pipe);
-    gblk *gb = malloc(depth * (size_t)G * sizeof(gblk));
+    gblk *gb = calloc(depth * (size_t)G, sizeof(gblk));
     shafa_pipe_block *pb = malloc((size_t)G * sizeof(*pb));
     shafa_pipe_result *res = malloc((size_t)G * sizeof(*res));
     int *brc = malloc((size_t)G * sizeof(int));
@@ -437,6 +444,7 @@ static int run_groups(shafa_pipe *pipe, int in_fd, uint64_t first, uint64_t end,
             while (cnt < (uint64_t)G && sub + cnt < end) {
                 if (have_held) { g[cnt] = held; have_held = false; }
                 else {
+                    free(g[cnt].staged);
                     memset(&g[cnt], 0, sizeof(gblk));
                     const int e = prepare(ctx, sub + cnt, &g[cnt]);
                     if (e) { deferred = e; break; }
@@ -474,12 +482,19 @@ static int run_groups(shafa_pipe *pipe, int in_fd, uint64_t first, uint64_t end,
             }
             uint8_t *buf = cnt ? shafa_pipe_in(pipe, slot, pos ? pos : 16) : NULL;
             if (cnt && !buf) { err = SHAFA_LACK_OF_MEMORY; break; }
-            for (uint64_t i = 0; i < cnt; ++i)
+            for (uint64_t i = 0; i < cnt; ++i) {
+                if (g[i].staged) {
+                    if (pb[i].in_n) memcpy(buf + pb[i].in_off, g[i].staged, pb[i].in_n);
+                    free(g[i].staged);
+                    g[i].staged = NULL;
+                    continue;
+                }
                 if (pb[i].in_n && !io_all(in_fd, buf + pb[i].in_off, pb[i].in_n, g[i].file_off, false)) {
                     deferred = SHAFA_FILE_STREAM_FAILED;                  /* the file is shorter than announced: block i and on */
                     cnt = i;
                     break;
                 }
+            }
             if (!cnt) continue;
             if ((err = writer_wait(wr, ticket[slot]))) break;              /* the slot's previous results are on disk */
             if ((err = shafa_pipe_submit_group(pipe, slot, op, (int)cnt, pb, flags))) break;
@@ -506,6 +521,8 @@ static int run_groups(shafa_pipe *pipe, int in_fd, uint64_t first, uint64_t end,
         }
         ++rg;
     }
+    for (size_t i = 0; gb && i < depth * (size_t)G; ++i) free(gb[i].staged);      /* (left behind by an error) */
+    if (have_held) free(held.staged);
     free(gb); free(pb); free(res); free(brc); free(no_codes);
     return err;
 }
@@ -1142,7 +1159,21 @@ _modules_error rle_decompress(char **path)
 static bool shaf_read_u64(int fd, off_t *off, char lead, uint64_t *v, bool trailing_at)
 {
     char b[32];
-    const ssize_t got = pread(fd, b, sizeof(b), *off);
+    ssize_t got = pread(fd, b, sizeof(b), *off);
+    if (got < 0 && errno == ESPIPE) {                   /* a FIFO (d.c:673,697 read it with fscanf): byte by byte, one byte given back */
+        got = 0;
+        while (got < (ssize_t)sizeof(b) && seq_read(fd, (uint8_t *)b + got, 1, *off + got) == 1) {
+            ++got;
+            if (got >= 2 && (b[got - 1] < '0' || b[got - 1] > '9')) break;     /* the byte behind the digits */
+        }
+        ssize_t used = 0;                               /* as the parse below will find: lead, digits, '@' if asked for */
+        if (got >= 2 && b[0] == lead) {
+            used = 1;
+            while (used < got && b[used] >= '0' && b[used] <= '9') ++used;
+            if (trailing_at && used < got && b[used] == '@') ++used;
+        }
+        if (used < got && got >= 1) { seq_back = (unsigned char)b[got - 1]; --seq_pos; }   /* at most the last byte was not used */
+    }
     if (got < 2 || b[0] != lead) return false;
     ssize_t i = 1;
     int digits = 0;
@@ -1167,6 +1198,11 @@ static int d_prepare(void *vc, uint64_t b, gblk *g)
     if (!budget_has(c->left, sf_n)) return SHAFA_FILE_STREAM_FAILED;
     g->in_n = sf_n;
     g->file_off = *c->in_off;
+    if (!fd_seeks(c->in) && sf_n) {                     /* the payload sits between this header and the next one */
+        g->staged = malloc(sf_n);
+        if (!g->staged) return SHAFA_LACK_OF_MEMORY;
+        if (!io_all(c->in, g->staged, sf_n, *c->in_off, false)) { free(g->staged); g->staged = NULL; return SHAFA_FILE_STREAM_FAILED; }
+    }
     *c->in_off += (off_t)sf_n;
     c->left->used += sf_n;
     char *codes = NULL;

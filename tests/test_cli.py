@@ -244,6 +244,35 @@ def test_cli_module_c_reads_a_fifo(case, stem, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fifo_name,side,argv,decoded", [
+    ("x.rle.shaf", ["x.rle.cod"], ["x.rle.shaf"], "decoded__sf_rle"),                 # d.c:673,697-706: fscanf / fread of the .shaf
+    ("x.rle", ["x.rle.freq"], ["x.rle", "-m", "d"], "decoded__rle_only"),             # d.c:75-95 load_rle
+])
+def test_cli_module_d_reads_a_fifo(fifo_name, side, argv, decoded, tmp_path):
+    """Module D's inputs through a FIFO (the reference reads them front to back with fscanf / fread): the block headers of
+    the .shaf are then parsed byte by byte, the payloads read in order.  Same decoded file as from the regular file."""
+    import threading
+    man = manifest("runs_default")
+    work = str(tmp_path)
+    src = os.path.join(work, "regular")
+    shutil.copyfile(os.path.join(GOLD, "runs_default", fifo_name), src)
+    for f in side:
+        shutil.copyfile(os.path.join(GOLD, "runs_default", f), os.path.join(work, f))
+    fifo = os.path.join(work, fifo_name)
+    os.mkfifo(fifo)
+
+    def feed():
+        with open(src, "rb") as f, open(fifo, "wb") as w:
+            shutil.copyfileobj(f, w, 1 << 16)
+    th = threading.Thread(target=feed)
+    th.start()
+    rc, err, _ = run(argv, work)
+    th.join()
+    assert rc == 0, err
+    assert sha(os.path.join(work, "x")) == man["files"][decoded]["sha256"]
+
+
+@pytest.mark.gpu
 def test_cli_device_list_errors_are_reported(tmp_path):
     """SHAFA_DEVICES naming a GPU the node does not have (or garbage) is an error message and exit 1 before any module
     runs — not a silent fall-back to device 0; a valid list works; Module T alone ignores the variable (it touches no GPU)."""
