@@ -194,6 +194,7 @@ __device__ __forceinline__ bool scan_single(const lds_u8 *tab, const u16 *lt, co
 // column).  The phase's words are fetched by lane PAIRS: pair px loads strips px and px + 32, 32 contiguous bytes per
 // pair and load, and stores them into those strips' columns.
 #define SC_QUAD 0
+#define SC_WAVES 6                                  // waves per SIMD the register allocation aims at (71 registers: seven fit)
 #define SC_NT 0
 struct ScanIO {
     const u8 *in;
@@ -245,6 +246,22 @@ struct ScanIO {
         for (int t = 0; t < 4; ++t)
             R[t] = fetch16<CHECKED>(grp_off + (long long)sgrp(t) * SPL * SC_SB + 64ll * k + piece(t));
     }
+    // phases 2 j and 2 j + 1 at once: the two halves of every strip's 128-byte line are asked for back to back (a phase
+    // alone asks for half a line, and the other half — a walk later — finds the line evicted: every line fetched twice,
+    // tools/ubench/fetch_calib.hip)
+    template <bool CHECKED>
+    __device__ __forceinline__ void load_line(const int j, uint4 (&R)[8]) const
+    {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = 2 * g + u;
+                    R[4 * h + t] = fetch16<CHECKED>(grp_off + (long long)sgrp(t) * SPL * SC_SB + 64ll * (2 * j + h) + piece(t));
+                }
+    }
     // the 32 bytes in front of every strip (the block's first strip has none: it is never guessed; reads its own head)
     static constexpr int NRU = SC_QUAD ? 4 : 2;        // loads of the run-up (SC_QUAD: half of the lanes idle)
     template <bool CHECKED>
@@ -281,7 +298,7 @@ struct ScanIO {
         wave_sync();
     }
     // the row of a phase: word 0 = the old row's last word, words 1..16 = the phase
-    __device__ __forceinline__ void put_phase(const uint4 (&R)[4]) const
+    __device__ __forceinline__ void put_phase(const uint4 *R) const
     {
         const u32 carry = *(const lds_u32 *)(size_t)(cb + 16u * SC_COLB);
         wave_sync();
@@ -357,7 +374,10 @@ __device__ __forceinline__ void scan_strip_fast(const lds_u8 *tab, const u16 *lt
     io.init(blk, wave_off);
     ScanWin sw;
     sw.init(io.cb);
-    uint4 R[4];
+#ifndef SC_LINE
+#define SC_LINE 1
+#endif
+    uint4 R[SC_LINE ? 8 : 4];
     u32 q, pc = 0;
     // the chunk in progress up to where the row ends (q >= 512 afterwards): the last step of a phase, and the whole run-up
     auto to_row_end = [&]() {
@@ -367,7 +387,11 @@ __device__ __forceinline__ void scan_strip_fast(const lds_u8 *tab, const u16 *lt
     {
         uint4 RU[ScanIO::NRU];
         io.load_runup<false>(RU);
+#if SC_LINE
+        io.load_line<false>(0, R);
+#else
         io.load_phase<false>(0, R);
+#endif
         io.put_runup(RU);
     }
     q = 32u * 9u;
@@ -375,9 +399,15 @@ __device__ __forceinline__ void scan_strip_fast(const lds_u8 *tab, const u16 *lt
     q -= 32u * SC_PHW;
     auto phase = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
+#if SC_LINE
+        io.put_phase(R + 4 * (k & 1));
+        sw.flush();
+        if ((k & 1) && k + 1 < SC_M) io.load_line<false>((k + 1) / 2, R);      // both halves are free: the next line, a phase ahead
+#else
         io.put_phase(R);
         sw.flush();
         if (k + 1 < SC_M) io.load_phase<false>(k + 1, R);
+#endif
         // 1. finish the chunk in progress: its count, and the entry of chunk 2 k
         scan_single<false, LONG>(tab, lt, KW, q, 32u, 0, pc, sw);
         if (k > 0) o.put_cnt<(k > 0 ? 2 * k - 1 : 0)>(pc);
@@ -559,7 +589,7 @@ __device__ __forceinline__ void scan_unit(u8 *smem, const DecBlk &blk, const u32
 
 // dynamic LDS: rows (SC_LDS_ROWS) | cnt3 + len0 (tab_bytes) | flags (SC_MISC) | long-code table (LONG)
 template <bool FIX, int LONG>
-__global__ __launch_bounds__(DEC_THREADS) __attribute__((amdgpu_waves_per_eu(FIX ? 1 : 8, 8))) void sfd_scan(const DecBlk *__restrict__ blks, u8 *__restrict__ chunk_entry,
+__global__ __launch_bounds__(DEC_THREADS) __attribute__((amdgpu_waves_per_eu(FIX ? 1 : SC_WAVES, 8))) void sfd_scan(const DecBlk *__restrict__ blks, u8 *__restrict__ chunk_entry,
                                                         u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt,
                                                         u8 *__restrict__ tile_guess, u8 *__restrict__ tile_exit,
                                                         const u8 *__restrict__ tile_fix, u32 tab_bytes, u32 long_bytes)

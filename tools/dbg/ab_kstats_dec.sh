@@ -3,7 +3,7 @@
 # usage (through gpurun): tools/dbg/ab_kstats_dec.sh lib1.so lib2.so ...
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$R" || exit 1
-export SHAFA_BENCH_ORACLE_CHECK=0 SHAFA_BENCH_ABLATION=2 TMPDIR=/tmp
+export SHAFA_BENCH_ORACLE_CHECK=0 SHAFA_BENCH_ABLATION=${ABL:-2} TMPDIR=/tmp
 cp shafa-cd_amd/libshafa_hip.so /tmp/orig.so
 for L in "$@"; do
   cp "$L" shafa-cd_amd/libshafa_hip.so
