@@ -313,7 +313,31 @@ struct ScanIO {
         *(lds_u32 *)(size_t)cb = carry;
         wave_sync();
     }
-    // the strip's last chunk ends in the next strip's first word: row = carried word, that word
+    // The strip's last chunk ends in the NEXT strip's first word.  Asked for at the end of the walk it costs a line per strip
+    // (that line was loaded — by the lanes that load the next strip — when the walk began: long evicted).  So it is taken at
+    // the beginning, from those lanes' registers: every loader lane that holds word 0 of a strip puts it (bit-reversed) into
+    // row word 0 of the column in front of it, and every walker keeps its own.  The wave's last strip has its successor in
+    // another wave: one 4-byte load.  (R: the registers of load_line(0) / load_phase(0).)
+    __device__ __forceinline__ u32 next_strip_word(const uint4 *R, const u64 wave_off) const
+    {
+        const u32 lane = threadIdx.x & 63u;
+        if (ph == 0) {                                  // this lane holds word 0 of strips px (R[0]) and px + SPL (R[2])
+            if (lane) *(lds_u32 *)(size_t)(wbase - 4u) = rev_bytes(R[0].x);
+            *(lds_u32 *)(size_t)(wbase - 4u + 4u * SPL) = rev_bytes(R[2].x);
+        }
+        wave_sync();
+        u32 nw = *(const lds_u32 *)(size_t)cb;
+        if (lane == 63) nw = rev_bytes(gload<u32>(in + wave_off + (u64)64 * SC_SB));
+        wave_sync();
+        return nw;
+    }
+    __device__ __forceinline__ void put_next_word(const u32 nw_rev) const
+    {
+        const u32 carry = *(const lds_u32 *)(size_t)(cb + 16u * SC_COLB);
+        *(lds_u32 *)(size_t)cb = carry;
+        *(lds_u32 *)(size_t)(cb + SC_COLB) = nw_rev;
+    }
+    // the same from memory (the rolled walk: bounded loads near the stream's end)
     template <bool CHECKED>
     __device__ __forceinline__ void put_next_strip(const u64 wave_off) const
     {
@@ -394,6 +418,8 @@ __device__ __forceinline__ void scan_strip_fast(const lds_u8 *tab, const u16 *lt
 #endif
         io.put_runup(RU);
     }
+    static_assert(!SC_QUAD, "next_strip_word: pair mapping");
+    const u32 nextw = io.next_strip_word(R, wave_off);  // (row word 0 is free until the first phase's carry goes there)
     q = 32u * 9u;
     to_row_end();
     q -= 32u * SC_PHW;
@@ -429,7 +455,7 @@ __device__ __forceinline__ void scan_strip_fast(const lds_u8 *tab, const u16 *lt
     phase(std::integral_constant<int, 2>{});
     phase(std::integral_constant<int, 3>{});
     static_assert(SC_M == 4, "four phases written out");
-    io.put_next_strip<false>(wave_off);
+    io.put_next_word(nextw);
     sw.flush();
     scan_single<false, LONG>(tab, lt, KW, q, 32u, 0, pc, sw);
     o.put_cnt<SC_CH - 1>(pc);
@@ -455,8 +481,11 @@ __device__ __forceinline__ void scan_strip_gen(const lds_u8 *tab, const u16 *lt,
     uint4 R[4];
     u32 q = 0, pc = 0;
     bool cut = false;
+    // (LAST: a lane whose row lies wholly inside the stream still takes whole fetches — only the strips the stream ends in
+    // go code by code)
+    auto inside = [&](const int ql) { return !LAST || ql > 32 * SC_PHW + 96; };
     auto to_row_end = [&](const int ql) {
-        if (!LAST) scan_multi<LONG>(tab, lt, KW, q, 32u * SC_PHW + 32u, pc, sw);
+        if (inside(ql)) scan_multi<LONG>(tab, lt, KW, q, 32u * SC_PHW + 32u, pc, sw);
         if (LAST || LONG) cut = scan_single<LAST, LONG>(tab, lt, KW, q, 32u * SC_PHW, ql, pc, sw);
     };
     if (!REDO) {
@@ -497,7 +526,7 @@ __device__ __forceinline__ void scan_strip_gen(const lds_u8 *tab, const u16 *lt,
         if (walking) {
             u32 c = 0;
             if (!cut) {
-                if (!LAST) scan_multi<LONG>(tab, lt, KW, q, 288u, c, sw);
+                if (inside(ql)) scan_multi<LONG>(tab, lt, KW, q, 288u, c, sw);
                 cut = scan_single<LAST, LONG>(tab, lt, KW, q, 288u, ql, c, sw);
             }
             o.set_cnt(2 * k, c);
