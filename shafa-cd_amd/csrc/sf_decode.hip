@@ -809,17 +809,19 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                 const u32 x = mis + (pre - done);
                 // LDS addresses are absolute from here on (the dynamic segment's base folded into the constants): an
                 // address that is "base + variable" costs an add per look-up that the ds instructions cannot absorb
-                u32 wp = img_off + (x & ~3u), nb8 = (x & 3u) * 8, acc = 0;
-                // n symbols (low bytes of syms) join the word being gathered; a finished word is ORed into the image
-                auto emit = [&](const u32 n, const u32 syms) {
-                    const u32 nbn = nb8 + 8 * n;
-                    acc |= syms << nb8;
-                    if (nbn >= 32) {                    // only the lanes with a finished word touch the image
+                // the bytes already in the word being gathered are counted in the TOP two bits of nbx: adding a look-up's
+                // count (the top two bits of its entry) carries out exactly when the word is finished
+                u32 wp = img_off + (x & ~3u), nbx = x << 30, acc = 0;
+                // the symbols of entry e (its low bytes; count in bits 30..31) join the word being gathered; a finished word
+                // is ORed into the image
+                auto emit = [&](const u32 e) {
+                    const u32 sh = nbx >> 27, syms = e & 0xFFFFFFu;
+                    acc |= syms << sh;
+                    if (__builtin_add_overflow(nbx, e & 0xC0000000u, &nbx)) {   // only the lanes with a finished word touch the image
                         __hip_atomic_fetch_or((lds_u32 *)(size_t)wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         wp += 4u;
-                        acc = syms >> (32u - nb8);      // the bytes that did not fit (nb8 >= 8 here: n <= 3)
+                        acc = syms >> (32u - sh);       // the bytes that did not fit (sh >= 8 here: at most three symbols)
                     }
-                    nb8 = nbn & 31u;
                 };
                 // the rows hold the stream LSB first; the 64 bits around the position shifted down to two bits in
                 // front of it are the window times four, the byte offset of its table entry: alignbit, and, read
@@ -843,7 +845,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                         n = n < want ? n : want;
                         syms &= (1u << (8 * n)) - 1u;
                     }
-                    emit(n, syms);
+                    emit(syms | n << 30);
                     q2 += (e >> 24) & 63u;
                     want -= n;
                 };
@@ -854,39 +856,41 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                 auto multi = [&](auto nlook) {
                     constexpr u32 N = decltype(nlook)::value;
                     if (by_pos) {
-                        const u32 q2stop = q2end - N * K3, b0 = wp + (nb8 >> 3);
+                        // (the top bytes of a fetch's entries — bits used, symbols << 6 — are summed: at most 30 bits, so the
+                        // sum's low five bits are the next look-up's shift as they stand)
+                        const u32 q2stop = q2end - N * K3, b0 = wp + (nbx >> 30);
                         while ((int)q2 <= (int)q2stop) {
                             const u32 w4 = window4();
-                            u32 used = 0, e = 0;
+                            u32 ua = 0, e = 0;
 #pragma unroll
                             for (u32 i = 0; i < N; ++i) {
-                                e = *(const lds_u32 *)(size_t)(tab_off + ((w4 >> used) & mask4));
-                                emit(e >> 30, e & 0xFFFFFFu);
-                                used += (e >> 24) & 63u;
+                                e = *(const lds_u32 *)(size_t)(tab_off + ((w4 >> (ua & 31u)) & mask4));
+                                emit(e);
+                                ua += e >> 24;
                             }
-                            q2 += used;
+                            q2 += ua & 63u;
                             if (ESC && __builtin_expect((e >> 30) == 0, 0)) { want += 1u; step(false); }   // (step counts its symbol down)
                         }
-                        want -= wp + (nb8 >> 3) - b0;       // image bytes = symbols
+                        want -= wp + (nbx >> 30) - b0;      // image bytes = symbols
                     }
                     while (want >= 3 * N) {
                         const u32 w4 = window4();
-                        u32 used = 0, e = 0;
+                        u32 ua = 0, e = 0;
 #pragma unroll
                         for (u32 i = 0; i < N; ++i) {
-                            e = *(const lds_u32 *)(size_t)(tab_off + ((w4 >> used) & mask4));
-                            emit(e >> 30, e & 0xFFFFFFu);
-                            used += (e >> 24) & 63u;
-                            want -= e >> 30;
+                            e = *(const lds_u32 *)(size_t)(tab_off + ((w4 >> (ua & 31u)) & mask4));
+                            emit(e);
+                            ua += e >> 24;
                         }
-                        q2 += used;
+                        q2 += ua & 63u;
+                        want -= ua >> 6;
                         if (ESC && __builtin_expect((e >> 30) == 0, 0)) step(false);
                     }
                 };
                 if (K3 <= 10) multi(std::integral_constant<u32, 3>{});
                 else if (K3 <= 15) multi(std::integral_constant<u32, 2>{});
                 while (want) step(true);
-                if (nb8) __hip_atomic_fetch_or((lds_u32 *)(size_t)wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (nbx) __hip_atomic_fetch_or((lds_u32 *)(size_t)wp, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             lds_barrier();
             // Image bytes [mis, end) are this round's symbols.  Whole 16-byte pieces leave as aligned stores; the piece the round
