@@ -419,7 +419,7 @@ def pipeline_leg(args, pkg, torch, dev, st, steps, nb, kind):
     rle_n = [int(x) for x in d_rle_n.cpu().numpy()]
     freq = d_freq.cpu().numpy().astype(np.uint64).reshape(nb, 256)
     t0 = time.perf_counter()
-    tables = bt._tables([pkg.sf_build_codes(freq[b]) for b in range(nb)])
+    tables = pkg.sf_build_codes_batch(freq)            # Module T for the launch's blocks (host: one call, up to 8 threads)
     t_t = time.perf_counter() - t0
     lens = np.stack([tables[b].lens() for b in range(nb)]).astype(np.uint64)
     enc_bytes = [int(x) for x in ((freq * lens).sum(axis=1) + 7) // 8]
@@ -533,7 +533,7 @@ def main():
         bt.hist256(st, d_in, in_off, in_n, d_freq)
     bt.finish(st, nb)
     freq = d_freq.cpu().numpy().astype(np.uint64).reshape(nb, 256)
-    tables = bt._tables([pkg.sf_build_codes(freq[b]) for b in range(nb)])     # Module T, host
+    tables = pkg.sf_build_codes_batch(freq)                                     # Module T, host
     lens = np.stack([tables[b].lens() for b in range(nb)]).astype(np.uint64)
     enc_bits = (freq * lens).sum(axis=1)
     enc_bytes = (enc_bits + 7) // 8

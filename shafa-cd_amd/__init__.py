@@ -446,6 +446,8 @@ def host():
     u64p, tp = C.POINTER(C.c_uint64), C.POINTER(CodeTable)
     H.shafa_sf_build_codes.argtypes = [u64p, tp]
     H.shafa_sf_build_codes.restype = None
+    H.shafa_sf_build_codes_batch.argtypes = [u64p, C.c_int, tp]
+    H.shafa_sf_build_codes_batch.restype = None
     H.shafa_freq_format.argtypes = [u64p, C.c_char_p]
     H.shafa_freq_format.restype = C.c_size_t
     H.shafa_freq_parse.argtypes = [C.c_char_p, u64p]
@@ -466,6 +468,14 @@ def sf_build_codes(freq):
     t = CodeTable()
     host().shafa_sf_build_codes(f.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(t))
     return t
+
+
+def sf_build_codes_batch(freq):
+    """Module T on n histograms (array n x 256) -> ctypes array of n CodeTable (what Batch.sf_encode / sf_decode take)."""
+    f = np.ascontiguousarray(freq, dtype=np.uint64).reshape(-1, 256)
+    arr = (CodeTable * f.shape[0])()
+    host().shafa_sf_build_codes_batch(f.ctypes.data_as(C.POINTER(C.c_uint64)), f.shape[0], arr)
+    return arr
 
 
 def freq_format(freq):

@@ -12,6 +12,8 @@
  */
 #include "shafa_host.h"
 
+#include <pthread.h>
+#include <stdatomic.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -71,4 +73,35 @@ void shafa_sf_build_codes(const uint64_t freq[256], shafa_code_table *out)
         stack[top].a = cut + 1; stack[top].b = b; ++top;
         stack[top].a = a; stack[top].b = cut; ++top;
     }
+}
+
+/* Module T for the n histograms of a launch (n x 256 counts in, n tables out): the blocks are independent (t.c:286-300 builds
+ * them one after the other), so they are handed out by a counter to the caller and up to seven helper threads — a helper
+ * is worth starting for sixteen blocks or more; the result does not depend on how many could be started. */
+typedef struct { const uint64_t *freq; shafa_code_table *out; int n; atomic_int next; } t_batch;
+
+static void *t_batch_main(void *arg)
+{
+    t_batch *tb = arg;
+    for (;;) {
+        const int b = atomic_fetch_add_explicit(&tb->next, 1, memory_order_relaxed);
+        if (b >= tb->n) break;
+        shafa_sf_build_codes(tb->freq + (size_t)b * 256, &tb->out[b]);
+    }
+    return NULL;
+}
+
+void shafa_sf_build_codes_batch(const uint64_t *freq, int n, shafa_code_table *out)
+{
+    if (n <= 0) return;
+    t_batch tb = {freq, out, n, 0};
+    pthread_t th[7];
+    int helpers = n / 16, started = 0;
+    if (helpers > 7) helpers = 7;
+    for (int i = 0; i < helpers; ++i) {
+        if (pthread_create(&th[started], NULL, t_batch_main, &tb) != 0) break;
+        ++started;
+    }
+    t_batch_main(&tb);
+    for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
 }

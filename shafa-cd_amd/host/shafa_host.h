@@ -54,6 +54,8 @@ int shafa_cod_parse(const char *text, shafa_code_table *t);
 
 /* ---- Module T core (t.c:74-210): Shannon-Fano codes of one histogram ---------------------------- */
 void shafa_sf_build_codes(const uint64_t freq[256], shafa_code_table *out);
+/* the same for n histograms (n x 256 counts, n tables), blocks spread over up to eight threads */
+void shafa_sf_build_codes_batch(const uint64_t *freq, int n, shafa_code_table *out);
 
 /* f.c:250-258: block-0 rule that switches RLE on/off for the whole file */
 bool shafa_rle_worthwhile(uint64_t n0, uint64_t rle0, bool force_rle);

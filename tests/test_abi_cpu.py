@@ -86,6 +86,22 @@ def test_host_module_t_and_formats_match_reference_files(shafa, case, stem):
         assert rc == 0 and bytes(tab2.bits) == bytes(tab.bits) and bytes(tab2.len) == bytes(tab.len)
 
 
+def test_host_module_t_batch_equals_block_by_block(shafa):
+    """shafa_sf_build_codes_batch (the launch's blocks over threads) = shafa_sf_build_codes per block, whatever the count."""
+    rng = np.random.default_rng(5)
+    for n in (1, 15, 16, 130):
+        freq = rng.integers(0, 1 << 20, size=(n, 256), dtype=np.uint64)
+        freq[0, 1:] = 0                                   # one symbol: no codes
+        if n > 2:
+            freq[1] = 0                                   # empty histogram
+            freq[2] = 1 << np.minimum(np.arange(256, dtype=np.uint64), 62)     # geometric: codes of up to 255 bits
+        arr = shafa.sf_build_codes_batch(freq)
+        assert len(arr) == n
+        for b in range(n):
+            one = shafa.sf_build_codes(freq[b])
+            assert bytes(arr[b].len) == bytes(one.len) and bytes(arr[b].bits) == bytes(one.bits), (n, b)
+
+
 def test_host_parsers_reject_malformed(shafa):
     assert shafa.freq_parse(b";" * 255)[0] == shafa.FILE_UNRECOGNIZABLE          # field 0 must be a number
     assert shafa.freq_parse(b"1" + b";" * 254)[0] == shafa.FILE_UNRECOGNIZABLE   # 255 fields
