@@ -58,7 +58,7 @@ typedef __attribute__((address_space(3))) u8 lds_u8;
 template <int LONG> constexpr u32 spec_emask() { return LONG == 2 ? 31u : 15u; }
 
 // per block: tiles whose first lane's guess differs from the previous tile's exit get tile_fix = 1 (redone by
-// sfd_spec<true>); FINAL: any difference left sends the block to the exact kernels
+// sfd_scan<true>); FINAL: any difference left sends the block to the exact kernels
 template <bool FINAL>
 __global__ __launch_bounds__(DEC_THREADS) void sfd_spec_check(const DecBlk *__restrict__ blks, const u8 *__restrict__ tile_guess,
                                                               const u8 *__restrict__ tile_exit, u8 *__restrict__ tile_fix)
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_spec_check(const DecBlk *__re
 // single codes up to 288), start chunk 2 k + 1 (three codes per look-up while the fetch stays inside the row: q < 512).
 // The run-up is the same last step on a row that holds the 32 bytes in front of the strip.
 // Lanes whose guess differs from the exit of the lane before them walk again from that exit until they are back on
-// their first path (scan_strip<.., true>: the wave reloads the phases, only those lanes walk); the first lane of a wave
+// their first path (scan_strip_gen<.., true>: the wave reloads the phases, only those lanes walk); the first lane of a wave
 // is compared with the wave before it by sfd_spec_check and redone by sfd_scan<true> with its entry forced.
 // ================================================================================================
 constexpr int SC_PHW = 16;                          // stream words per phase and strip (64 bytes)
@@ -1003,9 +1003,8 @@ template <class F> static void for_blocks_parallel(int nblocks, F fn)
 static int g_sfd_speculate = 1;                    // 0 never, 1 where spec_worthwhile() says so, 2 wherever the kernels apply
 void sfdec_configure(int speculate) { g_sfd_speculate = speculate; }
 // test knob ("sf_decode_path"): 0 = the fastest kernels the launch's tables allow; 1 = treat every table as if it were not
-// a complete code: one code per look-up (sfd_sync16<false> + sfd_count13 + sfd_write13 for Lmax <= 13, the two-level
-// LUT passes sfd_count / sfd_write for 14..16 bits); 2 = the generic byte-map kernels (sfd_sync / sfd_tiles / sfd_count /
-// sfd_write) that otherwise serve codes of more than 32 bits
+// a complete code and 2 = the same: the generic byte-map kernels (sfd_sync / sfd_tiles / sfd_count / sfd_write) that
+// otherwise serve incomplete tables and codes of more than 32 bits (the single-code kernels 1 used to select are gone)
 static int g_sfd_path = 0;
 void sfdec_configure_path(int path) { g_sfd_path = path; }
 
@@ -1153,7 +1152,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     // (long_all and mid32 launches too: a code of more than 13 bits is an escape inside the walk)
     const bool spec_path = (packed || mid32) && g_sfd_speculate != 0;
     const int spec_long = mid32 ? 2 : long_all ? 1 : 0;
-    // window of sfd_spec's counting tables.  A 13-bit table in a launch with the table of long codes (which holds every code
+    // window of sfd_scan's counting tables.  A 13-bit table in a launch with the table of long codes (which holds every code
     // of more than 12 bits, by 12-bit prefix) may count with 12-bit windows: the 13-bit codes become escapes like the 14..16-
     // bit ones, 8 KB of tables instead of 16 fit six workgroups on a CU instead of four (LABNOTES.md §3.2).  Worth it while the
     // 13-bit codes are few (an escape is a binary search that the whole wave waits for): at most eight of them, 0.1 % of the

@@ -13,7 +13,7 @@ constexpr int HALO_WORDS = 16;                     // 64 bytes past the tile (wi
 constexpr int DATA_WORDS = DTILE / 4 + HALO_WORDS;
 constexpr int LUT_MAXK = 11;
 constexpr int LUT2_MAX = 4096;                     // level-2 entries kept in LDS (8 KiB)
-constexpr int SPEC_MINW = 1;                       // narrowest window of the counting table of sfd_spec (1 = the longest code's
+constexpr int SPEC_MINW = 1;                       // narrowest window of the counting table of sfd_scan (1 = the longest code's
                                                    // length; measured on Lmax = 10 data: 11 bits no gain, 12 bits 3 % slower:
                                                    // fewer steps, but an 8 KiB table costs two workgroups per CU)
 constexpr int SYM3_MINW = 1;                       // narrowest window of the three-symbols table of sfd_wstage (1 = the longest
@@ -50,7 +50,7 @@ struct DecBlk {
     u32 n_tiles;
     u32 n_l2;              // level-2 entries
     u32 n_states;          // internal trie nodes = states of the counting automaton (<= 255 for a complete code)
-    u32 KW;                // window of sfd_spec's counting tables (spec_window(K1), or 12 for 13-bit tables whose 13-bit codes are few)
+    u32 KW;                // window of sfd_scan's counting tables (spec_window(K1), or 12 for 13-bit tables whose 13-bit codes are few)
     u32 *fsm4;             // [state][nibble]: next state * 64 | codes completed << 16   (complete codes; sfd_tables)
     u32 *fsm1;             // [state][bit]   : same, for one bit
     const u8 *lenlut32;    // 2^13 entries: len <= 13, or 128 + k = internal node root13[k] of long32 (16 < Lmax <= 32 launches)
@@ -60,7 +60,7 @@ struct DecBlk {
                            //   tried speculatively or did not verify; NULL: no speculation, the DP kernels always run
 };
 
-// window of the code-counting table of sfd_spec: wider than the longest code when that is short (more bits per look-up)
+// window of the code-counting table of sfd_scan: wider than the longest code when that is short (more bits per look-up)
 __host__ __device__ __forceinline__ u32 spec_window(u32 K1) { return K1 < (u32)SPEC_MINW ? (u32)SPEC_MINW : K1; }
 // window of the three-symbols table of sfd_wstage
 __host__ __device__ __forceinline__ u32 sym3_window(u32 K1)

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_tables(const DecBlk *__restri
             if (n == 0) l0 = L;
             pos += L;
         }
-        const u32 j = __builtin_bitreverse32(i) >> (32 - KW);    // sfd_spec reads its windows LSB first
+        const u32 j = __builtin_bitreverse32(i) >> (32 - KW);    // sfd_scan reads its windows LSB first
         ((u8 *)blk.cnt3)[j] = (u8)(pos | (n << 5));              // bits in the low five: the sum of a fetch's entries is the next look-up's shift
         ((u8 *)blk.cnt3)[(1u << KW) + j] = (u8)l0;
     }

@@ -405,7 +405,7 @@ DEFAULT_OPTIONS = {"sf_encode_one_pass_min_blocks": 0, "sf_encode_lanes": 0, "sf
     {"sf_encode_one_pass_min_blocks": 1, "sf_encode_window_bits": 4},      # ... windows too small: flagged, encoded again (256 lanes)
     {"sf_decode_speculate": 0},                                            # exact DP kernels (sfd_sync16 / sfd_countfsm)
     {"sf_decode_speculate": 2},                                            # speculative entries whatever the code
-    {"sf_decode_path": 1},                                                 # one code per look-up (sfd_count13 / sfd_write13, sfd_count / sfd_write)
+    {"sf_decode_path": 1},                                                 # tables treated as incomplete: the byte-map kernels
     {"sf_decode_path": 2},                                                 # generic byte-map kernels (sfd_sync / sfd_tiles)
     {"rle_encode_general": 1},                                             # per-element general RLE tile code for every tile
 ], ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))

@@ -1,5 +1,5 @@
 """GPU parity of the Shannon-Fano decoder's two newer passes (sf_decode.hip; reference d.c:171-300 decode_shafa):
-  * sfd_spec: speculative chunk entries, verified exactly, with a per-block fall-back to the exact kernels;
+  * sfd_scan: speculative chunk entries, verified exactly, with a per-block fall-back to the exact kernels;
   * sfd_wstage: the symbol pass staged through an LDS image of the output.
 Every launch is decoded with "sf_decode_speculate" 0 (exact kernels only), 1 (host heuristic) and 2 (speculate
 whatever the code: exercises the device-side fall-back); the three must give the block's original bytes, and
