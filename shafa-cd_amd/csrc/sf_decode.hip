@@ -667,7 +667,7 @@ __global__ __launch_bounds__(DEC_THREADS) __attribute__((amdgpu_waves_per_eu(FIX
 // The host sizes the image for the launch's average symbols per tile plus a margin (LDS is what limits the waves per
 // CU); a tile with more symbols than it holds goes in several rounds of consecutive lanes.
 // ------------------------------------------------------------------------------------------------
-constexpr int WS_ROW = CH_BYTES / 4 + 1;            // LDS words per chunk row
+constexpr int WS_ROW = CH_BYTES / 4 + 2;            // LDS words per chunk row: the chunk and the two words behind it
 constexpr int WS_ROWS_BYTES = 16 + DEC_THREADS * WS_ROW * 4;     // 16 in front: the window at a row's bit 0 reads the word before it
 constexpr int WS_MISC = 32;
 
@@ -734,14 +734,14 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
         // the entry of the chunk behind this one = where this chunk's codes end (not asked for in a block's last tile)
         pf_next = (tile + 1 < blk.n_tiles || tid + 1 < (u32)DEC_THREADS) ? chunk_entry[g + 1] : 0u;
     };
-    // tile word f -> LDS word f + f / 8; the first word of a row is also the look-ahead word of the row before
+    // tile word f -> LDS word f + 2 (f / 8); the first two words of a row are also the look-ahead words of the row before
     auto put16 = [&](const u32 i, const uint4 v) {
-        const u32 f = 4 * i, at = f + (f >> 3);
-        const u32 w0 = rev_bytes(v.x);
-        if ((f & 7u) == 0 && f > 0) rows[at - 1] = w0;
+        const u32 f = 4 * i, at = f + 2 * (f >> 3);
+        const u32 w0 = rev_bytes(v.x), w1 = rev_bytes(v.y);
+        if ((f & 7u) == 0 && f > 0) { rows[at - 2] = w0; rows[at - 1] = w1; }
         if (i < (u32)(DTILE / 16)) {
             rows[at] = w0;
-            rows[at + 1] = rev_bytes(v.y);
+            rows[at + 1] = w1;
             rows[at + 2] = rev_bytes(v.z);
             rows[at + 3] = rev_bytes(v.w);
         }
@@ -786,13 +786,15 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
         for (u32 done = 0; done < tot_c;) {
             u8 *gout = blk.out + toff + done;
             const u32 mis = (u32)((uintptr_t)gout & 15u);
-            if (carry_n && (carry_n != mis || carry_g != gout - mis)) {      // (uniform) the kept piece is not where this round
+            if (carry_g && (carry_n != mis || carry_g != gout - mis)) {      // (uniform) the kept pieces are not where this round
                 if (tid == 0) {                                              //   starts (cannot happen while tile offsets are a
-                    uint4 *ip = (uint4 *)(smem + img_off);                   //   scan of the counts): it leaves first
+                    uint4 *ip = (uint4 *)(smem + img_off);                   //   scan of the counts): they leave first
                     store_bytes(carry_g, *ip, carry_lo, carry_n);
-                    *ip = make_uint4(0, 0, 0, 0);
+                    ip[0] = make_uint4(0, 0, 0, 0);
+                    ip[1] = make_uint4(0, 0, 0, 0);
                 }
                 carry_n = 0;
+                carry_g = nullptr;
                 lds_barrier();
             }
             const u32 capw = cap - 32;
@@ -855,9 +857,28 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                 // the same round see the same window and do nothing either; the long code is then taken by one step
                 auto multi = [&](auto nlook) {
                     constexpr u32 N = decltype(nlook)::value;
-                    if (by_pos) {
-                        // (the top bytes of a fetch's entries — bits used, symbols << 6 — are summed: at most 30 bits, so the
-                        // sum's low five bits are the next look-up's shift as they stand)
+                    // (the top bytes of a fetch's entries — bits used, symbols << 6 — are summed: at most 30 bits, so the
+                    // sum's low five bits are the next look-up's shift as they stand)
+                    if (by_pos && !ESC) {
+                        // Whole fetches while the fetch STARTS in front of the end: the last one runs into the next chunk by up
+                        // to 29 bits and eight symbols — the very symbols the next lane (round, tile) places at the very bytes
+                        // this lane's word pointer has reached, and an OR of equal bytes changes nothing.  No tail of clipped
+                        // single steps, no count.  (Every look-up reads 10 bits from at most 19 bits behind the end: inside the
+                        // row's two look-ahead words.  The bytes this leaves behind the round's end stay in the image with the
+                        // piece the round ends in, below.)
+                        while ((int)q2 < (int)q2end) {
+                            const u32 w4 = window4();
+                            u32 ua = 0;
+#pragma unroll
+                            for (u32 i = 0; i < N; ++i) {
+                                const u32 e = *(const lds_u32 *)(size_t)(tab_off + ((w4 >> (ua & 31u)) & mask4));
+                                emit(e);
+                                ua += e >> 24;
+                            }
+                            q2 += ua & 63u;
+                        }
+                        want = 0;
+                    } else if (by_pos) {
                         const u32 q2stop = q2end - N * K3, b0 = wp + (nbx >> 30);
                         while ((int)q2 <= (int)q2stop) {
                             const u32 w4 = window4();
@@ -908,12 +929,13 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                 if (u == 0 && lo0) store_bytes(g0, v, lo0, 16u);
                 else gstore_nt<uint4>(g0 + 16 * u, v);
             }
-            if (tid == 0) {                             // the piece the round ends in moves to the front of the image
-                if ((end & 15u) && nfull) {
-                    uint4 *ip = (uint4 *)(smem + img_off + 16 * nfull);
-                    *(uint4 *)(smem + img_off) = *ip;
-                    *ip = make_uint4(0, 0, 0, 0);
-                }
+            if (tid == 0 && nfull) {                    // the piece the round ends in and the one behind it (symbols of the next
+                uint4 *ip = (uint4 *)(smem + img_off);  //   chunk that the round's last lane has already placed there) move to
+                const uint4 a = ip[nfull], b = ip[nfull + 1];           //   the front of the image
+                ip[nfull] = make_uint4(0, 0, 0, 0);
+                ip[nfull + 1] = make_uint4(0, 0, 0, 0);
+                ip[0] = a;
+                ip[1] = b;
             }
             carry_lo = nfull ? 0u : lo0;
             carry_n = end & 15u;
