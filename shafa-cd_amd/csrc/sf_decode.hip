@@ -668,7 +668,9 @@ __global__ __launch_bounds__(DEC_THREADS) __attribute__((amdgpu_waves_per_eu(FIX
 // CU); a tile with more symbols than it holds goes in several rounds of consecutive lanes.
 // ------------------------------------------------------------------------------------------------
 constexpr int WS_ROW = CH_BYTES / 4 + 2;            // LDS words per chunk row: the chunk and the two words behind it
-constexpr int WS_ROWS_BYTES = 16 + DEC_THREADS * WS_ROW * 4;     // 16 in front: the window at a row's bit 0 reads the word before it
+// rows 10 words apart put lanes 16 apart on one bank: every 16 rows the rows move on by a word (row r at word 10 r + r / 16),
+// so that the 32 lanes of a half wave that are at the same word of their rows are on 32 banks
+constexpr int WS_ROWS_BYTES = 16 + (DEC_THREADS * WS_ROW + DEC_THREADS / 16) * 4;   // 16 in front: the window at a row's bit 0 reads the word before it
 constexpr int WS_MISC = 32;
 
 // ESC: some code of the launch may be longer than its block's sym3 window (then a look-up can return no symbol)
@@ -706,7 +708,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
     // LDS addresses as literals: the kernel has no static LDS, so its dynamic segment starts at 0 (checked), and a
     // literal goes into the ds offset field where "smem + offset" leaves an add per look-up
     if (lds_addr(smem) != 0) __builtin_trap();
-    const u32 q2row = 8u * (16u + 4u * WS_ROW * tid) - 2u;      // LDS bit address of the lane's row, minus 2 (see step)
+    const u32 q2row = 8u * (16u + 4u * (WS_ROW * tid + (tid >> 4))) - 2u;     // LDS bit address of the lane's row, minus 2 (see step)
     const u32 mask4 = ((1u << K3) - 1u) << 2;
     // 16 stream bytes at `off` (zeros past the end)
     auto fetch16 = [&](const u64 off) -> uint4 {
@@ -736,9 +738,13 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
     };
     // tile word f -> LDS word f + 2 (f / 8); the first two words of a row are also the look-ahead words of the row before
     auto put16 = [&](const u32 i, const uint4 v) {
-        const u32 f = 4 * i, at = f + 2 * (f >> 3);
+        const u32 f = 4 * i, at = f + 2 * (f >> 3) + (f >> 7);
         const u32 w0 = rev_bytes(v.x), w1 = rev_bytes(v.y);
-        if ((f & 7u) == 0 && f > 0) { rows[at - 2] = w0; rows[at - 1] = w1; }
+        if ((f & 7u) == 0 && f > 0) {                  // (the row in front ends a word earlier when this row is the first of its 16)
+            const u32 lk = at - 2u - ((f & 127u) == 0 ? 1u : 0u);
+            rows[lk] = w0;
+            rows[lk + 1] = w1;
+        }
         if (i < (u32)(DTILE / 16)) {
             rows[at] = w0;
             rows[at + 1] = w1;
