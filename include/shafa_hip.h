@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SHAFA_HIP_ABI_VERSION 7
+#define SHAFA_HIP_ABI_VERSION 8
 
 /* utils/errors.h:5-16 (_modules_error), same numbers */
 enum shafa_error {
@@ -150,6 +150,15 @@ void shafa_hipd_batch_destroy(shafa_hipd_batch *b);
 /* make_freq per block: d_freq[b*256 + s], 64-bit counts. */
 int shafa_hipd_hist256(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,
                        const uint64_t *h_in_off, const uint64_t *h_in_n, uint64_t *d_freq);
+
+/* Module T's core on the device (t.c:74-210, the rule set of host/sfcodes.c shafa_sf_build_codes): d_freq = nblocks x 256
+ * counts (what shafa_hipd_hist256 / _rle_encode leave), d_tables = nblocks tables in DEVICE memory, bit-identical to the
+ * host's for counts whose sum fits 64 bits (a block's own histogram always does; else SHAFA_OUTSIDE_MODULE for the block
+ * and an empty table).  One workgroup per block.  The encoder's and decoder's entry points take their tables from the
+ * HOST (their launchers choose kernels by the longest code): this is for callers that keep histograms and tables on the
+ * GPU, and the device-side half of a host-free F -> T -> C. */
+int shafa_hipd_sf_build_codes(shafa_hipd_batch *b, void *stream, int nblocks, const uint64_t *d_freq,
+                              shafa_code_table *d_tables);
 
 /* block_compression per block; d_out_n[b] = RLE size; d_freq (may be NULL) = histogram of the RLE bytes. */
 int shafa_hipd_rle_encode(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,

@@ -106,6 +106,7 @@ def lib():
     L.shafa_hipd_sf_encode.argtypes = [vp, vp, C.c_int, u8p, u64p, u64p, tp, u8p, u64p, u64p, vp]
     L.shafa_hipd_sf_decode.argtypes = [vp, vp, C.c_int, u8p, u64p, u64p, tp, u64p, u8p, u64p]
     L.shafa_hipd_rle_decode.argtypes = [vp, vp, C.c_int, u8p, u64p, u64p, u8p, u64p, u64p, vp]
+    L.shafa_hipd_sf_build_codes.argtypes = [vp, vp, C.c_int, vp, vp]
     L.shafa_hip_tile_hist_bytes.argtypes = [C.c_size_t]
     L.shafa_hip_tile_hist_bytes.restype = C.c_size_t
     L.shafa_hipd_hist256_tiles.argtypes = [vp, vp, C.c_int, u8p, u64p, u64p, vp, u8p, u64p]
@@ -274,6 +275,11 @@ class Batch:
         io, il = _u64arr(in_off), _u64arr(in_n)
         _check(lib().shafa_hipd_hist256(self.h, self._st(stream), len(io), d_in.data_ptr(), _p64(io), _p64(il),
                                         d_freq.data_ptr()), "hipd_hist256")
+
+    def sf_build_codes(self, stream, nblocks, d_freq, d_tables):
+        """Module T on the device: d_freq nblocks x 256 u64 -> d_tables nblocks x sizeof(CodeTable) bytes (device memory)."""
+        _check(lib().shafa_hipd_sf_build_codes(self.h, self._st(stream), nblocks, d_freq.data_ptr(), d_tables.data_ptr()),
+               "hipd_sf_build_codes")
 
     def rle_encode(self, stream, d_in, in_off, in_n, d_out, out_off, out_cap, d_out_n, d_freq=None):
         io, il, oo, oc = _u64arr(in_off), _u64arr(in_n), _u64arr(out_off), _u64arr(out_cap)

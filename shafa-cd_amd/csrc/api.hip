@@ -309,6 +309,13 @@ int shafa_hipd_hist256(shafa_hipd_batch *b, void *stream, int nblocks, const uin
     return hist_launch((Batch *)b, (hipStream_t)stream, nblocks, d_in, h_in_off, h_in_n, d_freq);
 }
 
+int shafa_hipd_sf_build_codes(shafa_hipd_batch *b, void *stream, int nblocks, const uint64_t *d_freq, shafa_code_table *d_tables)
+{
+    if (!d_freq || !d_tables) return SHAFA_OUTSIDE_MODULE;
+    if (int rc = batch_enter((Batch *)b, (hipStream_t)stream)) return rc;
+    return sftab_launch((Batch *)b, (hipStream_t)stream, nblocks, d_freq, d_tables);
+}
+
 size_t shafa_hip_tile_hist_bytes(size_t n) { return ((n + SHAFA_TILE_BYTES - 1) / SHAFA_TILE_BYTES) * 512; }
 
 int shafa_hipd_hist256_tiles(shafa_hipd_batch *b, void *stream, int nblocks, const uint8_t *d_in,

@@ -126,6 +126,8 @@ struct SfeRedo {
 };
 
 // ---- launchers (one per reference function) ------------------------------------------------------
+// Module T on the device (sf_tables.hip): nblocks x 256 counts -> nblocks tables, both in device memory
+int sftab_launch(Batch *bt, hipStream_t st, int nblocks, const u64 *d_freq, shafa_code_table *d_tables);
 int hist_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                 const u64 *h_in_n, u64 *d_freq);
 // d_thist / h_thist_off (both or neither): also write every 32 KiB tile's own histogram (256 x u16) to d_thist + h_thist_off[b]

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(shafa):
     L = ctypes.CDLL(shafa.LIB_PATH)
     missing = [s for s in syms if not hasattr(L, s)]
     assert not missing, f"declared in include/shafa_hip.h but not exported: {missing}"
-    assert L.shafa_hip_abi_version() == 7
+    assert L.shafa_hip_abi_version() == 8
     assert ctypes.sizeof(shafa.CodeTable) == 256 + 256 * 32
 
 
