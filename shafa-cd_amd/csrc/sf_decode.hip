@@ -667,10 +667,15 @@ __global__ __launch_bounds__(DEC_THREADS) __attribute__((amdgpu_waves_per_eu(FIX
 // The host sizes the image for the launch's average symbols per tile plus a margin (LDS is what limits the waves per
 // CU); a tile with more symbols than it holds goes in several rounds of consecutive lanes.
 // ------------------------------------------------------------------------------------------------
-constexpr int WS_ROW = CH_BYTES / 4 + 2;            // LDS words per chunk row: the chunk and the two words behind it
-// rows 10 words apart put lanes 16 apart on one bank: every 16 rows the rows move on by a word (row r at word 10 r + r / 16),
-// so that the 32 lanes of a half wave that are at the same word of their rows are on 32 banks
-constexpr int WS_ROWS_BYTES = 16 + (DEC_THREADS * WS_ROW + DEC_THREADS / 16) * 4;   // 16 in front: the window at a row's bit 0 reads the word before it
+// LDS words per chunk row: the chunk and the words behind it that the last fetch of the walk may read — two, or three when a
+// code longer than the window (ESC: read as 32 bits) may start in them.  Rows 10 words apart would put lanes 16 apart on one
+// bank: every 16 rows they move on by a word (row r at word 10 r + r / 16), so that the 32 lanes of a half wave that are at
+// the same word of their rows are on 32 banks; 11 is odd as it is.
+constexpr int ws_row(bool esc) { return CH_BYTES / 4 + (esc ? 3 : 2); }
+constexpr int ws_rows_bytes(bool esc)               // 16 in front: the window at a row's bit 0 reads the word before it
+{
+    return 16 + (DEC_THREADS * ws_row(esc) + (esc ? 0 : DEC_THREADS / 16)) * 4;
+}
 constexpr int WS_MISC = 32;
 
 // ESC: some code of the launch may be longer than its block's sym3 window (then a look-up can return no symbol)
@@ -689,7 +694,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
     // decides whether four workgroups share a CU or two, LABNOTES.md §3.2)
     const u32 LONGB = LONG ? long_bytes : 0u;           // (LONG == 2: header, prefixes, roots and the sub-trie nodes in use)
     u32 *rows = (u32 *)(smem + 16);
-    const u32 tab_off = WS_ROWS_BYTES;
+    constexpr u32 WS_ROW = (u32)ws_row(ESC), tab_off = (u32)ws_rows_bytes(ESC);
     const u16 *lt = (const u16 *)(smem + tab_off + tab_bytes);
     const u32 img_off = tab_off + tab_bytes + LONGB;
     u32 *wsum = (u32 *)(smem + img_off + cap);
@@ -708,7 +713,7 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
     // LDS addresses as literals: the kernel has no static LDS, so its dynamic segment starts at 0 (checked), and a
     // literal goes into the ds offset field where "smem + offset" leaves an add per look-up
     if (lds_addr(smem) != 0) __builtin_trap();
-    const u32 q2row = 8u * (16u + 4u * (WS_ROW * tid + (tid >> 4))) - 2u;     // LDS bit address of the lane's row, minus 2 (see step)
+    const u32 q2row = 8u * (16u + 4u * (WS_ROW * tid + (ESC ? 0u : tid >> 4))) - 2u;     // LDS bit address of the lane's row, minus 2 (see step)
     const u32 mask4 = ((1u << K3) - 1u) << 2;
     // 16 stream bytes at `off` (zeros past the end)
     auto fetch16 = [&](const u64 off) -> uint4 {
@@ -736,19 +741,20 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
         // the entry of the chunk behind this one = where this chunk's codes end (not asked for in a block's last tile)
         pf_next = (tile + 1 < blk.n_tiles || tid + 1 < (u32)DEC_THREADS) ? chunk_entry[g + 1] : 0u;
     };
-    // tile word f -> LDS word f + 2 (f / 8); the first two words of a row are also the look-ahead words of the row before
+    // tile word f -> word f % 8 of row f / 8; a row's first two (ESC: three) words are also the look-ahead words of the row before
     auto put16 = [&](const u32 i, const uint4 v) {
-        const u32 f = 4 * i, at = f + 2 * (f >> 3) + (f >> 7);
-        const u32 w0 = rev_bytes(v.x), w1 = rev_bytes(v.y);
-        if ((f & 7u) == 0 && f > 0) {                  // (the row in front ends a word earlier when this row is the first of its 16)
-            const u32 lk = at - 2u - ((f & 127u) == 0 ? 1u : 0u);
+        const u32 f = 4 * i, at = f + (WS_ROW - 8u) * (f >> 3) + (ESC ? 0u : f >> 7);
+        const u32 w0 = rev_bytes(v.x), w1 = rev_bytes(v.y), w2 = rev_bytes(v.z);
+        if ((f & 7u) == 0 && f > 0) {                  // (not ESC: the row in front ends a word earlier when this row is the first of its 16)
+            const u32 lk = at - (WS_ROW - 8u) - (!ESC && (f & 127u) == 0 ? 1u : 0u);
             rows[lk] = w0;
             rows[lk + 1] = w1;
+            if (ESC) rows[lk + 2] = w2;
         }
         if (i < (u32)(DTILE / 16)) {
             rows[at] = w0;
             rows[at + 1] = w1;
-            rows[at + 2] = rev_bytes(v.z);
+            rows[at + 2] = w2;
             rows[at + 3] = rev_bytes(v.w);
         }
     };
@@ -865,28 +871,14 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                     constexpr u32 N = decltype(nlook)::value;
                     // (the top bytes of a fetch's entries — bits used, symbols << 6 — are summed: at most 30 bits, so the
                     // sum's low five bits are the next look-up's shift as they stand)
-                    if (by_pos && !ESC) {
+                    if (by_pos) {
                         // Whole fetches while the fetch STARTS in front of the end: the last one runs into the next chunk by up
-                        // to 29 bits and eight symbols — the very symbols the next lane (round, tile) places at the very bytes
+                        // to 29 bits and nine symbols — the very symbols the next lane (round, tile) places at the very bytes
                         // this lane's word pointer has reached, and an OR of equal bytes changes nothing.  No tail of clipped
-                        // single steps, no count.  (Every look-up reads 10 bits from at most 19 bits behind the end: inside the
-                        // row's two look-ahead words.  The bytes this leaves behind the round's end stay in the image with the
-                        // piece the round ends in, below.)
+                        // single steps, no count.  (A look-up reads its window from at most 19 bits behind the end, a long
+                        // code 32 bits from there: inside the row's two — ESC: three — look-ahead words.  The bytes this leaves behind the
+                        // round's end stay in the image with the piece the round ends in, below.)
                         while ((int)q2 < (int)q2end) {
-                            const u32 w4 = window4();
-                            u32 ua = 0;
-#pragma unroll
-                            for (u32 i = 0; i < N; ++i) {
-                                const u32 e = *(const lds_u32 *)(size_t)(tab_off + ((w4 >> (ua & 31u)) & mask4));
-                                emit(e);
-                                ua += e >> 24;
-                            }
-                            q2 += ua & 63u;
-                        }
-                        want = 0;
-                    } else if (by_pos) {
-                        const u32 q2stop = q2end - N * K3, b0 = wp + (nbx >> 30);
-                        while ((int)q2 <= (int)q2stop) {
                             const u32 w4 = window4();
                             u32 ua = 0, e = 0;
 #pragma unroll
@@ -896,9 +888,9 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
                                 ua += e >> 24;
                             }
                             q2 += ua & 63u;
-                            if (ESC && __builtin_expect((e >> 30) == 0, 0)) { want += 1u; step(false); }   // (step counts its symbol down)
+                            if (ESC && __builtin_expect((e >> 30) == 0, 0)) step(false);     // a long code stopped the look-ups: it starts at q2
                         }
-                        want -= wp + (nbx >> 30) - b0;      // image bytes = symbols
+                        want = 0;
                     }
                     while (want >= 3 * N) {
                         const u32 w4 = window4();
@@ -1406,6 +1398,8 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     // almost in proportion to the waves it loses, and a CU's LDS is handed out as two halves of 80 KiB (8 workgroups up to
     // 20 KiB each, 6 up to 26.25, 4 up to 40, 2 above: DESIGN.md §3.2).  Codes of up to 12 bits on run-heavy data: 41.7 KB
     // with the wide margin = 2 workgroups per CU, 40 KB with the narrow one = 4.
+    const bool ws_esc = mid32 || (packed && (long_all || lmax_all > (u32)SYM3_MAXK));       // the form launched below
+    const u32 ws_rows = (u32)ws_rows_bytes(ws_esc);
     u32 ws_cap = 4096, ws_tight = 4096;
     for (int b = 0; b < nblocks; ++b) {
         if (!ntiles[b]) continue;
@@ -1416,7 +1410,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     }
     {
         const u32 longb = long_used;
-        const u32 base = (u32)WS_ROWS_BYTES + ws_tab + longb + (u32)WS_MISC;
+        const u32 base = ws_rows + ws_tab + longb + (u32)WS_MISC;
         const u32 most = 65536u - base;                                           // 64 KiB of dynamic LDS
         if (ws_cap > most) ws_cap = most;
         constexpr u32 steps[3] = {20480u, 26880u, 40960u};                        // 8, 6, 4 workgroups per CU as launches show them
@@ -1430,7 +1424,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         }
     }
     ws_cap &= ~15u;
-    const size_t lds_ws = (size_t)WS_ROWS_BYTES + ws_tab + ws_cap + WS_MISC;
+    const size_t lds_ws = (size_t)ws_rows + ws_tab + ws_cap + WS_MISC;
     // the staged symbol pass takes 16 tiles per workgroup (table fill, image zeroing and the prefetch pipeline's start are
     // paid once per workgroup: 7.8 -> 7.7 ms on the headline data against 4; 32: the same), the chip kept full as above
     u32 tpw_ws = 16;
