@@ -516,7 +516,8 @@ int shafa_pipe_wait(shafa_pipe *p, int slot, shafa_pipe_result *res)
     switch (s.op) {
     case SHAFA_OP_FTC:                                   // Module F's results; the slot stays reserved for shafa_pipe_ftc_encode
         memcpy(res->freq, s.h_small, 256 * sizeof(u64));
-        if (s.ftc_flags & SHAFA_PIPE_FTC_RLE) memcpy(res->freq_in, s.h_small + 256, 256 * sizeof(u64));
+        if ((s.ftc_flags & SHAFA_PIPE_FTC_RLE) && (s.ftc_flags & (SHAFA_PIPE_FTC_PLAIN | SHAFA_PIPE_INPUT_HIST)))
+            memcpy(res->freq_in, s.h_small + 256, 256 * sizeof(u64));       // (only a stage one that counted the input has it)
         s.rle_n = (s.ftc_flags & SHAFA_PIPE_FTC_RLE) ? (size_t)s.h_small[512] : 0;
         if (!(s.ftc_flags & SHAFA_PIPE_FTC_RLE)) { res->out_n = 0; return SHAFA_SUCCESS; }
         break;
@@ -541,11 +542,15 @@ int shafa_pipe_wait(shafa_pipe *p, int slot, shafa_pipe_result *res)
     }
     // the size is known now: fetch what the speculative copy at submit did not bring (usually nothing)
     const size_t sz = (size_t)s.h_small[512];
-    if (sz > s.h_out_cap) return SHAFA_LACK_OF_MEMORY;
-    if (sz > s.copied) {
-        HIP_TRY(hipMemcpyAsync(s.h_out + s.copied, s.d_out + s.copied, sz - s.copied, hipMemcpyDeviceToHost, s.st));
-        HIP_TRY(hipStreamSynchronize(s.st));
-    }
+    const int tail_rc = [&]() -> int {
+        if (sz > s.h_out_cap) return SHAFA_LACK_OF_MEMORY;
+        if (sz > s.copied) {
+            HIP_TRY(hipMemcpyAsync(s.h_out + s.copied, s.d_out + s.copied, sz - s.copied, hipMemcpyDeviceToHost, s.st));
+            HIP_TRY(hipStreamSynchronize(s.st));
+        }
+        return SHAFA_SUCCESS;
+    }();
+    if (tail_rc) { s.stage = 0; return tail_rc; }          // (a failed FTC stage one does not keep the slot reserved)
     if (s.op >= 0 && s.op < 8) p->last_out[s.op] = sz;
     res->out_n = sz;
     return SHAFA_SUCCESS;

@@ -793,7 +793,9 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_wstage(const DecBlk *__restri
         // next chunk's entry.  Its main loop then runs on the POSITION (whole fetches while every code taken starts in front
         // of that end) instead of counting symbols down: no count bookkeeping per fetch, and a shorter tail of single steps
         // (on average 15 bits are left instead of 4.5 symbols).
-        const bool by_pos = want == cnt && tile + 1 < blk.n_tiles;
+        // (not when the next entry is the "stream ended in front of this chunk" mark — a truncated stream: the walk would
+        // run on zero fill past the lane's count; the counted loop is exact there)
+        const bool by_pos = want == cnt && tile + 1 < blk.n_tiles && nent != spec_emask<LONG>();
         const u32 q2end = q2row + 256u + nent;
         for (u32 done = 0; done < tot_c;) {
             u8 *gout = blk.out + toff + done;

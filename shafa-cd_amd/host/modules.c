@@ -96,6 +96,16 @@ typedef struct { int fd; uint8_t *buf; size_t n; off_t off; bool write; bool ok;
  * ask for their blocks front to back, so `off` must be where the last read ended. */
 static int seq_fd = -1, seq_back = -1;          /* seq_back: one byte read too far by a header parser (shaf_read_u64), given back */
 static off_t seq_pos = 0;
+/* The state belongs to ONE input at a time: every driver opens its input through in_open(), which forgets the stream before
+ * (a second FIFO in the same process usually gets the same fd number).  Like the module entry points themselves (called from
+ * the main thread only, multithread.c:55-60) it is not thread-safe. */
+static int in_open(const char *path)
+{
+    seq_fd = -1;
+    seq_back = -1;
+    seq_pos = 0;
+    return open(path, O_RDONLY);
+}
 static ssize_t seq_read(int fd, uint8_t *buf, size_t n, off_t off)
 {
     if (seq_fd != fd) { seq_fd = fd; seq_pos = 0; seq_back = -1; }
@@ -463,6 +473,7 @@ static int run_groups(shafa_pipe *pipe, int in_fd, uint64_t first, uint64_t end,
                 const uint64_t widest = out_b > max_out ? out_b : max_out;
                 if (cnt && (large || sum_in + in_b > (16u << 20) || (cnt + 1) * widest > (128u << 20))) {
                     held = g[cnt];                                       /* opens the next group */
+                    g[cnt].staged = NULL;                                /* (the payload now belongs to `held` alone) */
                     have_held = true;
                     break;
                 }
@@ -571,7 +582,7 @@ _modules_error freq_rle_compress(char **path, bool force_rle, bool force_freq, u
 {
     const double t0 = now_ms();
     int err = SHAFA_SUCCESS;
-    const int in = open(*path, O_RDONLY);
+    const int in = in_open(*path);
     if (in < 0) return SHAFA_FILE_INACCESSIBLE;
     const in_budget whole = budget_of(in);                                      /* fsize (f.c:212) */
     uint64_t bs = block_size, last = 0;
@@ -796,7 +807,7 @@ _modules_error shafa_compress(char **path)
     uint64_t n_blocks = 0;
     if (!read_header(&t, &mode, &n_blocks)) { free(t.buf); return SHAFA_FILE_UNRECOGNIZABLE; }   /* c.c:333,447 */
 
-    const int in = open(*path, O_RDONLY);
+    const int in = in_open(*path);
     if (in < 0) { free(t.buf); return SHAFA_FILE_INACCESSIBLE; }
     in_budget left = budget_of(in);
     char *p_shaf = shafa_add_ext(*path, SHAFA_SHAFA_EXT);
@@ -902,7 +913,7 @@ int shafa_ftc_compress(char **path, bool force_rle, bool force_freq, unsigned lo
 {
     if (NO_MULTITHREAD || block_size < (2u << 20)) return SHAFA_FTC_NOT_TAKEN;
     const double t0 = now_ms();
-    const int in = open(*path, O_RDONLY);
+    const int in = in_open(*path);
     if (in < 0) return SHAFA_FTC_NOT_TAKEN;
     const in_budget whole = budget_of(in);
     uint64_t bs = block_size, last = 0;
@@ -1082,7 +1093,7 @@ static int rd_consume(void *vc, uint64_t b, const shafa_pipe_result *r, uint64_t
 _modules_error rle_decompress(char **path)
 {
     const double t0 = now_ms();
-    const int in = open(*path, O_RDONLY);
+    const int in = in_open(*path);
     if (in < 0) return SHAFA_FILE_INACCESSIBLE;
     char *p_out = shafa_rm_ext(*path);
     off_t out_off = 0;
@@ -1227,7 +1238,7 @@ static int d_consume(void *vc, uint64_t b, const shafa_pipe_result *r, uint64_t 
 _modules_error shafa_decompress(char **path, bool decompress_rle)
 {
     const double t0 = now_ms();
-    const int in = open(*path, O_RDONLY);
+    const int in = in_open(*path);
     if (in < 0) return SHAFA_FILE_INACCESSIBLE;
     int err = SHAFA_SUCCESS;
     in_budget left = budget_of(in);
