@@ -94,6 +94,10 @@ const char *shafa_hip_last_error(void);      /* text of the last SHAFA_DEVICE_ER
  *   "sf_decode_path": 0 (default) = the fastest kernels the tables allow, 1 = one code per look-up as for incomplete
  *       codes, 2 = the generic byte-map kernels of codes longer than 32 bits.
  *   "rle_encode_general": 1 = every tile takes the per-element general RLE code (long runs, ragged tiles), 0 = by data.
+ *   "rle_encode_one_pass": 1 = block_compression and the histogram of its output in ONE pass over the input (chained
+ *       32 KiB super-tiles, rle_encode.hip rle4_kernel: 1.1 x the algorithmic HBM bytes instead of 2.4 x — for callers whose
+ *       memory system is the scarce resource), 0 (default) = the two-pass kernels (rle3_*) and a separate histogram pass,
+ *       which are faster when the GPU is otherwise idle.
  *   "sf_encode_window_bits": bits per symbol the 1024-lane encoder's LDS windows are sized for; 0 (default) = the launch's
  *       longest code, at most 12.  A tile that needs more is not placed: its block is flagged on the device and encoded
  *       again by the 256-lane form in the same call (what happens to 13..16-bit codes whose rare symbols fill a whole

@@ -246,6 +246,10 @@ int shafa_hip_set_option(const char *name, long value)
         rleenc_configure(value != 0);
         return SHAFA_SUCCESS;
     }
+    if (name && !strcmp(name, "rle_encode_one_pass")) {
+        rleenc_configure_one_pass(value != 0);
+        return SHAFA_SUCCESS;
+    }
     if (name && !strcmp(name, "sf_decode_speculate")) {
         sfdec_configure(value <= 0 ? 0 : value >= 2 ? 2 : 1);
         return SHAFA_SUCCESS;

@@ -149,4 +149,5 @@ void sfenc_configure(int sfe4_min_blocks);
 void sfdec_configure(int speculate);
 void sfdec_configure_path(int path);
 void rleenc_configure(int force_general);
+void rleenc_configure_one_pass(int on);
 int gen_launch(hipStream_t st, u64 seed, u64 first, const u8 *d_map, u8 *d_out, size_t n);

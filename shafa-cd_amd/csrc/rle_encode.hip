@@ -18,6 +18,7 @@
 #include "internal.hpp"
 
 #include <stdlib.h>
+#include <vector>
 
 namespace {
 
@@ -37,6 +38,12 @@ struct RleBlk {
     u32 ticket;
     u32 force_general;     // test knob ("rle_encode_general"): every tile takes the per-element general code
     uint2 *masks;          // per 32-byte granule of the block: {E, Z} masks of the first pass for the emit pass (pairs of tiles)
+    // one-pass form (rle4_kernel): the block's first super-tile descriptor, its super-tiles, its packed tile histograms
+    u32 st_base;
+    u32 n_st;
+    u32 *th32;             // 128 words per 32 KiB tile of the OUTPUT: counts of bytes 2 j (low half) and 2 j + 1 (high half)
+    u64 *freq;             // the block's 256 bins (NULL: no histogram asked for)
+    u64 th_bytes;          // bytes of th32 that a launch may touch (zeroed by rle4_zero)
 };
 
 struct Seg { u32 f, v; };
@@ -1029,10 +1036,592 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_fix(const RleBlk *__restrict
     }
 }
 
+// ================================================================================================
+// rle4_kernel: block_compression (f.c:29-55) and make_freq of its output (f.c:63-79, as f.c:310 calls it) in ONE pass
+// over the input: n read + rle_n written, the output counted while it is still in LDS.
+//
+// A workgroup takes a SUPER-TILE of 32 KiB (four 8 KiB units, the pairs of rle3_emit8k) by a per-block ticket — whoever
+// holds a later ticket started after its predecessors, so the two chains below cannot deadlock whatever is resident —
+// and requests everything it will ever load at once.  Then, without waiting for anybody:
+//   * E / Z masks, run heads and the mask code's emitted sizes of its four units (what rle3_first computed and passed
+//     through the workspace);
+//   * the run that ENTERS the super-tile, from the 64 bytes in front of it: a shorter run is known exactly, only a run that
+//     fills them all needs the STATE chain — one descriptor per super-tile, PREFIX = length of the run that ends at its last
+//     byte (published at once by every super-tile that holds a run head: all of them on ordinary data), AGG = "one run from
+//     end to end, 32 KiB more" — and such a run sends its unit to the general per-element code anyway;
+//   * its size goes into the SIZE chain (decoupled look-back on 64-bit byte offsets, common.hpp), the exclusive prefix is
+//     the super-tile's place in the output.
+// The units are then emitted one after the other by the code of rle3_emit8k / rle3_copy8k / rle_tile_general into the LDS
+// image and leave as aligned 16-byte stores; the image is read once more for the histogram: 16 bank-spread replicas of 256
+// counters in LDS, added to the PACKED tile histogram of the output (two 16-bit counts per word: no carry, a 32 KiB tile
+// holds at most 32768 of a byte) with at most 128 atomics whenever the output crosses into the next 32 KiB tile and at the
+// end.  rle4_freq sums a block's tile histograms into its 256 bins.  The sidecar is what shafa_hipd_rle_encode_tiles leaves
+// for the one-shot Shannon-Fano encoder; without a caller's buffer it lives in the workspace.
+// ================================================================================================
+constexpr int R4_U = 4;                                 // units per workgroup
+constexpr u32 R4_ST = (u32)R4_U * (u32)R8_TILE;         // bytes of a super-tile
+constexpr int R4_HREP = 16;                             // replicas of the LDS histogram (replica = lane & 15)
+constexpr u32 R4_HALO = 64;                             // bytes in front of a super-tile that are looked at for the entering run
+
+struct R4Unit {
+    u32 E[RLE_THREADS + 2];        // E masks of the lanes; [0] bits 29..31: the three bytes before the unit, [257] bits 0..2: after
+    u32 wsum[4];                   // emitted bytes of every wave (mask code)
+    u32 wfirst[4];                 // bytes from the start of a wave to its first run head
+    u32 wlast[4];                  // last byte of every wave
+    int whead[4];                  // position in the unit of every wave's last run head, -1: none
+    u32 pure[4];                   // every byte of the wave is a literal
+    u32 slowv;                     // the unit takes the general code whatever enters
+    u32 H;                         // bytes after the unit equal to its last byte (<= 255)
+};
+struct R4Shared {
+    R8Shared s;                    // the image of the unit being emitted / the general code's scratch
+    R4Unit un[R4_U];
+    u32 hist[256 * R4_HREP];       // counter of byte b in replica r: hist[b * R4_HREP + r]
+    u32 Tk[2 * R4_U];              // emitted bytes of the 4 KiB tiles of units that take the general code
+    u32 ticket;
+    u32 halo;                      // bytes in front of the super-tile equal to the byte before it (<= R4_HALO)
+    u64 R0;                        // state chain: the run that ends at the last byte before the super-tile
+    u64 G;                         // size chain: bytes emitted before the super-tile
+};
+static_assert(sizeof(R4Shared) <= 40960, "rle4_kernel: four workgroups per CU");
+
+// bytes p .. p + 3 of the block (p a multiple of 4), zeros past its end
+__device__ __forceinline__ u32 r4_ldw(const RleBlk &blk, const u64 p)
+{
+    if (p + 4 <= blk.n) return gload<u32>(blk.in + p);
+    u32 v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (p + j < blk.n) v |= (u32)gload<u8>(blk.in + p + j) << (8 * j);
+    return v;
+}
+
+// count the m bytes at LDS pointer `at` (any alignment) into the replicated histogram
+__device__ __forceinline__ void r4_count_range(u32 *hist, const u8 *at, const u32 m)
+{
+    if (!m) return;                                     // (uniform)
+    const u32 a = lds_addr(at), lo = a & 15u, hi = lo + m;          // valid bytes of the 16-byte pieces: [lo, hi)
+    const uint4 *pc = (const uint4 *)(at - lo);
+    u32 *h = hist + (threadIdx.x & (R4_HREP - 1));
+    const u32 np = (hi + 15u) >> 4;
+    for (u32 p = threadIdx.x; p < np; p += RLE_THREADS) {
+        const uint4 v = pc[p];
+        const u32 wds[4] = {v.x, v.y, v.z, v.w};
+        const u32 b0 = 16u * p;
+        if (b0 >= lo && b0 + 16u <= hi) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) atomicAdd(&h[((wds[j >> 2] >> (8 * (j & 3))) & 0xFFu) * R4_HREP], 1u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (b0 + (u32)j >= lo && b0 + (u32)j < hi) atomicAdd(&h[((wds[j >> 2] >> (8 * (j & 3))) & 0xFFu) * R4_HREP], 1u);
+        }
+    }
+}
+
+// the counts so far belong to output tile `tile` of the block: add them to its packed histogram, clear the replicas
+__device__ __forceinline__ void r4_flush(R4Shared &sh, const RleBlk &blk, const u32 tile)
+{
+    __syncthreads();
+    const u32 tid = threadIdx.x;
+    uint4 *row = (uint4 *)(sh.hist + tid * R4_HREP);
+    u32 c = 0;
+#pragma unroll
+    for (u32 j = 0; j < R4_HREP / 4; ++j) {
+        const u32 jj = (j + (tid >> 2)) & (R4_HREP / 4 - 1);
+        const uint4 v = row[jj];
+        c += v.x + v.y + v.z + v.w;
+        row[jj] = make_uint4(0, 0, 0, 0);
+    }
+    const u32 up = (u32)__shfl_down((int)c, 1, 64);
+    const u32 packed = c | (up << 16);
+    if (!(tid & 1u) && packed) atomicAdd(blk.th32 + (size_t)tile * 128u + (tid >> 1), packed);
+    __syncthreads();
+}
+
+// the n bytes at LDS pointer `at` are the block's output bytes [G, G + n): count them, tile by tile (n <= 32 KiB)
+__device__ __forceinline__ void r4_count(R4Shared &sh, const RleBlk &blk, const u8 *at, const u32 n, const u64 G, u32 &cur_tile)
+{
+    const u64 tile_end = ((u64)cur_tile + 1) << 15;
+    const u32 first = G + n <= tile_end ? n : (u32)(tile_end - G);
+    r4_count_range(sh.hist, at, first);
+    if (first < n) {                                    // (uniform) the output crosses into the next tile
+        r4_flush(sh, blk, cur_tile);
+        ++cur_tile;
+        r4_count_range(sh.hist, at + first, n - first);
+    }
+}
+
+template <bool HIST>
+__global__ __launch_bounds__(RLE_THREADS, 4) void rle4_kernel(const RleBlk *__restrict__ blks, u32 *__restrict__ tickets,
+                                                           u64 *__restrict__ sdesc, u64 *__restrict__ gdesc)
+{
+    __shared__ __attribute__((aligned(16))) R4Shared sh;
+    const RleBlk blk = blks[blockIdx.y];
+    if (blockIdx.x >= blk.n_st) return;
+    const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+    if (tid == 0) sh.ticket = atomicAdd(tickets + blk.ticket, 1u);
+    if (HIST)
+        for (int i = tid; i < 256 * R4_HREP / 4; i += RLE_THREADS) ((uint4 *)sh.hist)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const u32 g = sh.ticket;                            // the super-tile
+    const u64 n = blk.n, st0 = (u64)g * R4_ST;
+    const u32 left = n - st0 < (u64)R4_ST ? (u32)(n - st0) : R4_ST;
+    const int nun = (int)((left + (u32)R8_TILE - 1u) / (u32)R8_TILE);        // units that exist
+    const bool has_next = g + 1 < blk.n_st;
+    u64 *const sd = sdesc + blk.st_base, *const gd = gdesc + blk.st_base;
+    u8 *const smem = (u8 *)&sh;
+
+    // ---- everything the workgroup ever loads ----------------------------------------------------------------
+    u32 w[R4_U][8], qb[R4_U], qa[R4_U], hq[R4_U];
+    bool full[R4_U];                                    // the mask code is possible: the unit and four bytes more lie inside the block
+#pragma unroll
+    for (int u = 0; u < R4_U; ++u) {
+        const u64 us = st0 + (u64)u * R8_TILE;
+        full[u] = u < nun && us + R8_TILE + 4 <= n;
+        qb[u] = qa[u] = hq[u] = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[u][i] = 0;
+        if (full[u]) {
+            const u64 pos = us + (u64)tid * R8_BPL;
+            const uint4 v0 = gload_nt<uint4>(blk.in + pos), v1 = gload_nt<uint4>(blk.in + pos + 16);
+            w[u][0] = v0.x; w[u][1] = v0.y; w[u][2] = v0.z; w[u][3] = v0.w;
+            w[u][4] = v1.x; w[u][5] = v1.y; w[u][6] = v1.z; w[u][7] = v1.w;
+            if (tid == RLE_THREADS - 1) qa[u] = gload<u32>(blk.in + us + R8_TILE);
+            if (wv == 2) hq[u] = r4_ldw(blk, us + R8_TILE + 4u * (u32)lane);
+        } else if (u < nun) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[u][i] = r4_ldw(blk, us + (u64)tid * R8_BPL + 4u * (u32)i);
+        }
+        if (u < nun && tid == 0 && us > 0) qb[u] = gload<u32>(blk.in + us - 4);
+    }
+    u32 hb = 0;                                         // wave 3, lanes 0..15: the 64 bytes in front of the super-tile
+    if (wv == 3 && lane < (int)(R4_HALO / 4) && g > 0) hb = gload<u32>(blk.in + st0 - R4_HALO + 4u * (u32)lane);
+
+    // ---- masks: what the lanes need from their neighbours first --------------------------------------------
+#pragma unroll
+    for (int u = 0; u < R4_U; ++u) {
+        if (u >= nun) break;
+        if (lane == 63) sh.un[u].wlast[wv] = w[u][7] >> 24;
+        if (tid == 0) {
+            sh.un[u].E[0] = (st0 + (u64)u * R8_TILE > 0) ? (zmask4(qb[u] ^ (qb[u] << 8)) >> 1) << 29 : 0u;
+            sh.un[u].slowv = (blk.force_general || !full[u]) ? 1u : 0u;
+        }
+        if (tid == RLE_THREADS - 1)
+            sh.un[u].E[RLE_THREADS + 1] = full[u] ? zmask4(qa[u] ^ ((qa[u] << 8) | (w[u][7] >> 24))) & 7u : 0u;
+    }
+    if (wv == 3) {                                      // the run that ends at the byte before the super-tile, inside the halo
+        const u32 last = (u32)__shfl((int)hb, (int)(R4_HALO / 4) - 1, 64) >> 24;
+        const u32 m = zmask4(hb ^ (last * 0x01010101u));                 // bytes equal to it
+        const u32 cnt = (u32)__builtin_clz(~(m << 28));                 // ... counted down from the word's last byte
+        const u64 fullm = __ballot(lane < (int)(R4_HALO / 4) && cnt >= 4u) | ~((1ull << (R4_HALO / 4)) - 1ull);
+        const u64 nf = ~fullm;                           // lanes 0..15 whose word is not all equal
+        const int hl = nf ? 63 - __builtin_clzll((unsigned long long)nf) : -1;
+        const u32 ch = hl >= 0 ? (u32)__shfl((int)cnt, hl, 64) : 0u;
+        if (lane == 0) sh.halo = g == 0 ? 0u : (hl < 0 ? R4_HALO : 4u * (u32)((int)(R4_HALO / 4) - 1 - hl) + ch);
+    }
+    lds_barrier();
+
+    // ---- E / Z masks, run heads per wave, the bytes behind every unit that continue its last run ------------------
+    u32 E[R4_U], Z[R4_U];
+#pragma unroll
+    for (int u = 0; u < R4_U; ++u) {
+        E[u] = Z[u] = 0;
+        if (u >= nun) break;
+        const u64 us = st0 + (u64)u * R8_TILE;
+        u32 pb = (u32)__shfl_up((int)(w[u][7] >> 24), 1, 64);
+        if (lane == 0) pb = wv ? sh.un[u].wlast[wv - 1] : (us > 0 ? qb[u] >> 24 : 0x100u);
+        u32 dif[8];                                     // every byte xor the byte before it
+        dif[0] = w[u][0] ^ ((w[u][0] << 8) | (pb & 0xFFu));
+#pragma unroll
+        for (int i = 1; i < 8; ++i) dif[i] = w[u][i] ^ __builtin_amdgcn_alignbit(w[u][i], w[u][i - 1], 24);
+        u32 e = zmask32(dif);
+        Z[u] = zmask32(w[u]);
+        if (pb > 0xFFu) e &= ~1u;
+        if (!full[u]) {                                 // bytes past the block's end: heads, so that nothing continues into them
+            const u64 p = us + (u64)tid * R8_BPL;
+            const u32 nv = p >= n ? 0u : (n - p >= (u64)R8_BPL ? (u32)R8_BPL : (u32)(n - p));
+            e &= nv >= 32u ? 0xFFFFFFFFu : ((1u << nv) - 1u);
+        }
+        E[u] = e;
+        sh.un[u].E[tid + 1] = e;
+        const u32 H = ~e;
+        const u64 hm = __ballot(H != 0);
+        const u32 transparent = (u32)__builtin_popcountll((unsigned long long)__ballot(e == 0xFFFFFFFFu));
+        const int l1 = hm ? 63 - __builtin_clzll((unsigned long long)hm) : 0, l0 = hm ? __builtin_ctzll((unsigned long long)hm) : 0;
+        const u32 hv = (u32)__shfl((int)H, l1, 64), h0 = (u32)__shfl((int)H, l0, 64);
+        if (lane == 0) {
+            if (transparent > 2) sh.un[u].slowv = 1;   // a run could reach 255 bytes inside the unit
+            sh.un[u].whead[wv] = hm ? (wv * 64 + l1) * R8_BPL + (31 - __builtin_clz(hv)) : -1;
+            sh.un[u].wfirst[wv] = hm ? 32u * (u32)l0 + (u32)__builtin_ctz(h0) : 0xFFFFFFFFu;
+        }
+        if (wv == 2) {                                  // halo: bytes after the unit equal to its last byte (<= 255)
+            const u32 lastb = sh.un[u].wlast[3];
+            const u64 q = us + R8_TILE + 4u * (u32)lane;
+            const u32 nv = q >= n ? 0u : (n - q >= 4 ? 4u : (u32)(n - q));
+            u32 cnt = 0;
+            bool go = true;
+#pragma unroll
+            for (u32 j = 0; j < 4; ++j) {
+                go &= j < nv && ((hq[u] >> (8 * j)) & 0xFFu) == lastb;
+                cnt += go ? 1u : 0u;
+            }
+            const u64 f4 = __ballot(cnt == 4);
+            const int f0 = (~f4) ? (__ffsll((unsigned long long)~f4) - 1) : 64;
+            const u32 c0 = (f0 < 64) ? (u32)__shfl((int)cnt, f0, 64) : 0u;
+            u32 Hh = (u32)f0 * 4 + c0;
+            if (Hh > 255) Hh = 255;
+            if (lane == 0) sh.un[u].H = full[u] ? Hh : 0u;
+        }
+    }
+    lds_barrier();
+
+    // ---- (uniform) the run that enters every unit; which units take the general code ------------------------------
+    int lasthead[R4_U];
+    bool enters[R4_U], slow[R4_U];
+    u64 Rin[R4_U];
+    const u32 halo = sh.halo;
+    bool has_head = false;
+    u64 trail = 0;                                      // the run that ends at the super-tile's last byte, when it starts inside
+#pragma unroll
+    for (int u = 0; u < R4_U; ++u) {
+        lasthead[u] = -1;
+        enters[u] = slow[u] = false;
+        Rin[u] = 0;
+        if (u >= nun) continue;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) if (sh.un[u].whead[ww] >= 0) lasthead[u] = sh.un[u].whead[ww];
+        enters[u] = (sh.un[u].E[1] & 1u) != 0;
+        if (lasthead[u] >= 0) { has_head = true; trail = (u64)(nun - 1 - u) * R8_TILE + (u64)(R8_TILE - lasthead[u]); }
+    }
+    const bool need_chain = enters[0] && halo >= R4_HALO;      // the entering run fills the halo: its length is the chain's
+    auto enter_runs = [&](const u64 r0) {
+        Rin[0] = enters[0] ? r0 : 0;
+#pragma unroll
+        for (int u = 1; u < R4_U; ++u) {
+            if (u >= nun) break;
+            const u64 tp = lasthead[u - 1] >= 0 ? (u64)(R8_TILE - lasthead[u - 1]) : Rin[u - 1] + R8_TILE;
+            Rin[u] = enters[u] ? tp : 0;
+        }
+    };
+    enter_runs(halo);
+#pragma unroll
+    for (int u = 0; u < R4_U; ++u)
+        if (u < nun) slow[u] = sh.un[u].slowv != 0 || (enters[u] && Rin[u] >= 60);
+    if (tid == 0 && has_next) {                         // state chain: published before anything is waited for
+        if (has_head) desc_store(sd + g, DESC_PREFIX, trail);
+        else if (!need_chain) desc_store(sd + g, DESC_PREFIX, Rin[0] + R4_ST);
+        else desc_store(sd + g, DESC_AGG, R4_ST);
+    }
+
+    // ---- mask code: literals, triple heads, emitted bytes ------------------------------------------------------------
+    u32 Lit[R4_U], T3[R4_U], tot[R4_U], incl[R4_U];
+#pragma unroll
+    for (int u = 0; u < R4_U; ++u) {
+        Lit[u] = T3[u] = tot[u] = incl[u] = 0;
+        if (u >= nun || slow[u]) continue;              // (uniform)
+        const u64 B = (u64)(sh.un[u].E[tid] >> 29) | ((u64)E[u] << 3) | ((u64)(sh.un[u].E[tid + 2] & 7u) << 35);   // positions -3 .. 34
+        const u64 T = B & (B >> 1) & (B >> 2);
+        const u32 LC = (u32)(((T >> 1) | T | (T << 1) | (T << 2)) >> 3);    // bytes of runs of >= 4
+        Lit[u] = ~Z[u] & ~LC;
+        T3[u] = ~E[u] & (Z[u] | LC);
+        tot[u] = (u32)__builtin_popcount(Lit[u]) + 3u * (u32)__builtin_popcount(T3[u]);
+        incl[u] = wave_incl_scan_add<u32>(tot[u]);
+        const bool wpure = __ballot(Lit[u] != 0xFFFFFFFFu) == 0ull;
+        if (lane == 63) sh.un[u].wsum[wv] = incl[u];
+        if (lane == 0) sh.un[u].pure[wv] = wpure ? 1u : 0u;
+    }
+    if (need_chain) {                                   // (uniform, rare) a long run enters: its exact length
+        if (wv == 0) {
+            const u64 R = lookback_sum(sd, (int)g, blk.err);
+            if (lane == 0) {
+                sh.R0 = R;
+                if (!has_head && has_next) desc_store(sd + g, DESC_PREFIX, R + R4_ST);
+            }
+        }
+        lds_barrier();
+        enter_runs(sh.R0);
+    }
+    // run that ends at the last byte of a unit's first 4 KiB tile (the general code works on those)
+    auto second_tile_run = [&](const int u) -> u64 {
+        const int lh = sh.un[u].whead[1] >= 0 ? sh.un[u].whead[1] : sh.un[u].whead[0];
+        return lh >= 0 ? (u64)(RLE_TILE - lh) : Rin[u] + RLE_TILE;
+    };
+#pragma unroll
+    for (int u = 0; u < R4_U; ++u) {
+        if (u >= nun || !slow[u]) continue;             // (uniform)
+        for (int t = 0; t < 2; ++t) {
+            const u32 k = 2u * (g * (u32)R4_U + (u32)u) + (u32)t;
+            __syncthreads();
+            if (k < blk.n_tiles) rle_tile_general<1>(sh.s.gen, blk, (int)k, t ? second_tile_run(u) : Rin[u], 0ull, &sh.Tk[2 * u + t]);
+            else if (tid == 0) sh.Tk[2 * u + t] = 0;
+        }
+    }
+    __syncthreads();
+    u32 Tu[R4_U], Ttot = 0;
+#pragma unroll
+    for (int u = 0; u < R4_U; ++u) {
+        Tu[u] = 0;
+        if (u >= nun) continue;
+        Tu[u] = slow[u] ? sh.Tk[2 * u] + sh.Tk[2 * u + 1] : sh.un[u].wsum[0] + sh.un[u].wsum[1] + sh.un[u].wsum[2] + sh.un[u].wsum[3];
+        Ttot += Tu[u];
+    }
+
+    // ---- size chain -------------------------------------------------------------------------------------------------------
+    if (wv == 0) {
+        u64 G = 0;
+        if (g == 0) {
+            if (lane == 0) desc_store(gd, DESC_PREFIX, Ttot);
+        } else {
+            if (lane == 0) desc_store(gd + g, DESC_AGG, Ttot);
+            G = lookback_sum(gd, (int)g, blk.err);
+            if (lane == 0) desc_store(gd + g, DESC_PREFIX, G + Ttot);
+        }
+        if (lane == 0) {
+            sh.G = G;
+            if (!has_next) gstore<u64>(blk.out_n, G + Ttot);
+        }
+    }
+    lds_barrier();
+    u64 Gu = sh.G;
+    if (Gu + Ttot > blk.out_cap) {                      // (uniform) the block does not fit: nothing of this super-tile is stored
+        if (tid == 0) set_error(blk.err, SHAFA_LACK_OF_MEMORY);
+        return;
+    }
+    u32 cur_tile = (u32)(Gu >> 15);
+
+    // ---- the units leave, one after the other ---------------------------------------------------------------------------
+#pragma unroll
+    for (int u = 0; u < R4_U; ++u) {
+        if (u >= nun) break;
+        lds_barrier();                                  // the image of the unit before is done with
+        if (slow[u]) {                                  // general per-element code, 4 KiB tile by tile
+            u64 Gk = Gu;
+            for (int t = 0; t < 2; ++t) {
+                const u32 k = 2u * (g * (u32)R4_U + (u32)u) + (u32)t;
+                if (k >= blk.n_tiles) break;
+                __syncthreads();
+                rle_tile_general<2>(sh.s.gen, blk, (int)k, t ? second_tile_run(u) : Rin[u], Gk, nullptr);
+                if (HIST) r4_count(sh, blk, (const u8 *)sh.s.gen.stage + ((u32)Gk & 3u), sh.Tk[2 * u + t], Gk, cur_tile);
+                Gk += sh.Tk[2 * u + t];
+            }
+            Gu += Tu[u];
+            continue;
+        }
+        const u32 Tt = Tu[u];
+        if (sh.un[u].pure[0] & sh.un[u].pure[1] & sh.un[u].pure[2] & sh.un[u].pure[3]) {
+            // every byte is a literal: the unit leaves as it came (rle3_copy8k)
+            constexpr u32 base = (u32)offsetof(R8Fast, img) + 16u;         // 16 bytes in front: a piece may start before the unit
+            *(uint4 *)(smem + base + 32u * (u32)tid) = make_uint4(w[u][0], w[u][1], w[u][2], w[u][3]);
+            *(uint4 *)(smem + base + 32u * (u32)tid + 16u) = make_uint4(w[u][4], w[u][5], w[u][6], w[u][7]);
+            lds_barrier();
+            u8 *gout = blk.out + Gu;
+            const u32 mis = (u32)((uintptr_t)gout & 15u);
+            for (u32 q = (u32)tid; 16 * q < mis + (u32)R8_TILE; q += RLE_THREADS) {
+                const u32 s0 = base + 16 * q - mis, sb = s0 & ~3u, sf = s0 & 3u;
+                const u32 d0 = *(const u32 *)__builtin_assume_aligned(smem + sb, 4), d1 = *(const u32 *)__builtin_assume_aligned(smem + sb + 4, 4),
+                          d2 = *(const u32 *)__builtin_assume_aligned(smem + sb + 8, 4), d3 = *(const u32 *)__builtin_assume_aligned(smem + sb + 12, 4),
+                          d4 = *(const u32 *)__builtin_assume_aligned(smem + sb + 16, 4);
+                const u32 wds[4] = {__builtin_amdgcn_alignbyte(d1, d0, sf), __builtin_amdgcn_alignbyte(d2, d1, sf),
+                                    __builtin_amdgcn_alignbyte(d3, d2, sf), __builtin_amdgcn_alignbyte(d4, d3, sf)};
+                u8 *ga = gout - mis + 16 * q;
+                const u32 lo = 16 * q;                  // the piece is bytes [lo - mis, lo - mis + 16) of the unit
+                if (lo >= mis && lo + 16 <= mis + (u32)R8_TILE) {
+                    gstore_nt<uint4>(ga, make_uint4(wds[0], wds[1], wds[2], wds[3]));
+                } else {
+#pragma unroll
+                    for (u32 b = 0; b < 16; ++b)
+                        if (lo + b >= mis && lo + b < mis + (u32)R8_TILE) ga[b] = (u8)(wds[b >> 2] >> (8 * (b & 3)));
+                }
+            }
+            if (HIST) r4_count(sh, blk, smem + base, (u32)R8_TILE, Gu, cur_tile);
+            Gu += Tt;
+            continue;
+        }
+        // the mask code (rle3_emit8k): tokens into the image, which is aligned like the output address
+        const u32 H = ~E[u];
+        const u64 hm = __ballot(H != 0);                // never 0: at most two lanes of a wave have no head
+        u32 after;                                      // bytes from the end of this lane to the next run head
+        {
+            const u64 above = lane == 63 ? 0ull : hm & ~((2ull << lane) - 1);
+            const int l2 = above ? __builtin_ctzll((unsigned long long)above) : 0;
+            const u32 hv = (u32)__shfl((int)H, l2, 64);
+            after = above ? 32u * (u32)(l2 - lane - 1) + (u32)__builtin_ctz(hv)
+                          : 32u * (u32)(63 - lane) + (wv < 3 ? sh.un[u].wfirst[wv + 1] : sh.un[u].H);
+        }
+        u32 off = incl[u] - tot[u];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) if (q < wv) off += sh.un[u].wsum[q];
+        const u32 shift = (u32)((uintptr_t)(blk.out + Gu) & 15u);
+        const u32 p0 = (u32)offsetof(R8Fast, img) + shift + off;
+        {   // every byte is written somewhere, no branches (see rle3_emit8k)
+            u32 p = p0;
+            const u32 p_end = p0 + tot[u];
+            const u32 dump = (u32)offsetof(R8Fast, dump) + 4u * (u32)tid;
+#pragma unroll
+            for (int q = 0; q < R8_BPL / 4; ++q) {
+                const u32 ft = nibf(T3[u], q), sz = nibf(Lit[u], q) | ft | (ft << 1);
+                u32 a;
+                a = add_byte<0>(p, ft); smem[a < p_end ? a : dump] = (u8)w[u][q];         p = add_byte<0>(p, sz);
+                a = add_byte<1>(p, ft); smem[a < p_end ? a : dump] = (u8)(w[u][q] >> 8);  p = add_byte<1>(p, sz);
+                a = add_byte<2>(p, ft); smem[a < p_end ? a : dump] = (u8)(w[u][q] >> 16); p = add_byte<2>(p, sz);
+                a = add_byte<3>(p, ft); smem[a < p_end ? a : dump] = (u8)(w[u][q] >> 24); p = add_byte<3>(p, sz);
+            }
+        }
+        u32 p3 = p0;
+        for (u32 t = T3[u]; t; t &= t - 1, p3 += 3u) {  // triples: the lane's heads in order
+            const u32 j = (u32)__builtin_ctz(t), below = (1u << j) - 1u;
+            const u32 hn = j < 31 ? H >> (j + 1) : 0u;
+            u32 L = hn ? (u32)__builtin_ctz(hn) + 1u : (32u - j) + after;
+            L = L > 255u ? 255u : L;
+            const u32 at = p3 + (u32)__builtin_popcount(Lit[u] & below);
+            smem[at] = 0;
+            smem[at + 2] = (u8)L;
+        }
+        lds_barrier();
+        {
+            u8 *gbase = blk.out + Gu - shift;           // aligned 16-byte pieces, non-temporal
+            const u32 npieces = (shift + Tt + 15) >> 4;
+            for (u32 q = (u32)tid; q < npieces; q += RLE_THREADS) {
+                const uint4 v = ((const uint4 *)sh.s.f.img)[q];
+                const u32 lo = 16 * q;
+                if (lo >= shift && lo + 16 <= shift + Tt) {
+                    gstore_nt<uint4>(gbase + lo, v);
+                } else {
+                    const u32 wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (u32 b = 0; b < 16; ++b)
+                        if (lo + b >= shift && lo + b < shift + Tt) gbase[lo + b] = (u8)(wds[b >> 2] >> (8 * (b & 3)));
+                }
+            }
+        }
+        if (HIST) r4_count(sh, blk, sh.s.f.img + shift, Tt, Gu, cur_tile);
+        Gu += Tt;
+    }
+    if (HIST) r4_flush(sh, blk, cur_tile);
+}
+
+// before rle4_kernel: tickets and descriptors, the packed tile histograms, the blocks' bins and sizes
+__global__ __launch_bounds__(256) void rle4_zero(const RleBlk *__restrict__ blks, u32 *__restrict__ tickets, u64 *__restrict__ sdesc,
+                                                 u64 *__restrict__ gdesc)
+{
+    const RleBlk blk = blks[blockIdx.y];
+    const u32 t = blockIdx.x * 256u + threadIdx.x, step = gridDim.x * 256u;
+    if (t == 0) {
+        tickets[blk.ticket] = 0;
+        gstore<u64>(blk.out_n, 0);
+    }
+    if (blk.freq && t < 256) blk.freq[t] = 0;
+    for (u32 i = t; i < blk.n_st; i += step) { sdesc[blk.st_base + i] = 0; gdesc[blk.st_base + i] = 0; }
+    if (blk.th32)
+        for (u64 i = t; i < blk.th_bytes / 16; i += step) ((uint4 *)blk.th32)[i] = make_uint4(0, 0, 0, 0);
+}
+
+// a block's bins = the sum of its tile histograms
+__global__ __launch_bounds__(256) void rle4_freq(const RleBlk *__restrict__ blks)
+{
+    const RleBlk blk = blks[blockIdx.y];
+    if (!blk.freq || !blk.th32) return;
+    const u64 out_n = gload<u64>(blk.out_n);
+    const u32 nt = (u32)((out_n + 32767) >> 15);
+    const u16 *th = (const u16 *)blk.th32;
+    u64 c = 0;
+    for (u32 t = blockIdx.x; t < nt; t += gridDim.x) c += th[(size_t)t * 256 + threadIdx.x];
+    if (c) atomicAdd((unsigned long long *)(blk.freq + threadIdx.x), (unsigned long long)c);
+}
+
 }  // namespace
 
 static int g_rle_force_general = 0;
+// "rle_encode_one_pass": 1 = rle4_kernel, 0 (default) = the two-pass kernels (rle3_*) and a histogram pass.  Measured on
+// 32 x 64 MiB of Zipf symbols in geometric runs (profiles/r6_rle_one_pass.txt): one pass moves 4.10 GB where the two-pass
+// sequence moves 8.87 GB (1.10 x against 2.39 x the algorithmic bytes) and takes 2.41 ms against 1.82 ms: both forms execute
+// the same 8.2-8.5 G vector instructions per launch (25 per input byte: masks, classification, the byte loop, the counts),
+// at four cycles each on 1024 SIMDs that is 1.55 ms, and the chained form keeps the vector ALUs 65 % busy (sixteen waves per
+// CU: 39.5 KB of LDS per workgroup, ticket, look-back and a dozen barriers per super-tile) where the independent
+// workgroups of the two-pass kernels keep them 84 % busy.  The family is bound by its instruction count, not by its traffic.
+static int g_rle_one_pass = 0;
 void rleenc_configure(int force_general) { g_rle_force_general = force_general; }
+void rleenc_configure_one_pass(int on) { g_rle_one_pass = on; }
+
+// One pass over the input: rle4_zero -> rle4_kernel -> rle4_freq (d_freq wanted).  The packed tile histograms go to the
+// caller's sidecar (shafa_hipd_rle_encode_tiles) or, when only the bins are wanted, to the workspace.
+static int rleenc_launch_one_pass(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
+                                  const u64 *h_in_n, u8 *d_out, const u64 *h_out_off, const u64 *h_out_cap, u64 *d_out_n,
+                                  u64 *d_freq, u8 *d_thist, const u64 *h_thist_off)
+{
+    if ((d_thist == nullptr) != (h_thist_off == nullptr)) return SHAFA_OUTSIDE_MODULE;
+    if (d_thist && !d_freq) return SHAFA_OUTSIDE_MODULE;
+    u64 nst = 0, ws_th = 0;
+    u32 max_st = 0;
+    std::vector<u64> thb(nblocks, 0);
+    for (int b = 0; b < nblocks; ++b) {
+        if ((h_in_off[b] & 15) || (h_out_off[b] & 15) || (d_thist && (h_thist_off[b] & 15))) return SHAFA_OUTSIDE_MODULE;
+        const u64 t = ceil_div_u64(h_in_n[b], R4_ST);
+        if (t > 0x7FFFFFFFull) return SHAFA_OUTSIDE_MODULE;
+        nst += t;
+        if (t > max_st) max_st = (u32)t;
+        if (d_freq) {                                   // tiles the output can reach: 2 n + 3 bytes at most, and never past out_cap
+            const u64 worst = 2 * h_in_n[b] + 3, reach = h_out_cap[b] < worst ? h_out_cap[b] : worst;
+            thb[b] = h_in_n[b] ? ceil_div_u64(reach, 32768) * 512 : 0;
+            if (!d_thist) ws_th += thb[b];
+        }
+    }
+    // workspace: [RleBlk] [tickets] [state descriptors] [size descriptors] [packed tile histograms, unless the caller's]
+    size_t off = 0;
+    const size_t o_blk = off; off += (size_t)nblocks * sizeof(RleBlk); off = (off + 15) & ~(size_t)15;
+    const size_t o_tick = off; off += (size_t)nblocks * 4; off = (off + 15) & ~(size_t)15;
+    const size_t o_sd = off; off += nst * 8; off = (off + 15) & ~(size_t)15;
+    const size_t o_gd = off; off += nst * 8; off = (off + 15) & ~(size_t)15;
+    const size_t o_th = off; off += ws_th;
+    int rc = batch_reserve(bt, st, off);
+    if (rc) return rc;
+    u8 *ws = (u8 *)bt->d_ws;
+    RleBlk *hb = (RleBlk *)batch_stage(bt, st, (size_t)nblocks * sizeof(RleBlk));
+    if (!hb) return SHAFA_LACK_OF_MEMORY;
+    u32 sbase = 0;
+    u64 thpos = 0, max_th = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        RleBlk &e = hb[b];
+        memset(&e, 0, sizeof(e));
+        e.in = d_in + h_in_off[b];
+        e.out = d_out + h_out_off[b];
+        e.n = h_in_n[b];
+        e.out_cap = h_out_cap[b];
+        e.out_n = d_out_n + b;
+        e.err = bt->d_err + b;
+        e.n_tiles = (u32)ceil_div_u64(h_in_n[b], RLE_TILE);
+        e.ticket = (u32)b;
+        e.force_general = g_rle_force_general ? 1u : 0u;
+        e.st_base = sbase;
+        e.n_st = (u32)ceil_div_u64(h_in_n[b], R4_ST);
+        sbase += e.n_st;
+        e.freq = d_freq ? d_freq + (size_t)b * 256 : nullptr;
+        e.th_bytes = thb[b];
+        if (d_freq) {
+            if (d_thist) e.th32 = (u32 *)(d_thist + h_thist_off[b]);
+            else { e.th32 = (u32 *)(ws + o_th + thpos); thpos += thb[b]; }
+        }
+        if (thb[b] > max_th) max_th = thb[b];
+    }
+    if ((rc = batch_upload(bt, st, ws + o_blk, hb, (size_t)nblocks * sizeof(RleBlk)))) return rc;
+    const RleBlk *dblk = (const RleBlk *)(ws + o_blk);
+    u32 *tick = (u32 *)(ws + o_tick);
+    u64 *sd = (u64 *)(ws + o_sd), *gd = (u64 *)(ws + o_gd);
+    {   // enough workgroups per block to zero its tile histograms at memory speed, at least one (tickets, sizes, bins)
+        u64 zx = ceil_div_u64(max_th / 16 > max_st ? max_th / 16 : max_st, 256 * 8);
+        if (zx < 1) zx = 1;
+        if (zx > 64) zx = 64;
+        hipLaunchKernelGGL(rle4_zero, dim3((u32)zx, (u32)nblocks), dim3(256), 0, st, dblk, tick, sd, gd);
+    }
+    if (max_st) {
+        if (d_freq) hipLaunchKernelGGL(rle4_kernel<true>, dim3(max_st, (u32)nblocks), dim3(RLE_THREADS), 0, st, dblk, tick, sd, gd);
+        else hipLaunchKernelGGL(rle4_kernel<false>, dim3(max_st, (u32)nblocks), dim3(RLE_THREADS), 0, st, dblk, tick, sd, gd);
+        if (d_freq) hipLaunchKernelGGL(rle4_freq, dim3(16, (u32)nblocks), dim3(256), 0, st, dblk);
+    }
+    HIP_TRY(hipGetLastError());
+    return SHAFA_SUCCESS;
+}
 
 int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u64 *h_in_off,
                   const u64 *h_in_n, u8 *d_out, const u64 *h_out_off, const u64 *h_out_cap, u64 *d_out_n,
@@ -1040,6 +1629,9 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
 {
     if (nblocks <= 0) return SHAFA_SUCCESS;
     if (nblocks > bt->max_blocks) return SHAFA_LACK_OF_MEMORY;
+    if (g_rle_one_pass)
+        return rleenc_launch_one_pass(bt, st, nblocks, d_in, h_in_off, h_in_n, d_out, h_out_off, h_out_cap, d_out_n, d_freq, d_thist,
+                                      h_thist_off);
     u64 ndesc = 0;
     u32 max_tiles = 0;
     for (int b = 0; b < nblocks; ++b) {

@@ -48,7 +48,8 @@ def test_library_exports_nothing_but_the_declared_symbols(shafa):
     for v in (0, 2, 1):
         assert shafa.lib().shafa_hip_set_option(b"sf_decode_speculate", v) == shafa.SUCCESS
     for name, good, bad in ((b"sf_encode_lanes", (256, 512, 0), 100),
-                            (b"sf_encode_window_bits", (4, 16, 0), 17), (b"sf_decode_path", (1, 2, 0), 3), (b"rle_encode_general", (1, 0), None)):
+                            (b"sf_encode_window_bits", (4, 16, 0), 17), (b"sf_decode_path", (1, 2, 0), 3), (b"rle_encode_general", (1, 0), None),
+                            (b"rle_encode_one_pass", (0, 1), None)):
         for v in good:
             assert shafa.lib().shafa_hip_set_option(name, v) == shafa.SUCCESS, (name, v)
         if bad is not None:

@@ -273,6 +273,38 @@ def test_cli_module_d_reads_a_fifo(fifo_name, side, argv, decoded, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_module_d_fifo_with_groups_closing_on_the_budget(tmp_path):
+    """701 RLE blocks of 64 KiB through a FIFO: Module D works in groups of up to 256 blocks, has to stage the payloads it
+    reads past, and a group closes on the pipe's byte budget with a staged block in hand (run_groups' `held`), which then
+    opens the next group: the payload must be owned by exactly one record (it was freed twice)."""
+    import threading
+    case = "many_default_rle"
+    work = scratch_dir(tmp_path, case + "_fifo")
+    try:
+        man = replay(case, work)
+        src = os.path.join(work, "regular")
+        os.rename(os.path.join(work, "m.rle.shaf"), src)
+        for f in ("m", "m.rle"):
+            if os.path.exists(os.path.join(work, f)):
+                os.remove(os.path.join(work, f))
+        fifo = os.path.join(work, "m.rle.shaf")
+        os.mkfifo(fifo)
+
+        def feed():
+            with open(src, "rb") as f, open(fifo, "wb") as w:
+                shutil.copyfileobj(f, w, 1 << 16)
+        th = threading.Thread(target=feed)
+        th.start()
+        rc, err, _ = run(["m.rle.shaf"], work)
+        th.join()
+        assert rc == 0, err
+        assert sha(os.path.join(work, "m")) == man["files"]["decoded__sf_rle"]["sha256"]
+    finally:
+        if work != str(tmp_path):
+            shutil.rmtree(work, ignore_errors=True)
+
+
+@pytest.mark.gpu
 def test_cli_device_list_errors_are_reported(tmp_path):
     """SHAFA_DEVICES naming a GPU the node does not have (or garbage) is an error message and exit 1 before any module
     runs — not a silent fall-back to device 0; a valid list works; Module T alone ignores the variable (it touches no GPU)."""

@@ -63,6 +63,20 @@ def rle_inputs(oracle, shafa):
             e[8192 * 2 - 1] = 0                                               # a zero as the last byte of the second pair
             e[8192 * 2 + 1:8192 * 2 + 4] = e[8192 * 2]                        # a run of four that starts on a pair's first byte
             cases[f"literal_pair_edges_{n}"] = e
+    # the one-pass encoder's 32 KiB super-tiles: a run that ENTERS one with L bytes behind it is known from the 64 bytes in
+    # front (L < 64), sends its unit to the general code (L >= 60) or needs the state chain (L >= 64: the halo is all run);
+    # runs that swallow whole super-tiles (transparent ones: chain aggregates), of a plain byte and of the escaped one
+    base = (rng.integers(1, 255, size=32768 * 4 + 1000) | 1).astype(np.uint8)
+    base[1:] = np.where(base[1:] == base[:-1], base[1:] ^ 2, base[1:])
+    for L in (1, 3, 59, 60, 63, 64, 65, 254, 255, 256, 300, 8192, 33000, 70000):
+        for sym in (0x33, 0):
+            d = base.copy()
+            a0 = 32768 * 3 - L if L < 32768 * 2 else 32768 - (L - 65536) // 2
+            d[a0:a0 + L + 10] = sym                     # L bytes in front of a super-tile border, ten behind it (or far more)
+            d[a0 + L + 10] = 0x35
+            cases[f"supertile_enter_{L}_{sym}"] = d
+    for n in (32768, 32768 + 3, 32768 * 2 - 1, 32768 * 2 + 4, 32768 * 3 + 8192 + 2):      # ragged ends around the borders
+        cases[f"supertile_ragged_{n}"] = mg.runs_stream(4000 + n, n, zt)
     return cases
 
 
@@ -77,6 +91,27 @@ def test_rle_encode_matches_oracle(oracle, shafa):
         elif not (freq == oracle.hist256(want)).all():
             bad.append(f"{name}: fused histogram differs")
     assert not bad, "\n".join(bad[:12])
+
+
+def test_rle_encode_one_pass_matches_oracle(oracle, shafa):
+    """The chained one-pass form (rle4_kernel, option rle_encode_one_pass) on every input of the default form: run states that
+    enter a 32 KiB super-tile (halo / state chain), transparent super-tiles, ragged ends, the fused histogram of the output."""
+    shafa.lib().shafa_hip_init(0)
+    shafa.set_option("rle_encode_one_pass", 1)
+    try:
+        bad = []
+        for name, data in rle_inputs(oracle, shafa).items():
+            want = oracle.rle_encode(data)
+            got, freq = shafa.rle_encode(data, want_freq=True)
+            if got.tobytes() != want.tobytes():
+                bad.append(f"{name}: {first_diff(got, want)}")
+            elif not (freq == oracle.hist256(want)).all():
+                bad.append(f"{name}: fused histogram differs")
+            elif shafa.rle_encode(data).tobytes() != want.tobytes():             # without the histogram
+                bad.append(f"{name}: differs when no histogram is asked for")
+        assert not bad, "\n".join(bad[:12])
+    finally:
+        shafa.set_option("rle_encode_one_pass", 0)
 
 
 @pytest.mark.parametrize("case,fn", [("runs_default", "x"), ("edges_forced_rle", "e"), ("uniform_forced_both", "v"),
@@ -394,7 +429,7 @@ def test_sf_decode_codes_of_17_to_32_bits_fast_path(oracle, shafa):
 
 
 DEFAULT_OPTIONS = {"sf_encode_one_pass_min_blocks": 0, "sf_encode_lanes": 0, "sf_encode_window_bits": 0,
-                   "sf_decode_speculate": 1, "sf_decode_path": 0, "rle_encode_general": 0}
+                   "sf_decode_speculate": 1, "sf_decode_path": 0, "rle_encode_general": 0, "rle_encode_one_pass": 0}
 
 
 @pytest.mark.parametrize("options", [
@@ -408,6 +443,8 @@ DEFAULT_OPTIONS = {"sf_encode_one_pass_min_blocks": 0, "sf_encode_lanes": 0, "sf
     {"sf_decode_path": 1},                                                 # tables treated as incomplete: the byte-map kernels
     {"sf_decode_path": 2},                                                 # generic byte-map kernels (sfd_sync / sfd_tiles)
     {"rle_encode_general": 1},                                             # per-element general RLE tile code for every tile
+    {"rle_encode_one_pass": 1},                                            # RLE + histogram of its output in one chained pass (rle4_kernel)
+    {"rle_encode_one_pass": 1, "rle_encode_general": 1},                   # ... with the general tile code for every unit
 ], ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
 def test_alternative_kernel_paths_stay_bit_exact(oracle, shafa, options):
     """Every fall-back / alternative kernel path that the library can be told to take (shafa_hip_set_option) must produce

@@ -217,8 +217,10 @@ def test_tiles_garbage_sidecar_is_refused(shafa, oracle):
               expect_err={0: shafa.OUTSIDE_MODULE, 2: shafa.OUTSIDE_MODULE, 4: shafa.OUTSIDE_MODULE})
 
 
-def test_tiles_of_rle_output_feed_the_encoder(shafa, oracle):
-    """F -> T -> C on the device: shafa_hipd_rle_encode_tiles (block_compression + make_freq of the RLE bytes, f.c:248,310)
+@pytest.mark.parametrize("one_pass", [0, 1])
+def test_tiles_of_rle_output_feed_the_encoder(shafa, oracle, one_pass):
+    """(one_pass: the two-pass RLE kernels and a histogram pass, or the chained rle4_kernel that counts its own output.)
+    F -> T -> C on the device: shafa_hipd_rle_encode_tiles (block_compression + make_freq of the RLE bytes, f.c:248,310)
     leaves the tile histograms of the RLE bytes, whose sizes only the device knows at that point; Module T on the host;
     shafa_hipd_sf_encode_tiles encodes the RLE bytes.  Compared with the oracle's F -> T -> C per block."""
     import torch
@@ -240,11 +242,15 @@ def test_tiles_of_rle_output_feed_the_encoder(shafa, oracle):
     d_rle = torch.empty(rpos, dtype=torch.uint8, device=dev)
     d_rle_n = torch.zeros(nb, dtype=torch.int64, device=dev)
     d_freq = torch.zeros(nb * 256, dtype=torch.int64, device=dev)
-    d_th = torch.zeros(tpos, dtype=torch.uint8, device=dev)
+    d_th = torch.full((tpos,), 0x5A, dtype=torch.uint8, device=dev)          # garbage: the sidecar is written, not added to
     bt = shafa.Batch(nb, max(rcap))
     torch.cuda.synchronize()
-    bt.rle_encode_tiles(st, d_in, off, sizes, d_rle, roff, rcap, d_rle_n, d_freq, d_th, toff)
-    bt.finish(st, nb)
+    shafa.set_option("rle_encode_one_pass", one_pass)
+    try:
+        bt.rle_encode_tiles(st, d_in, off, sizes, d_rle, roff, rcap, d_rle_n, d_freq, d_th, toff)
+        bt.finish(st, nb)
+    finally:
+        shafa.set_option("rle_encode_one_pass", 0)
     rle_n = [int(x) for x in d_rle_n.cpu().numpy()]
     freq = d_freq.cpu().numpy().astype(np.uint64).reshape(nb, 256)
     rle = d_rle.cpu().numpy()
