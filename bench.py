@@ -473,6 +473,81 @@ def pipeline_leg(args, pkg, torch, dev, st, steps, nb, kind):
     return out
 
 
+def small_launch_rows(args, pkg, torch, dev, st):
+    """The `runs` pipeline leg at the launch sizes a file at -b M really has (1 and 8 blocks): the fixed sequence of a launch
+    weighs most there.  Compact rows: ms and fraction of the HBM peak per family."""
+    rows = {}
+    for nb in (1, 8):
+        leg = pipeline_leg(args, pkg, torch, dev, st, 8, nb, "runs")
+        rows[f"{nb}_blocks"] = {k: {"ms": round(v["ms"], 4), "frac": round(v["frac"], 4)} for k, v in leg.items()
+                                if isinstance(v, dict) and "frac" in v}
+        rows[f"{nb}_blocks"].update({"F_T_C_GiBs": leg["F_T_C_GiBs"], "D_GiBs": leg["D_GiBs"]})
+    return rows
+
+
+def uniform_leg(pkg, torch, dev, st):
+    """cfg[1]: 1 GiB of uniform bytes at -b m (128 x 8 MiB), Module C encode and Module D decode.  Codes of 8 / 9 bits never
+    re-synchronise, so the decoder takes its EXACT kernels (sfd_sync16 / sfd_countfsm / sfd_wstage), not the speculative ones:
+    the path any incompressible section of a real file takes."""
+    import numpy as np
+    nb, bs = 128, 8 << 20
+    d_in = torch.empty(nb * bs, dtype=torch.uint8, device=dev)
+    with torch.cuda.stream(st):
+        pkg.gen_bytes(st, SEED + 1, 0, d_in, nb * bs, None)
+    bt = pkg.Batch(nb, bs)
+    off, n = [b * bs for b in range(nb)], [bs] * nb
+    d_freq = torch.zeros(nb * 256, dtype=torch.int64, device=dev)
+    bt.hist256(st, d_in, off, n, d_freq)
+    bt.finish(st, nb)
+    freq = d_freq.cpu().numpy().astype(np.uint64).reshape(nb, 256)
+    tables = pkg.sf_build_codes_batch(freq)
+    lens = np.stack([tables[b].lens() for b in range(nb)]).astype(np.uint64)
+    enc_bytes = [int(x) for x in ((freq * lens).sum(axis=1) + 7) // 8]
+    cap = ((max(enc_bytes) + 4096 + 255) // 256) * 256
+    eoff = [b * cap for b in range(nb)]
+    d_enc = torch.empty(nb * cap, dtype=torch.uint8, device=dev)
+    d_enc_n = torch.zeros(nb, dtype=torch.int64, device=dev)
+    d_dec = torch.empty(nb * bs, dtype=torch.uint8, device=dev)
+
+    def timed(fn, steps=8):
+        torch.cuda.synchronize()
+        fn()
+        bt.finish(st, nb)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(steps):
+            fn()
+        e1.record(st)
+        bt.finish(st, nb)
+        return e0.elapsed_time(e1) / steps * 1e-3
+
+    t_c = timed(lambda: bt.sf_encode(st, d_in, off, n, tables, d_enc, eoff, [cap] * nb, d_enc_n))
+    assert [int(x) for x in d_enc_n.cpu().numpy()] == enc_bytes
+    t_d = timed(lambda: bt.sf_decode(st, d_enc, eoff, enc_bytes, tables, n, d_dec, off))
+    assert torch.equal(d_dec, d_in), "uniform leg: decode differs from the input"
+    alg = float(nb * bs + sum(enc_bytes))
+    bt.close()
+    return {"workload": "cfg[1]: 128 x 8 MiB uniform bytes (-b m)", "compressed_ratio": sum(enc_bytes) / float(nb * bs),
+            "encode_ms": t_c * 1e3, "encode_frac": alg / t_c / 1e9 / HBM_PEAK_GBS,
+            "decode_ms": t_d * 1e3, "decode_frac": alg / t_d / 1e9 / HBM_PEAK_GBS,
+            "decode_path": "exact (no speculation: 8/9-bit codes do not re-synchronise)"}
+
+
+def mover_leg():
+    """What a kernel that only moves the encoder's bytes reaches on THIS device right now (tools/ubench/mover, built by
+    __graft_entry__.build(): 8 GiB read, 6.5 GiB written, nothing computed): the ceiling the encoder's fraction is read against.
+    A child process (never under a profiler); None when the binary is not there."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "ubench", "mover")
+    if not os.path.exists(exe):
+        return None
+    r = subprocess.run([exe, "headline"], capture_output=True, text=True, timeout=120)
+    fr = [float(l.rsplit(":", 1)[1].strip(" )")) for l in r.stdout.splitlines() if "of 8 TB/s" in l]
+    if len(fr) < 2:
+        return None
+    return {"one_shot": fr[0], "persistent": fr[1]}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -727,6 +802,19 @@ def main():
             except Exception as e:                     # (memory on a small device: the headline line must still come out)
                 legs[kind] = {"error": f"{type(e).__name__}: {e}"[:300]}
         pipe, pipe_mixed = legs.get("runs"), legs.get("mixed")
+    small_rows, uni = None, None
+    if not args.no_pipeline and rank == 0 and args.block_mib == 64:
+        for name, fn in (("small", lambda: small_launch_rows(args, pkg, torch, dev, st)), ("uniform", lambda: uniform_leg(pkg, torch, dev, st))):
+            try:
+                r = fn()
+            except AssertionError:
+                raise
+            except Exception as e:
+                r = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if name == "small":
+                small_rows = r
+            else:
+                uni = r
 
     host_path = None
     profiled = any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
@@ -789,6 +877,21 @@ def main():
             out["pipeline"] = pipe
         if pipe_mixed:
             out["pipeline_mixed"] = pipe_mixed
+        if small_rows:
+            out["pipeline_small_launches"] = small_rows
+        if uni:
+            out["uniform_stream"] = uni
+        if world == 1 and not profiled and args.block_mib == 64 and args.dist == "zipfmod" and not args.no_host_path:
+            try:
+                mv = mover_leg()                       # a child process: after everything that is timed in this one
+            except Exception:
+                mv = None
+            if mv:
+                out["roofline_encode"]["mover_frac"] = mv["one_shot"]
+                out["roofline_encode"]["mover_persistent_frac"] = mv["persistent"]
+                out["roofline_encode"]["mover"] = ("tools/ubench/mover on this device in this run: a kernel that only moves the encoder's "
+                                                    "bytes (8 GiB read, 6.5 GiB written, nothing computed) as a one-shot grid of 32 KiB "
+                                                    "workgroups / as a persistent grid; the chained encoder is a persistent kernel")
         if host_path:
             out["host_path"] = host_path
         if world == 1 and not args.no_cpu:

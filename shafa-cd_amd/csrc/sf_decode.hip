@@ -8,12 +8,15 @@
 // Every launch goes   entries + counts  ->  sfd_offsets (scan of the tile counts)  ->  symbol pass:
 //
 //   code class (per launch)                 entries + counts                                   symbols
-//   complete, Lmax <= 16 (Module T's)       sfd_scan (speculative, verified exactly; here)     sfd_wstage (here)
+//   complete, Lmax <= 16 (Module T's)       sfd_scan + sfd_ends (speculative, verified exactly; here)   sfd_wstage (here)
 //                                           else exact: sfd_sync16 .. sfd_countfsm (sfd_dp.hpp)
-//   complete, 16 < Lmax <= 32               sfd_scan<.., 2>, else sfd_sync32 / sfd_countfsm32  sfd_wstage<2>
-//   anything else (hand-made .cod)          sfd_sync / sfd_tiles / sfd_count (sfd_generic.hpp) sfd_write
+//   complete, 16 < Lmax <= 32               sfd_scan<2> + sfd_ends<2>, else sfd_sync32 / sfd_countfsm32 sfd_wstage<2>
+//   anything else (hand-made .cod)          sfd_sync / sfd_tiles / sfd_count (sfd_generic.hpp)          sfd_write
 //
-// This file: the two kernels the time goes to on ordinary data (sfd_scan, sfd_wstage), sfd_offsets, and the launcher.
+// A speculating launch is eight kernels: sfd_tables, sfd_scan (every 16 KiB unit but the ones a stream ends in), sfd_ends (those
+// units, the links between all units, the verdict per block), the three exact kernels (fat grids that return at once for blocks
+// that verified), sfd_offsets, sfd_wstage.
+// This file: the kernels the time goes to on ordinary data (sfd_scan, sfd_wstage), sfd_ends, sfd_offsets, and the launcher.
 // Algorithmic HBM bytes per block: sf_n read + n_symbols written.
 #include <type_traits>
 #include "common.hpp"
@@ -44,7 +47,7 @@ namespace {
 //      guess of the strip's entry, then walks the strip, noting entry and code count of each chunk, to its exit;
 //   2. compares its guess with the exit of the lane before it; lanes that differ take that exit as their entry and walk
 //      again until they are back on their earlier path.
-// The first lane of a wave is compared with the wave before it by sfd_spec_check and redone with its entry forced.  When
+// The first lane of a wave is compared with the wave before it by sfd_ends, which walks the few chunks that differ again.  When
 // every comparison of a block holds — entry(c) == exit(c-1) for all chunks, entry 0 at the block's first bit — the
 // entries ARE the true parse, by induction: nothing is approximate.  A block that does not get there in the fixed number
 // of rounds sets *run_dp and goes through the exact kernels, which skip the blocks that verified; which blocks try at all
@@ -57,28 +60,9 @@ typedef __attribute__((address_space(3))) u8 lds_u8;
 // ended in front of this chunk"
 template <int LONG> constexpr u32 spec_emask() { return LONG == 2 ? 31u : 15u; }
 
-// per block: tiles whose first lane's guess differs from the previous tile's exit get tile_fix = 1 (redone by
-// sfd_scan<true>); FINAL: any difference left sends the block to the exact kernels
-template <bool FINAL>
-__global__ __launch_bounds__(DEC_THREADS) void sfd_spec_check(const DecBlk *__restrict__ blks, const u8 *__restrict__ tile_guess,
-                                                              const u8 *__restrict__ tile_exit, u8 *__restrict__ tile_fix)
-{
-    const DecBlk blk = blks[blockIdx.x];
-    if (!blk.n_tiles || !blk.run_dp || __hip_atomic_load(blk.run_dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
-    bool any = false;
-    for (u32 t = threadIdx.x + blockIdx.y * DEC_THREADS; t < blk.n_tiles; t += DEC_THREADS * gridDim.y) {   // gridDim.y workgroups per block
-        const size_t gt = (size_t)blk.tile_base + t;
-        const bool diff = t > 0 ? tile_guess[gt] != tile_exit[gt - 1] : tile_guess[gt] == 0xFFu;   // 0xFF: left to the repair launch (sfd_scan)
-        if (!FINAL) tile_fix[gt] = diff ? 1 : 0;
-        any |= diff;
-    }
-    if (FINAL && __syncthreads_or(any) && threadIdx.x == 0)
-        __hip_atomic_store(blk.run_dp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // ================================================================================================
 // sfd_scan: the speculative entries, shaped for the way gfx950's LDS and vector ALUs price the walk.
-// Outputs: entry and code count of every 256-bit chunk, tile counts, a guess / exit pair per unit for sfd_spec_check.
+// Outputs: entry and code count of every 256-bit chunk, tile counts, a guess / exit pair per unit for sfd_ends.
 //   * a lane owns a STRIP of SC_SB = 256 bytes (8 chunks) and walks it front to back with its exact position carried
 //     from chunk to chunk, so only the strip's first entry is a guess: the 256-bit run-up is paid once per 2048 bits;
 //   * the strip passes through LDS one 64-byte PHASE at a time (17 words per lane, as before), each lane's words in
@@ -96,21 +80,20 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_spec_check(const DecBlk *__re
 // single codes up to 288), start chunk 2 k + 1 (three codes per look-up while the fetch stays inside the row: q < 512).
 // The run-up is the same last step on a row that holds the 32 bytes in front of the strip.
 // Lanes whose guess differs from the exit of the lane before them walk again from that exit until they are back on
-// their first path (scan_strip_gen<.., true>: the wave reloads the phases, only those lanes walk); the first lane of a wave
-// is compared with the wave before it by sfd_spec_check and redone by sfd_scan<true> with its entry forced.
+// their first path (scan_strip_redo: the wave reloads the phases, only those lanes walk); the first lane of a wave
+// is compared with the wave before it by sfd_ends (sf_links), which walks the unit's first chunks again from the true entry.
 // ================================================================================================
 constexpr int SC_PHW = 16;                          // stream words per phase and strip (64 bytes)
 constexpr int SC_M = 4;                             // phases per strip
 constexpr int SC_SB = SC_PHW * 4 * SC_M;            // bytes per strip
 constexpr int SC_CH = SC_SB / CH_BYTES;             // chunks per strip
 constexpr int SC_STRIPS_TILE = DTILE / SC_SB;       // strips per tile (32: half a wave)
-constexpr int SC_WTILES = 64 / SC_STRIPS_TILE;      // tiles per wave (2): the "unit" of sfd_spec_check's links
+constexpr int SC_WTILES = 64 / SC_STRIPS_TILE;      // tiles per wave (2): the "unit" of the links sfd_ends checks
 constexpr int SC_TILES = DEC_THREADS / SC_STRIPS_TILE;   // tiles per workgroup (8)
 constexpr int SC_ROWW = SC_PHW + 1;                 // row words: the carried word, then the phase's 16
 constexpr int SC_COLB = DEC_THREADS * 4;            // bytes between two words of a column
 constexpr int SC_LDS_ROWS = SC_ROWW * SC_COLB;
 constexpr int SC_MISC = 64;                         // flags of wg_any
-constexpr int SC_FIX_REGIONS = 16;                  // regions a workgroup of a repair launch looks at
 static_assert(SC_COLB == 1024 && SC_WTILES == 2 && SC_STRIPS_TILE == 32, "sfd_scan's lane maps");
 
 struct ScanWin {
@@ -462,96 +445,63 @@ __device__ __forceinline__ void scan_strip_fast(const lds_u8 *tab, const u16 *lt
     exit_ = (q - 32u) & spec_emask<LONG>();
 }
 
-// The same walk for the rare cases, phases rolled (a few of them per launch: registers matter, speed does not):
-// LAST: the stream ends inside (or in front of) the wave's strips, at `end_bits` relative to the lane's strip (any sign);
-//       loads are bounded, a code that does not end inside the stream is not a symbol and nothing starts after it.
-// REDO = false: every lane walks: run-up (or `e_forced` where `forced`), then the strip.
-// REDO = true : the lanes with `walking` walk again from entry `e_forced` until an entry equals the one recorded in `o`
-//               (back on the first walk's path: the rest of o / exit stands); the others only help loading.
-template <bool LAST, int LONG, bool REDO>
-__device__ __forceinline__ void scan_strip_gen(const lds_u8 *tab, const u16 *lt, const u32 KW, const DecBlk &blk, const u64 wave_off,
-                                            const int end_bits, const u32 e_forced, const bool forced, bool walking,
-                                            ScanOut &o, u32 &exit_)
+// The walk again, phases rolled (a few waves per launch: registers matter, speed does not): the lanes with `walking` walk from
+// entry `e_forced` until an entry equals the one recorded in `o` (back on the first walk's path: the rest of o / exit stands);
+// the other lanes only help loading.  Strips inside the stream only (sfd_scan's units; the stream's end is sfd_ends').
+template <int LONG>
+__device__ __forceinline__ void scan_strip_redo(const lds_u8 *tab, const u16 *lt, const u32 KW, const DecBlk &blk, const u64 wave_off,
+                                                const u32 e_forced, bool walking, ScanOut &o, u32 &exit_)
 {
-    const u32 emask = spec_emask<LONG>();
     ScanIO io;
     io.init(blk, wave_off);
     ScanWin sw;
     sw.init(io.cb);
     uint4 R[4];
     u32 q = 0, pc = 0;
-    bool cut = false;
-    // (LAST: a lane whose row lies wholly inside the stream still takes whole fetches — only the strips the stream ends in
-    // go code by code)
-    auto inside = [&](const int ql) { return !LAST || ql > 32 * SC_PHW + 96; };
-    auto to_row_end = [&](const int ql) {
-        if (inside(ql)) scan_multi<LONG>(tab, lt, KW, q, 32u * SC_PHW + 32u, pc, sw);
-        if (LAST || LONG) cut = scan_single<LAST, LONG>(tab, lt, KW, q, 32u * SC_PHW, ql, pc, sw);
-    };
-    if (!REDO) {
-        uint4 RU[ScanIO::NRU];
-        io.load_runup<LAST>(RU);
-        io.put_runup(RU);
-        q = 32u * 9u;
-        to_row_end(end_bits + 32 * (SC_PHW + 1));
-        q -= 32u * SC_PHW;
-    }
     // (a walk that repeats loads each phase when it gets there: no registers held across the look-up loops)
-    if (!REDO) io.load_phase<LAST>(0, R);
 #pragma clang loop unroll(disable)
     for (int k = 0; k < SC_M; ++k) {
-        if (REDO) io.load_phase<LAST>(k, R);
+        io.load_phase<false>(k, R);
         io.put_phase(R);
         sw.flush();
-        if (!REDO && k + 1 < SC_M) io.load_phase<LAST>(k + 1, R);
-        const int ql = end_bits - 32 * SC_PHW * k + 32;
-        if (!REDO) {
-            if (!cut) cut = scan_single<LAST, LONG>(tab, lt, KW, q, 32u, ql, pc, sw);
-            if (k > 0) o.set_cnt(2 * k - 1, pc);
-            u32 e = cut ? emask : q - 32u;
-            if (k == 0 && forced) { e = e_forced; q = 32u + e; cut = false; }
-            o.set_ent(2 * k, e);
-        } else if (walking) {
+        if (walking) {
             if (k == 0) {
                 q = 32u + e_forced;
-                cut = false;
                 o.set_ent(0, e_forced);
             } else {
-                if (!cut) cut = scan_single<LAST, LONG>(tab, lt, KW, q, 32u, ql, pc, sw);
+                scan_single<false, LONG>(tab, lt, KW, q, 32u, 0, pc, sw);
                 o.set_cnt(2 * k - 1, pc);
-                const u32 e = cut ? emask : q - 32u;
+                const u32 e = q - 32u;
                 if (e == o.ent(2 * k)) walking = false; else o.set_ent(2 * k, e);
             }
         }
         if (walking) {
             u32 c = 0;
-            if (!cut) {
-                if (inside(ql)) scan_multi<LONG>(tab, lt, KW, q, 288u, c, sw);
-                cut = scan_single<LAST, LONG>(tab, lt, KW, q, 288u, ql, c, sw);
-            }
+            scan_multi<LONG>(tab, lt, KW, q, 288u, c, sw);
+            scan_single<false, LONG>(tab, lt, KW, q, 288u, 0, c, sw);
             o.set_cnt(2 * k, c);
-            const u32 e = cut ? emask : q - 288u;
-            if (REDO && e == o.ent(2 * k + 1)) walking = false; else o.set_ent(2 * k + 1, e);
+            const u32 e = q - 288u;
+            if (e == o.ent(2 * k + 1)) walking = false; else o.set_ent(2 * k + 1, e);
         }
         if (walking) {
             pc = 0;
-            if (!cut) to_row_end(ql);
+            scan_multi<LONG>(tab, lt, KW, q, 32u * SC_PHW + 32u, pc, sw);
+            if (LONG) scan_single<false, LONG>(tab, lt, KW, q, 32u * SC_PHW, 0, pc, sw);
             q -= 32u * SC_PHW;
         }
-        if (REDO && !__any(walking)) return;            // (uniform) every lane is back on its first path
+        if (!__any(walking)) return;                    // (uniform) every lane is back on its first path
     }
-    io.put_next_strip<LAST>(wave_off);
+    io.put_next_strip<false>(wave_off);
     sw.flush();
     if (walking) {
-        const int ql = end_bits - 32 * SC_PHW * SC_M + 32;
-        if (!cut) cut = scan_single<LAST, LONG>(tab, lt, KW, q, 32u, ql, pc, sw);
+        scan_single<false, LONG>(tab, lt, KW, q, 32u, 0, pc, sw);
         o.set_cnt(SC_CH - 1, pc);
-        exit_ = cut ? emask : (q - 32u) & emask;
+        exit_ = (q - 32u) & spec_emask<LONG>();
     }
 }
 
 // the wave's unit: tiles wtile, wtile + 1 of the block
-template <bool FIX, int LONG>
+template <int LONG>
 __device__ __forceinline__ void scan_unit(u8 *smem, const DecBlk &blk, const u32 wtile, u8 *__restrict__ chunk_entry,
                                           u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt, u8 *__restrict__ tile_guess,
                                           u8 *__restrict__ tile_exit, const u32 tab_bytes)
@@ -563,35 +513,18 @@ __device__ __forceinline__ void scan_unit(u8 *smem, const DecBlk &blk, const u32
     const u16 *lt = (const u16 *)(smem + SC_LDS_ROWS + tab_bytes + SC_MISC);
     const u64 wave_off = (u64)wtile * DTILE;
     const u64 left = blk.in_n > wave_off ? blk.in_n - wave_off : 0;
-    const bool last = left < (u64)64 * SC_SB + 4;       // the stream ends inside (or in front of) the wave's strips
-    const int end_bits = last ? (int)(left * 8) - (int)(8u * SC_SB * lane) : 0;
-    const bool exact0 = wtile == 0 && lane == 0;        // the block's first bit: entry 0, no guess
-    const bool forced = exact0 || (FIX && lane == 0);
-    const u32 e_forced = exact0 ? 0u : (FIX && lane == 0) ? (u32)tile_exit[gtw - 1] : 0u;
+    if (left < (u64)64 * SC_SB + 4) return;             // (uniform) the stream ends inside the wave's strips: the unit is sfd_ends'
+    const bool forced = wtile == 0 && lane == 0;        // the block's first bit: entry 0, no guess
     ScanOut o;
     u32 exit_ = 0;
-    if (!FIX) {
-        if (last) {                                     // (uniform) the block's last wave is left to the repair launch: a guess
-            if (lane == 0) {                            // that no exit equals marks it (sfd_spec_check)
-                tile_guess[gtw] = 0xFFu;
-                if (wtile + 1 < blk.n_tiles) { tile_exit[gtw] = 0; tile_guess[gtw + 1] = 0; }
-            }
-            return;
-        }
-        scan_strip_fast<LONG>(tab, lt, KW, blk, wave_off, e_forced, forced, o, exit_);
-    } else {
-        o.clear();
-        if (last) scan_strip_gen<true, LONG, false>(tab, lt, KW, blk, wave_off, end_bits, e_forced, forced, true, o, exit_);
-        else scan_strip_gen<false, LONG, false>(tab, lt, KW, blk, wave_off, 0, e_forced, forced, true, o, exit_);
-    }
+    scan_strip_fast<LONG>(tab, lt, KW, blk, wave_off, 0u, forced, o, exit_);
     // lanes whose guess differs from the exit in front of them walk again from that exit
     bool bad = false;
     for (int round = 0; round < 3; ++round) {
         const u32 prev = (u32)__shfl_up((int)exit_, 1, 64);
         bad = lane > 0 && (o.e[0] & 0xFFu) != prev;
         if (!__any(bad) || round == 2) break;
-        if (FIX && last) scan_strip_gen<true, LONG, true>(tab, lt, KW, blk, wave_off, end_bits, prev, false, bad, o, exit_);
-        else scan_strip_gen<false, LONG, true>(tab, lt, KW, blk, wave_off, 0, prev, false, bad, o, exit_);
+        scan_strip_redo<LONG>(tab, lt, KW, blk, wave_off, prev, bad, o, exit_);
     }
     if (__any(bad)) {                                   // did not settle: the block takes the exact kernels
         if (lane == 0) __hip_atomic_store(blk.run_dp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -617,26 +550,18 @@ __device__ __forceinline__ void scan_unit(u8 *smem, const DecBlk &blk, const u32
 }
 
 // dynamic LDS: rows (SC_LDS_ROWS) | cnt3 + len0 (tab_bytes) | flags (SC_MISC) | long-code table (LONG)
-template <bool FIX, int LONG>
-__global__ __launch_bounds__(DEC_THREADS) __attribute__((amdgpu_waves_per_eu(FIX ? 1 : SC_WAVES, 8))) void sfd_scan(const DecBlk *__restrict__ blks, u8 *__restrict__ chunk_entry,
+template <int LONG>
+__global__ __launch_bounds__(DEC_THREADS) __attribute__((amdgpu_waves_per_eu(SC_WAVES, 8))) void sfd_scan(const DecBlk *__restrict__ blks, u8 *__restrict__ chunk_entry,
                                                         u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt,
-                                                        u8 *__restrict__ tile_guess, u8 *__restrict__ tile_exit,
-                                                        const u8 *__restrict__ tile_fix, u32 tab_bytes, u32 long_bytes)
+                                                        u8 *__restrict__ tile_guess, u8 *__restrict__ tile_exit, u32 tab_bytes, u32 long_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const DecBlk blk = blks[blockIdx.y];
     if (!blk.run_dp || __hip_atomic_load(blk.run_dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // exact path
     if (lds_addr(smem) != 0) __builtin_trap();
     const u32 wv = threadIdx.x >> 6;
-    const u32 t_lo = blockIdx.x * (FIX ? SC_FIX_REGIONS * SC_TILES : SC_TILES);
+    const u32 t_lo = blockIdx.x * SC_TILES;
     if (t_lo >= blk.n_tiles) return;
-    if (FIX) {                                          // repair launch: almost no workgroup has a marked unit
-        bool mine = false;
-        for (u32 t = t_lo + threadIdx.x; t < t_lo + SC_FIX_REGIONS * SC_TILES && t < blk.n_tiles; t += DEC_THREADS)
-            mine |= tile_fix[(size_t)blk.tile_base + t] != 0;
-        u32 turn = 0;
-        if (!wg_any(mine, (u32 *)(smem + SC_LDS_ROWS + tab_bytes), turn)) return;
-    }
     fill_lds16((void *)(smem + SC_LDS_ROWS), (const void *)blk.cnt3, 2u << blk.KW);
     if (LONG) {
         u16 *lt = (u16 *)(smem + SC_LDS_ROWS + tab_bytes + SC_MISC);
@@ -645,12 +570,327 @@ __global__ __launch_bounds__(DEC_THREADS) __attribute__((amdgpu_waves_per_eu(FIX
         else if (threadIdx.x == 0) *lt = 0;
     }
     lds_barrier();
-    for (u32 r = 0; r < (FIX ? (u32)SC_FIX_REGIONS : 1u); ++r) {
-        const u32 wtile = t_lo + r * SC_TILES + wv * SC_WTILES;
-        if (wtile >= blk.n_tiles) break;
-        if (FIX && tile_fix[(size_t)blk.tile_base + wtile] == 0) continue;      // (wave-uniform)
-        scan_unit<FIX, LONG>(smem, blk, wtile, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tab_bytes);
+    const u32 wtile = t_lo + wv * SC_WTILES;
+    if (wtile < blk.n_tiles) scan_unit<LONG>(smem, blk, wtile, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tab_bytes);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The unit(s) a block's stream ENDS in, one chunk pair per lane (sl_region, a role of sfd_ends below).
+// sfd_scan walks 256-byte strips, one wave per 16 KiB unit: right for a grid that fills the chip, but the unit the stream
+// ends in (bounded loads, the cut at the last code) would be ONE wave that walks its 2 K bits per lane alone, and a dependent
+// look-up costs a lonely wave ~120 cycles: it used to take 40-50 us at the end of every launch, whatever the launch's size.
+// Here that unit is a whole workgroup: 256 lanes with 64 bytes each (two chunks) and the 256 bits in front as run-up — a third
+// of the look-ups per chain, all loads in flight at once — verified inside the workgroup like sfd_scan's units (a lane whose
+// guess differs from the exit in front of it walks again from that exit); its first lane needs no guess: it runs behind
+// sfd_scan and enters at the exit of the unit in front.  (The shape of round 3's sfd_spec, which sfd_scan replaced for the
+// bulk of the stream.)
+// ------------------------------------------------------------------------------------------------
+constexpr int SL_SW = 16;                          // stream words per lane (two chunks)
+constexpr int SL_ROW = SL_SW + 1;                  // LDS words per lane: its strip, then a copy of the next strip's first word
+constexpr int SL_STRIPS = DEC_THREADS + 1;         // strip 0 = the strip in front of the unit (its last chunk is lane 0's run-up)
+constexpr int SL_LDS_DATA = (SL_STRIPS * SL_ROW + 3) / 4 * 16;
+constexpr int SL_MISC = DEC_THREADS + 16 + 32;     // exits[256] | wsum[4] | flags[8]
+
+struct SlWin {
+    u32 lo, hi, wa;                                     // words at LDS address wa, wa + 4
+    __device__ __forceinline__ void init() { wa = 0xFFFFFFFFu; hi = lo = 0; }
+    __device__ __forceinline__ u32 at(u32 q)            // the 32 stream bits from LDS bit address q on
+    {
+        const u32 a = (q >> 3) & ~3u;
+        if (a != wa) {
+            const lds_u32 *pa = (const lds_u32 *)(size_t)a;
+            lo = pa[0];
+            hi = pa[1];
+            wa = a;
+        }
+        return __builtin_amdgcn_alignbit(hi, lo, q);
     }
+};
+
+// one walk: from LDS bit address q (a code start, by assumption) to the first code start >= qe, counting the codes started on
+// the way; the stream ends at bit address `qlimit` (may lie in front of q): a code that does not end inside it is not a symbol
+// and nothing starts after it (q = qe + emask: "cut").  tab: sfd_scan's tables (bits | codes << 5 per window, then the length
+// of a window's first code).
+template <int LONG>
+__device__ __forceinline__ void sl_walk(const lds_u8 *tab, const u16 *lt, const u32 KW, u32 &q, const u32 qe, const int qlimit, u32 &cnt, SlWin &sw)
+{
+    const u32 mask = (1u << KW) - 1u;
+    auto long_len = [&](const u32 qq) -> u32 {          // the code of more than KW bits at qq (at least 1: the walk must move)
+        const u32 win = __builtin_bitreverse32(sw.at(qq));
+        const u32 l = (LONG == 1 ? long_code(lt, win) : long_code32(lt, win)) >> 8;
+        return l ? l : 1u;
+    };
+    // whole fetches while every code taken ends in front of the stream's end (three or two windows of KW bits each)
+    const u32 nlook = KW <= 10 ? 3u : 2u;
+    while (q + nlook * KW <= qe && (int)(q + nlook * KW) <= qlimit) {
+        const u32 w = sw.at(q);
+        u32 sum = 0, e = 0;
+        for (u32 i = 0; i < nlook; ++i) {
+            e = tab[(w >> (sum & 31u)) & mask];
+            sum += e;
+        }
+        q += sum & 31u;
+        cnt += sum >> 5;
+        if (LONG && __builtin_expect((e & 31u) == 0u, 0)) {      // a long code stopped the look-ups: it starts at q
+            const u32 l = long_len(q);
+            if ((int)(q + l) > qlimit) { q = qe + spec_emask<LONG>(); return; }
+            q += l;
+            ++cnt;
+        }
+    }
+    const lds_u8 *len0 = tab + (1u << KW);
+    while (q < qe) {
+        u32 l0 = len0[sw.at(q) & mask];
+        if (LONG && __builtin_expect(l0 == 0u, 0)) l0 = long_len(q);
+        if ((int)(q + l0) > qlimit) { q = qe + spec_emask<LONG>(); break; }   // cut by the end of the stream
+        q += l0;
+        ++cnt;
+    }
+}
+
+// a lane's two chunks (LDS bit address qrow) from entry `ent0` of the first: entries, counts, the exit of the second.
+// HAVE_OLD: ent[] holds the entries of an earlier walk: once this walk meets it the rest is unchanged.
+template <bool HAVE_OLD, int LONG>
+__device__ __forceinline__ void sl_strip(const lds_u8 *tab, const u16 *lt, const u32 KW, const u32 qrow, const int qlimit, const u32 ent0,
+                                         u32 (&ent)[2], u32 (&cnt)[2], u32 &exit_)
+{
+    u32 q = qrow + ent0;
+    SlWin sw;
+    sw.init();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const u32 r = q - (qrow + 256u * k);
+        if (HAVE_OLD && k > 0 && r == ent[k]) return;   // back on the earlier walk's path
+        ent[k] = r;
+        u32 c = 0;                                      // (a chunk the stream ended in front of: entry emask, cut at once, count 0)
+        sl_walk<LONG>(tab, lt, KW, q, qrow + 256u * (k + 1), qlimit, c, sw);
+        cnt[k] = c;
+    }
+    exit_ = (q - (qrow + 512u)) & spec_emask<LONG>();
+}
+
+// One unit the stream ends in (tiles tile0, tile0 + 1), the tables already in LDS.  `have_e0`: lane 0 enters at e0 (the exit of the
+// unit in front, which is final by now: sfd_ends runs behind sfd_scan), else at the block's first bit.  Returns the unit's exit.
+// dynamic LDS: stream frame (SL_LDS_DATA) | cnt3 + len0 (tab_bytes) | exits[256] wsum[4] flags[8] (SL_MISC) | long-code table (LONG)
+template <int LONG>
+__device__ __forceinline__ u32 sl_region(u8 *smem, const DecBlk &blk, const u32 tile0, const u32 e0_forced, u8 *__restrict__ chunk_entry,
+                                         u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt, u8 *__restrict__ tile_guess,
+                                         u8 *__restrict__ tile_exit, const u32 tab_bytes)
+{
+    const u64 start = (u64)tile0 * DTILE;
+    const u64 left = blk.in_n > start ? blk.in_n - start : 0;
+    const size_t gt0 = (size_t)blk.tile_base + tile0;
+    const u32 ntl = blk.n_tiles - tile0 < (u32)SC_WTILES ? blk.n_tiles - tile0 : (u32)SC_WTILES;   // tiles of the unit
+    u32 *data = (u32 *)smem;
+    const u32 tab_off = SL_LDS_DATA;
+    u8 *ex = smem + SL_LDS_DATA + tab_bytes;
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 KW = blk.KW;
+    const u16 *lt = (const u16 *)(smem + SL_LDS_DATA + tab_bytes + SL_MISC);
+    {   // the unit's stream from one strip before it, 16 bytes a lane; frame word f -> LDS word f + f / SL_SW.  All of a lane's
+        // pieces are requested before the first is used; bytes outside the stream read as zero.
+        const long long base = (long long)start - 4 * SL_SW;
+        constexpr u32 UNITS = (u32)(SL_STRIPS * SL_SW / 4 + 1), NIT = (UNITS + DEC_THREADS - 1) / DEC_THREADS;
+        uint4 v[NIT];
+#pragma unroll
+        for (u32 it = 0; it < NIT; ++it) {
+            const u32 i = tid + it * DEC_THREADS;
+            const long long off = base + (long long)i * 16;
+            v[it] = make_uint4(0, 0, 0, 0);
+            if (i < UNITS && off >= 0 && (u64)off + 16 <= blk.in_n) v[it] = gload<uint4>(blk.in + off);
+        }
+#pragma unroll
+        for (u32 it = 0; it < NIT; ++it) {
+            const u32 i = tid + it * DEC_THREADS;
+            if (i >= UNITS) break;
+            const long long off = base + (long long)i * 16;
+            u32 w[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+            if (off >= 0 && (u64)off < blk.in_n && (u64)off + 16 > blk.in_n) {      // the piece the stream ends in
+                const int nv = (int)(blk.in_n - (u64)off);
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (q < nv) w[q >> 2] |= (u32)gload<u8>(blk.in + off + q) << (8 * (q & 3));
+            }
+            const u32 f = 4 * i, at = f + f / SL_SW;
+            const u32 w0 = rev_bytes(w[0]);
+            if (f % SL_SW == 0 && f > 0) data[at - 1] = w0;         // the previous row's look-ahead word
+            if (i < UNITS - 1) {
+                data[at] = w0;
+                data[at + 1] = rev_bytes(w[1]);
+                data[at + 2] = rev_bytes(w[2]);
+                data[at + 3] = rev_bytes(w[3]);
+            }
+        }
+    }
+    __syncthreads();
+    // lane tid owns frame strip tid + 1; the stream ends at bit `limit` of that strip (<= 0: in front of it)
+    const int limit = (int)(left * 8) - (int)(512u * tid);
+    const u32 qrow = 8u * ((4u * SL_ROW) * (tid + 1));  // LDS bit address of the strip's first bit (the segment starts at 0)
+    const int qlimit = (int)qrow + limit;
+    const lds_u8 *tab = (const lds_u8 *)(size_t)tab_off;
+    u32 ent[2] = {0, 0}, cnt[2] = {0, 0}, exit_ = 0;
+    {
+        u32 e0;
+        if (tid == 0) e0 = e0_forced;                   // known: the block's first bit, or the exit of the unit in front
+        else {                                          // run-up: the last chunk of the strip in front, from its first bit
+            const u32 qe = qrow;
+            u32 q = qe - 256u, dummy = 0;
+            SlWin sw;
+            sw.init();
+            sl_walk<LONG>(tab, lt, KW, q, qe, qlimit, dummy, sw);
+            e0 = (q - qe) & spec_emask<LONG>();
+        }
+        sl_strip<false, LONG>(tab, lt, KW, qrow, qlimit, e0, ent, cnt, exit_);
+    }
+    ex[tid] = (u8)exit_;
+    __syncthreads();
+    // lanes whose guess differs from the exit in front of them walk again from that exit, until the walk meets the old one
+    bool bad = false;
+    u32 *const wsum = (u32 *)(ex + DEC_THREADS), *const flags = wsum + 4;
+    u32 turn = 0;
+    for (int round = 0; round < 4; ++round) {
+        bad = tid > 0 && ent[0] != (u32)ex[tid - 1];
+        if (!wg_any(bad, flags, turn)) break;
+        if (bad) sl_strip<true, LONG>(tab, lt, KW, qrow, qlimit, (u32)ex[tid - 1], ent, cnt, exit_);
+        __syncthreads();                                // every lane has read the exit in front of it
+        ex[tid] = (u8)exit_;
+        __syncthreads();
+        bad = tid > 0 && ent[0] != (u32)ex[tid - 1];
+    }
+    if (wg_any(bad, flags, turn)) {                     // did not settle: the block takes the exact kernels
+        if (tid == 0) __hip_atomic_store(blk.run_dp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // chunks 2 tid, 2 tid + 1 of the unit; a tile is 128 consecutive lanes (two waves)
+    const u32 my_tile = tid / 128u;
+    const u32 wtot = dpp_scan_add(cnt[0] + cnt[1]);     // lane 63: the wave's codes
+    if (lane == 63) wsum[wv] = wtot;
+    __syncthreads();
+    if (my_tile < ntl) {
+        const size_t c0 = gt0 * DEC_THREADS + (size_t)tid * 2;
+        gstore<u16>(chunk_entry + c0, (u16)((ent[0] & 0xFFu) | (ent[1] << 8)));
+        gstore<u32>(chunk_cnt + c0, cnt[0] | (cnt[1] << 16));
+        const u32 in_tile = tid & 127u;
+        if (in_tile == 0) {
+            tile_cnt[gt0 + my_tile] = wsum[2 * my_tile] + wsum[2 * my_tile + 1];
+            tile_guess[gt0 + my_tile] = (u8)ent[0];
+        }
+        if (in_tile == 127u) tile_exit[gt0 + my_tile] = (u8)exit_;
+    }
+    const u32 unit_exit = ex[ntl * 128u - 1u];          // the exit of the unit's last existing tile
+    __syncthreads();                                    // (the frame and ex[] may be rewritten by the next unit)
+    return unit_exit;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sfd_fix: the links BETWEEN units, checked and repaired in one launch (one workgroup per block).
+// A unit's first lane guesses its entry from a 256-bit run-up; the unit in front of it knows the truth: its exit.  Where the
+// two differ (0.2 % of the links of Zipf-like data: a handful per 64 MiB block) the unit's walk was wrong only until it met
+// the true parse — a few dozen bits.  So ONE lane per bad link walks again from the exit in front, code by code, rewriting the
+// entries and counts of the unit's first chunks until its position at a chunk boundary equals the entry recorded there: from
+// then on everything the unit wrote stands, its own exit included — which is why one round is enough and no link depends on
+// another's repair.  (This used to be two rounds of a check kernel and a repair launch of sfd_scan, where a whole 16 KiB unit was walked
+// again by one lonely wave: 40-50 us per round, whatever the launch's size.)  A link that does not heal within SF_CHUNKS
+// chunks, or lies within that distance of the stream's end, sends its block to the exact kernels; when every link of a
+// block holds, its entries ARE the true parse (the argument at the top of this file).
+// ------------------------------------------------------------------------------------------------
+constexpr u32 SF_CHUNKS = 8;                       // chunks a repair may walk before it gives up (2048 bits)
+
+// the links into tiles 1 .. t_end - 1 (the tiles of the units the stream ends in are sfd_ends' other workgroup's); tables at smem
+template <int LONG>
+__device__ __forceinline__ void sf_links(u8 *smem, const DecBlk &blk, const u32 t_end, u8 *__restrict__ chunk_entry, u16 *__restrict__ chunk_cnt,
+                                         u32 *__restrict__ tile_cnt, u8 *__restrict__ tile_guess, const u8 *__restrict__ tile_exit,
+                                         const u32 tab_bytes)
+{
+    const u32 tid = threadIdx.x, KW = blk.KW, mask = (1u << KW) - 1u;
+    const u16 *lt = (const u16 *)(smem + tab_bytes + 32);
+    const u8 *len0 = smem + (1u << KW);
+    const u64 end_bit = blk.in_n * 8;
+    bool failed = false;
+    for (u32 t = 1 + tid; t < t_end; t += DEC_THREADS) {
+        const size_t gt = (size_t)blk.tile_base + t;
+        const u32 x = tile_exit[gt - 1];
+        if (tile_guess[gt] == x) continue;
+        const u64 tile_bit0 = (u64)t * DTILE * 8;
+        // a "stream ended" mark in front, or the stream's end within reach of the walk: not repaired here
+        if (x >= spec_emask<LONG>() || tile_bit0 + (u64)(SF_CHUNKS + 1) * CH_BITS + 64 > end_bit) { failed = true; continue; }
+        u32 q = x, wi = 0xFFFFFFFFu, lo = 0, hi = 0;    // q: bit position in the tile; (lo, hi): stream words wi, wi + 1 of the tile, LSB first
+        auto window = [&](const u32 qq) -> u32 {
+            const u32 i = qq >> 5;
+            if (i != wi) {
+                const u8 *p = blk.in + (u64)t * DTILE + 4u * i;
+                lo = rev_bytes(gload<u32>(p));
+                hi = rev_bytes(gload<u32>(p + 4));
+                wi = i;
+            }
+            return __builtin_amdgcn_alignbit(hi, lo, qq);
+        };
+        int delta = 0;
+        bool merged = false;
+        const size_t c0 = gt * DEC_THREADS;
+        for (u32 c = 0; c < SF_CHUNKS; ++c) {
+            const u32 qe = CH_BITS * (c + 1);
+            u32 cnt = 0;
+            while (q < qe) {
+                const u32 w = window(q);
+                u32 l = len0[w & mask];
+                if (LONG && l == 0u) {
+                    const u32 win = __builtin_bitreverse32(w);
+                    l = (LONG == 1 ? long_code(lt, win) : long_code32(lt, win)) >> 8;
+                    if (!l) l = 1u;
+                }
+                q += l;
+                ++cnt;
+            }
+            delta += (int)cnt - (int)chunk_cnt[c0 + c];
+            chunk_cnt[c0 + c] = (u16)cnt;
+            const u32 e = q - qe;
+            if (e == (u32)chunk_entry[c0 + c + 1]) { merged = true; break; }
+            chunk_entry[c0 + c + 1] = (u8)e;
+        }
+        if (!merged) { failed = true; continue; }
+        chunk_entry[c0] = (u8)x;
+        tile_guess[gt] = (u8)x;
+        tile_cnt[gt] = (u32)((int)tile_cnt[gt] + delta);
+    }
+    u32 turn = 0;
+    if (wg_any(failed, (u32 *)(smem + tab_bytes), turn) && tid == 0)
+        __hip_atomic_store(blk.run_dp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// sfd_ends, behind sfd_scan: grid (2, blocks).  Workgroup 0 of a block: the unit(s) its stream ends in (sl_region; sfd_scan leaves
+// them out), the first lane entered at the exit of the unit in front — final by now, so these units' links hold by construction.
+// Workgroup 1: every other link of the block (sf_links).  Either sets *run_dp when something does not hold.
+template <int LONG>
+__global__ __launch_bounds__(DEC_THREADS) void sfd_ends(const DecBlk *__restrict__ blks, u8 *__restrict__ chunk_entry,
+                                                        u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt,
+                                                        u8 *__restrict__ tile_guess, u8 *__restrict__ tile_exit, u32 tab_bytes, u32 long_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const DecBlk blk = blks[blockIdx.y];
+    if (!blk.n_tiles || !blk.run_dp || __hip_atomic_load(blk.run_dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // exact path
+    if (lds_addr(smem) != 0) __builtin_trap();
+    // the units sfd_scan left out: those with fewer than 64 strips + 4 bytes of stream from their start (the last one; the one
+    // before it too when the stream ends one to three bytes into the last)
+    const u32 units = (blk.n_tiles + SC_WTILES - 1) / SC_WTILES;
+    u32 first_end = units - 1;
+    if (units >= 2 && blk.in_n - (u64)(units - 2) * SC_WTILES * DTILE < (u64)64 * SC_SB + 4) first_end = units - 2;
+    const bool ends_role = blockIdx.x == 0;
+    const u32 tab_at = ends_role ? (u32)SL_LDS_DATA : 0u;
+    fill_lds16((void *)(smem + tab_at), (const void *)blk.cnt3, 2u << blk.KW);
+    if (LONG) {
+        u16 *lt = (u16 *)(smem + tab_at + tab_bytes + (ends_role ? (u32)SL_MISC : 32u));
+        const u16 *src = LONG == 1 ? blk.longtab : blk.long32;
+        if (src) fill_lds16((void *)lt, src, long_bytes);
+        else if (threadIdx.x == 0) *lt = 0;
+    }
+    __syncthreads();
+    if (!ends_role) {
+        sf_links<LONG>(smem, blk, first_end * SC_WTILES, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tab_bytes);
+        return;
+    }
+    u32 e0 = first_end ? (u32)tile_exit[(size_t)blk.tile_base + first_end * SC_WTILES - 1] : 0u;
+    for (u32 u = first_end; u < units; ++u)
+        e0 = sl_region<LONG>(smem, blk, u * SC_WTILES, e0, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tab_bytes);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1207,7 +1447,6 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
         if (ntiles[b] && spec_worthwhile(h_tables[b], tabs[b], g_sfd_speculate == 2)) { spec_blk[b] = 1; any_spec = true; }
     const size_t o_tguess = off; off += any_spec ? (size_t)total_tiles : 0; off = (off + 15) & ~(size_t)15;
     const size_t o_texit = off; off += any_spec ? (size_t)total_tiles : 0; off = (off + 15) & ~(size_t)15;
-    const size_t o_tfix = off; off += any_spec ? (size_t)total_tiles : 0; off = (off + 15) & ~(size_t)15;
     int rc = batch_reserve(bt, st, off);
     if (rc) return rc;
     u8 *ws = (u8 *)bt->d_ws;
@@ -1314,33 +1553,37 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
     const dim3 grid_f((u32)ceil_div_u64(max_tiles, tpw), (u32)nblocks);
     constexpr int CSUBS = 4;                           // 256-lane groups per workgroup of sfd_countfsm
     const dim3 grid_c((u32)ceil_div_u64(max_tiles, tpw * CSUBS), (u32)nblocks);
-    // speculative entries: guesses, two rounds of tile repairs, final verdict per block
+    // speculative entries: the guesses of every unit (sfd_scan), then the units the streams end in, the links between all units and
+    // the verdict per block (sfd_ends)
     auto launch_spec = [&]() {
-        u8 *tg = ws + o_tguess, *tx = ws + o_texit, *tf = ws + o_tfix;
+        u8 *tg = ws + o_tguess, *tx = ws + o_texit;
         u32 k1_max = 1;
         for (int b = 0; b < nblocks; ++b) if (spec_blk[b] && hblk_kw[b] > k1_max) k1_max = hblk_kw[b];
         const u32 tabb = 2u << k1_max;
         const size_t lds_scan = (size_t)SC_LDS_ROWS + tabb + SC_MISC + (spec_long ? (size_t)long_used : 0);
         const dim3 grid_c((u32)ceil_div_u64(max_tiles, SC_TILES), (u32)nblocks);
-        const dim3 grid_cf((u32)ceil_div_u64(max_tiles, SC_TILES * SC_FIX_REGIONS), (u32)nblocks);
-        auto scan = [&](auto fix, const dim3 grid) {
-            constexpr bool FIX = decltype(fix)::value;
+        if (spec_long == 2)
+            hipLaunchKernelGGL((sfd_scan<2>), grid_c, dim3(DEC_THREADS), lds_scan, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
+                               (u32 *)(ws + o_tcnt), tg, tx, tabb, long_used);
+        else if (spec_long == 1)
+            hipLaunchKernelGGL((sfd_scan<1>), grid_c, dim3(DEC_THREADS), lds_scan, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
+                               (u32 *)(ws + o_tcnt), tg, tx, tabb, long_used);
+        else
+            hipLaunchKernelGGL((sfd_scan<0>), grid_c, dim3(DEC_THREADS), lds_scan, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
+                               (u32 *)(ws + o_tcnt), tg, tx, tabb, long_used);
+        {   // the units the streams end in and the links between all units: checked, repaired, the blocks' verdicts
+            const size_t lds_ends = (size_t)SL_LDS_DATA + tabb + SL_MISC + (spec_long ? (size_t)long_used : 0);
+            const dim3 grid_e(2, (u32)nblocks);
             if (spec_long == 2)
-                hipLaunchKernelGGL((sfd_scan<FIX, 2>), grid, dim3(DEC_THREADS), lds_scan, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
-                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb, long_used);
+                hipLaunchKernelGGL((sfd_ends<2>), grid_e, dim3(DEC_THREADS), lds_ends, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
+                                   (u32 *)(ws + o_tcnt), tg, tx, tabb, long_used);
             else if (spec_long == 1)
-                hipLaunchKernelGGL((sfd_scan<FIX, 1>), grid, dim3(DEC_THREADS), lds_scan, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
-                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb, long_used);
+                hipLaunchKernelGGL((sfd_ends<1>), grid_e, dim3(DEC_THREADS), lds_ends, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
+                                   (u32 *)(ws + o_tcnt), tg, tx, tabb, long_used);
             else
-                hipLaunchKernelGGL((sfd_scan<FIX, 0>), grid, dim3(DEC_THREADS), lds_scan, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
-                                   (u32 *)(ws + o_tcnt), tg, tx, (const u8 *)tf, tabb, long_used);
-        };
-        scan(std::false_type{}, grid_c);
-        for (int round = 0; round < 2; ++round) {
-            hipLaunchKernelGGL(sfd_spec_check<false>, dim3((u32)nblocks, 4), dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
-            scan(std::true_type{}, grid_cf);
+                hipLaunchKernelGGL((sfd_ends<0>), grid_e, dim3(DEC_THREADS), lds_ends, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
+                                   (u32 *)(ws + o_tcnt), tg, tx, tabb, long_used);
         }
-        hipLaunchKernelGGL(sfd_spec_check<true>, dim3((u32)nblocks, 4), dim3(DEC_THREADS), 0, st, dblk, (const u8 *)tg, (const u8 *)tx, tf);
     };
     // when every block of the launch speculates, the exact kernels are fall-backs that normally return at once:
     // fat workgroups (256 tiles each) make that a launch of a few thousand workgroups instead of a few hundred thousand

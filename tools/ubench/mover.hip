@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <string.h>
 
 typedef uint32_t u32;
 typedef uint64_t u64;
@@ -65,8 +66,10 @@ static float time_ms(F f, int iters)
     return ms / iters;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    // `mover headline`: the two figures bench.py quotes next to the encoder (roofline_encode.mover_*), one line each
+    const bool brief = argc > 1 && !strcmp(argv[1], "headline");
     const u64 n = 8ull << 30;                          // input bytes per launch, as the headline's 128 x 64 MiB
     v4u *d_a, *d_b;
     CK(hipMalloc(&d_a, n)); CK(hipMalloc(&d_b, n));
@@ -77,6 +80,11 @@ int main()
         const u32 grid = PERSIST ? (u32)(GRID) : (u32)nwg; \
         float ms = time_ms([&] { hipLaunchKernelGGL((k_move<U, S32, NTL, NTS, LDSRT, PERSIST>), dim3(grid), dim3(256), 0, 0, d_a, d_b, nwg); }, 5); \
         printf("%-64s %7.3f ms  %5.2f TB/s  (of 8 TB/s: %.3f)\n", NAME, ms, bytes / ms / 1e9, bytes / ms / 1e9 / 8.0); }
+    if (brief) {
+        RUN("one-shot 32 KiB/WG coalesced, nt ld, nt st", 8, false, true, true, false, false, 0)
+        RUN("persistent 2048 WGs, 32 KiB/iter coalesced, plain ld, nt st", 8, false, false, true, false, true, 2048)
+        return 0;
+    }
     for (int rep = 0; rep < 2; ++rep) {
         RUN("one-shot 32 KiB/WG coalesced, plain ld, nt st", 8, false, false, true, false, false, 0)
         RUN("one-shot 32 KiB/WG coalesced, nt ld, nt st", 8, false, true, true, false, false, 0)
