@@ -421,6 +421,30 @@ def pipeline_leg(args, pkg, torch, dev, st, steps, nb, kind):
     t0 = time.perf_counter()
     tables = pkg.sf_build_codes_batch(freq)            # Module T for the launch's blocks (host: one call, up to 8 threads)
     t_t = time.perf_counter() - t0
+    # Module T on the device (csrc/sf_tables.hip): the histograms never leave the GPU, the launch's tables come back in ONE copy
+    # (8.25 KB a block) because the encoder's launcher picks its kernel forms from the code lengths on the host.  This is the
+    # leg's T: its time goes into F_T_C_GiBs; the host's is reported next to it.  Bit-identical to the host's tables.
+    import ctypes as C
+    tsz = C.sizeof(pkg.CodeTable)
+    d_tabs = torch.empty(nb * tsz, dtype=torch.uint8, device=dev)
+    h_tabs = torch.empty(nb * tsz, dtype=torch.uint8).pin_memory()
+
+    def device_t():
+        bt.sf_build_codes(st, nb, d_freq, d_tabs)
+        with torch.cuda.stream(st):
+            h_tabs.copy_(d_tabs, non_blocking=True)
+    torch.cuda.synchronize()
+    device_t()
+    bt.finish(st, nb)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        device_t()
+        bt.finish(st, nb)                              # the tables are needed on the host: every round ends in a synchronisation
+    t_td = (time.perf_counter() - t0) / steps
+    dev_tables = (pkg.CodeTable * nb).from_buffer_copy(h_tabs.numpy().tobytes())
+    for b in range(nb):
+        assert bytes(dev_tables[b]) == bytes(tables[b]), f"Module T on the device differs from the host's in block {b}"
+    tables = [dev_tables[b] for b in range(nb)]
     lens = np.stack([tables[b].lens() for b in range(nb)]).astype(np.uint64)
     enc_bytes = [int(x) for x in ((freq * lens).sum(axis=1) + 7) // 8]
     cap = ((max(enc_bytes) + 4096 + 255) // 256) * 256
@@ -464,9 +488,9 @@ def pipeline_leg(args, pkg, torch, dev, st, steps, nb, kind):
 
     out.update({"rle_ratio": rle_tot / tot, "sf_ratio_of_rle": enc_tot / rle_tot, "traffic_source": tsrc,
                 "K1_hist256": fam(tot, t_h, "K1_hist256"), "K2_rle_encode_hist": fam(tot + rle_tot, t_f, "K2_rle_encode_hist"),
-                "T_host_ms": t_t * 1e3, "K3_sf_encode": fam(rle_tot + enc_tot, t_c, "K3_sf_encode"),
+                "T_device_ms": t_td * 1e3, "T_host_ms": t_t * 1e3, "K3_sf_encode": fam(rle_tot + enc_tot, t_c, "K3_sf_encode"),
                 "K4_sf_decode": fam(enc_tot + rle_tot, t_ds, "K4_sf_decode"), "K5_rle_decode": fam(rle_tot + tot, t_dr, "K5_rle_decode"),
-                "F_T_C_GiBs": tot / GIB / (t_f + t_t + t_c), "D_GiBs": tot / GIB / (t_ds + t_dr),
+                "F_T_C_GiBs": tot / GIB / (t_f + t_td + t_c), "D_GiBs": tot / GIB / (t_ds + t_dr),
                 "tile_histograms": "K1 and K2 also write the 256 x u16 histogram of every 32 KiB tile (1.6 % of the bytes "
                                    "they count), which lets K3 run as a one-shot grid (sf_encode6)"})
     bt.close()
