@@ -1,6 +1,6 @@
 #!/bin/bash
 # The round's profile set in one call (through gpurun): headline alone, the two pipeline legs alone, config[1].
-# Summaries and traffic.json land in gpurun_out/prof_<tag>/; copy them to profiles/r5_<tag>_* afterwards.
+# Summaries and traffic.json land in gpurun_out/prof_<tag>/; copy them to profiles/<round>_<tag>_* afterwards (tools/copy_profiles.sh r6).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$R" || exit 1
 tools/gpu_prof.sh main --steps 5 --warmup 2 --no-pipeline > /dev/null 2>&1
