@@ -806,13 +806,19 @@ __device__ __forceinline__ void sf_links(u8 *smem, const DecBlk &blk, const u32 
     const u8 *len0 = smem + (1u << KW);
     const u64 end_bit = blk.in_n * 8;
     bool failed = false;
+    // (one link that does not heal sends the whole block to the exact kernels: the others stop looking — a table that does not
+    // re-synchronise, forced to speculate, would otherwise walk eight chunks behind most of its 4096 links)
+    volatile u32 *const gave_up = (volatile u32 *)(smem + tab_bytes + 28);      // (the last word of the flag area: the one wg_any call below uses its first four)
+    if (tid == 0) *gave_up = 0;
+    __syncthreads();
     for (u32 t = 1 + tid; t < t_end; t += DEC_THREADS) {
+        if (*gave_up) break;
         const size_t gt = (size_t)blk.tile_base + t;
         const u32 x = tile_exit[gt - 1];
         if (tile_guess[gt] == x) continue;
         const u64 tile_bit0 = (u64)t * DTILE * 8;
         // a "stream ended" mark in front, or the stream's end within reach of the walk: not repaired here
-        if (x >= spec_emask<LONG>() || tile_bit0 + (u64)(SF_CHUNKS + 1) * CH_BITS + 64 > end_bit) { failed = true; continue; }
+        if (x >= spec_emask<LONG>() || tile_bit0 + (u64)(SF_CHUNKS + 1) * CH_BITS + 64 > end_bit) { failed = true; *gave_up = 1; continue; }
         u32 q = x, wi = 0xFFFFFFFFu, lo = 0, hi = 0;    // q: bit position in the tile; (lo, hi): stream words wi, wi + 1 of the tile, LSB first
         auto window = [&](const u32 qq) -> u32 {
             const u32 i = qq >> 5;
@@ -847,7 +853,7 @@ __device__ __forceinline__ void sf_links(u8 *smem, const DecBlk &blk, const u32 
             if (e == (u32)chunk_entry[c0 + c + 1]) { merged = true; break; }
             chunk_entry[c0 + c + 1] = (u8)e;
         }
-        if (!merged) { failed = true; continue; }
+        if (!merged) { failed = true; *gave_up = 1; continue; }
         chunk_entry[c0] = (u8)x;
         tile_guess[gt] = (u8)x;
         tile_cnt[gt] = (u32)((int)tile_cnt[gt] + delta);
