@@ -278,6 +278,13 @@ __device__ __forceinline__ void set_error(int *err, int code)
 {
     atomicCAS(err, 0, code);
 }
+// A block with two faults of different kinds: the sequential coder (the oracle) reports the one it meets first, and which that
+// is does not depend on timing.  `code` replaces "no error" and the error `weaker`, whichever workgroup comes first.
+__device__ __forceinline__ void set_error_over(int *err, int code, int weaker)
+{
+    const int old = atomicCAS(err, 0, code);
+    if (old == weaker) atomicCAS(err, weaker, code);
+}
 
 // ---------------------------------------------------------------------------------------------
 // look-back over one block's tile descriptors; wave 0 only, all 64 lanes.  Returns the exclusive

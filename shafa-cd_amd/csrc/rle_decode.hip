@@ -405,8 +405,34 @@ __global__ __launch_bounds__(RLD_THREADS) __attribute__((amdgpu_waves_per_eu(RLD
         if (done == 0) {
             O = sh.O;
             const u64 Oend = O + ltot;
-            if (Oend > (u64)SHAFA_RLE_DECODE_MAX) { if (tid == 0) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE); }
-            else if (Oend > blk.out_cap) { if (tid == 0) set_error(blk.err, SHAFA_LACK_OF_MEMORY); }
+            // The block's return code is the one a sequential decoder stops with (the oracle): the first token whose end
+            // passes min(out_cap, MAX) — it is in the one tile with O <= limit < Oend — is FILE_UNRECOGNIZABLE when it passes
+            // MAX, LACK_OF_MEMORY otherwise; a triple cut by the end of the block (above) comes behind every token, so
+            // LACK_OF_MEMORY replaces its FILE_UNRECOGNIZABLE, whichever tile reports first.
+            if (O <= limit && Oend > limit) {           // (uniform)
+                if (limit == (u64)SHAFA_RLE_DECODE_MAX) {
+                    if (tid == 0) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
+                } else if (Oend <= (u64)SHAFA_RLE_DECODE_MAX) {
+                    if (tid == 0) set_error_over(blk.err, SHAFA_LACK_OF_MEMORY, SHAFA_FILE_UNRECOGNIZABLE);
+                } else if (tid == 0) {                  // out_cap within a token's length of MAX and the tile passes both: the
+                    const u64 tile0 = (u64)k * RLD_TILE;        //   token that passes out_cap decides; thread 0 parses the tile again
+                    const u32 nv = n - tile0 < (u64)RLD_TILE ? (u32)(n - tile0) : (u32)RLD_TILE;
+                    u64 l = O;
+                    int code = SHAFA_LACK_OF_MEMORY;
+                    for (u32 i = sh.state_in == 1u ? 2u : sh.state_in == 2u ? 1u : 0u; i < nv; ++i) {
+                        u32 c = 1;
+                        if (sh.in[i] == 0) {
+                            if (tile0 + i + 2 >= n) break;      // cut by the end of the block: no output
+                            c = sh.in[i + 2] ? sh.in[i + 2] : 1u;
+                            i += 2;
+                        }
+                        l += c;
+                        if (l > limit) { if (l > (u64)SHAFA_RLE_DECODE_MAX) code = SHAFA_FILE_UNRECOGNIZABLE; break; }
+                    }
+                    if (code == SHAFA_LACK_OF_MEMORY) set_error_over(blk.err, code, SHAFA_FILE_UNRECOGNIZABLE);
+                    else set_error(blk.err, code);
+                }
+            }
             if (k == (int)blk.n_tiles - 1 && tid == 0) *blk.out_n = Oend;
             if (!ltot || O >= limit) return;
         }

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(ENC_THREADS) void sf_encode_generic(const EncBlk *_
         }
         tot += len[j];
     }
-    if (bad) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
+    if (bad) set_error_over(blk.err, SHAFA_FILE_UNRECOGNIZABLE, SHAFA_LACK_OF_MEMORY);
 
     const u32 incl = wave_incl_scan_add<u32>(tot);
     if (lane_id() == 63) sh.wtot[wave_id()] = incl;

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_count(const EncBlk *__restric
 #pragma unroll
         for (int it = 0; it < CI; ++it) cur[it] = nxt[it];
     }
-    if (absent) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
+    if (absent) set_error_over(blk.err, SHAFA_FILE_UNRECOGNIZABLE, SHAFA_LACK_OF_MEMORY);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(E3_THREADS) void sfe3_pack(const EncBlk *__restrict
         u32 absent = 0;
 #pragma unroll
         for (int it = 0; it < E3_ITEMS; ++it) { absent |= itot[it] >> 12; itot[it] &= 0xFFFu; }
-        if (absent) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);     // data symbol without a code (output undefined, in bounds)
+        if (absent) set_error_over(blk.err, SHAFA_FILE_UNRECOGNIZABLE, SHAFA_LACK_OF_MEMORY);     // data symbol without a code (output undefined, in bounds)
     }
     u32 incl[E3_ITEMS];
 #pragma unroll

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(NT, E4_WPS) void sfe5_kernel(const EncBlk *__restri
                 u32 absent = 0;
                 if constexpr (UNITS == 4) tile_octs5<NW, L16>(sh.lut, cin, c_oct, tot, incl, tail, absent);
                 else tile_quads5(sh.lut, cin, c_oct, tot, incl, tail, absent);
-                if (absent) set_error(bp->err, SHAFA_FILE_UNRECOGNIZABLE);   // data symbol without a code (output undefined, in bounds)
+                if (absent) set_error_over(bp->err, SHAFA_FILE_UNRECOGNIZABLE, SHAFA_LACK_OF_MEMORY);   // data symbol without a code (output undefined, in bounds)
                 if (lane == 63) {
                     sh.wtot5[par][wv] = incl;
                     sh.tail5[par][wv] = tail;

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void sfe6_dot(const EncBlk *__restrict__ blks,
     if (lane < 16 && t0 + (u32)lane < nt) tbits[bp->desc_base + t0 + (u32)lane] = mine;
     // a data symbol without a code (c.c:156-159): reported here, ahead of sfe6_scan's size check, as the other encoders
     // meet it before they run out of room
-    if (seen & nocode) set_error(bp->err, SHAFA_FILE_UNRECOGNIZABLE);
+    if (seen & nocode) set_error_over(bp->err, SHAFA_FILE_UNRECOGNIZABLE, SHAFA_LACK_OF_MEMORY);
 }
 
 // ---- per block: exclusive scan of the tile totals -> tile offsets; the block's size ---------------------------------------
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(T6_NT, E6_WPS) void sfe6_kernel(const EncBlk *__res
             asm volatile("" ::: "memory");
         }
         tile_octs5<NW, L16>(sh.lut, tin[k], oct, tot, incl, tail, absent);
-        if (absent) set_error(bp->err, SHAFA_FILE_UNRECOGNIZABLE);          // data symbol without a code (output undefined, in bounds)
+        if (absent) set_error_over(bp->err, SHAFA_FILE_UNRECOGNIZABLE, SHAFA_LACK_OF_MEMORY);          // data symbol without a code (output undefined, in bounds)
         if (lane == 63) {
             sh.wtot[par][wv] = incl;
             sh.tail[par][wv] = tail;

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(NT) void sfe4_tail_kernel(const EncBlk *__restrict_
     Oct oct[4];
     u32 incl[2], absent = 0, roff[4];
     tile_octs<true, NW, L16, NT>(sh.lut, in, rem, tid, oct, incl, absent);
-    if (absent) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
+    if (absent) set_error_over(blk.err, SHAFA_FILE_UNRECOGNIZABLE, SHAFA_LACK_OF_MEMORY);
     if (lane == 63) {
         sh.wtot[wv] = incl[0] & 0xFFFFu;
         sh.wtot[NWV + wv] = incl[0] >> 16;
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(NT) void sfe5q_tail_kernel(const EncBlk *__restrict
         qd[q].ll &= 0xFFFFu;
         tot += qd[q].ll;
     }
-    if (absent) set_error(blk.err, SHAFA_FILE_UNRECOGNIZABLE);
+    if (absent) set_error_over(blk.err, SHAFA_FILE_UNRECOGNIZABLE, SHAFA_LACK_OF_MEMORY);
     const u32 incl = dpp_scan_add(tot);
     if (lane == 63) sh.wtot5[0][wv] = incl;
     if (wv == 0 && ((u32)B & 31u) && nfull > 0) lead_bits(sh.lut, win, pv, (u32)B & 31u, lane);

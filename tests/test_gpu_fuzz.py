@@ -101,3 +101,54 @@ def test_rle_decode_of_arbitrary_bytes_equals_the_oracle(oracle, shafa):
         assert got_rc == want_rc, f"n={n} pz={pz}: rc {got_rc}, oracle {want_rc}"
         if want_rc == 0:
             assert got.tobytes() == want.tobytes(), f"n={n} pz={pz}: {first_diff(got, want)}"
+
+
+def test_blocks_with_two_faults_report_the_one_a_sequential_coder_meets_first(oracle, shafa):
+    """Two faults of different kinds in one block are found by different workgroups in no fixed order; the return code must
+    still be the oracle's — the fault a sequential coder stops at — every time.  rle_decode: output past out_cap
+    (LACK_OF_MEMORY) in front of a triple cut by the end of the block (FILE_UNRECOGNIZABLE), and out_cap within one token's
+    length of SHAFA_RLE_DECODE_MAX (the token that passes out_cap decides; one that also passes the maximum is
+    FILE_UNRECOGNIZABLE).  sf_encode: a symbol without a code outranks an output that does not fit (the oracle looks at
+    every symbol first)."""
+    shafa.lib().shafa_hip_init(0)
+    rng = np.random.default_rng(6061)
+    # rle_decode: many tiles of triples and literals, the last bytes a cut triple
+    for n_tok in (50, 3000, 200000):
+        body = np.zeros((n_tok, 3), dtype=np.uint8)
+        body[:, 1] = rng.integers(0, 256, size=n_tok)
+        body[:, 2] = rng.integers(0, 256, size=n_tok)
+        stream = np.concatenate([body.reshape(-1), rng.integers(1, 256, size=777).astype(np.uint8), np.array([0, 65], dtype=np.uint8)])
+        rc_full, full = oracle.rle_decode(stream[:-2], cap=int(shafa.RLE_DECODE_MAX))
+        total = full.size if rc_full == 0 else None
+        for cap in ([total // 2, total - 1, total, total + 5] if total is not None else [1000, 1 << 20]):
+            want_rc, _ = oracle.rle_decode(stream, cap=cap)
+            for rep in range(4):
+                got_rc, _ = shafa.rle_decode(stream, cap=cap, raw_rc=True)
+                assert got_rc == want_rc, f"rle_decode n_tok={n_tok} cap={cap} (run {rep}): rc {got_rc}, oracle {want_rc}"
+    # out_cap just under the maximum, output past both: runs of 255 (and of 1..254 in front, so that the edges fall inside tokens)
+    MAX = int(shafa.RLE_DECODE_MAX)
+    n_tok = MAX // 255 + 40
+    body = np.zeros((n_tok, 3), dtype=np.uint8)
+    body[:, 1] = 9
+    body[:, 2] = 255
+    for lead in (0, 1, 100, 254):
+        stream = np.concatenate([np.full(lead, 7, dtype=np.uint8), body.reshape(-1)])
+        for cap in (MAX - 1, MAX - 100, MAX - 254, MAX - 255, MAX - 256, MAX - 400, MAX, MAX + 10):
+            want_rc, _ = oracle.rle_decode(stream, cap=cap)
+            got_rc, _ = shafa.rle_decode(stream, cap=cap, raw_rc=True)
+            assert got_rc == want_rc, f"rle_decode lead={lead} cap=MAX{cap - MAX:+d}: rc {got_rc}, oracle {want_rc}"
+    # sf_encode: the table of other data (symbol 200 has no code), an output region that is too small
+    zt = shafa.zipf_table(1.2)
+    for n in (3000, 500000):
+        data = oracle.gen_bytes(4 + n, n, zt) % 128
+        otab = oracle.sf_build(oracle.hist256(data))
+        t = to_shafa_table(shafa, otab)
+        _, enc = oracle.sf_encode(data, otab)
+        for where in (5, n // 2, n - 1):
+            bad = data.copy()
+            bad[where] = 200
+            for cap in (enc.size // 3, enc.size - 1, enc.size + 64):
+                want_rc, _ = oracle.sf_encode(bad, otab, cap=cap)
+                for rep in range(3):
+                    got_rc, _ = shafa.sf_encode(bad, t, cap=cap, raw_rc=True)
+                    assert got_rc == want_rc, f"sf_encode n={n} bad at {where} cap={cap} (run {rep}): rc {got_rc}, oracle {want_rc}"
