@@ -144,9 +144,66 @@ def chain(tag, data):
             assert gotd.tobytes() == want.tobytes(), f"{tag}: rle_decode of raw bytes {diff(gotd, want)}"
 
 
+def group_chain(tag, pipe, datas):
+    """the same chain for several blocks per launch (shafa_pipe_submit_group): F, C, then D with both decoders fused"""
+    k = len(datas)
+    pipe.submit_group(0, shafa.OP_RLE_ENCODE, datas, flags=shafa.PIPE_INPUT_HIST)
+    rc, brc, outs, res = pipe.wait_group(0, k)
+    assert rc == 0 and not any(brc), f"{tag}: group rle_encode rc {rc} {list(brc)}"
+    rle = []
+    for j, d in enumerate(datas):
+        want = oracle.rle_encode(d)
+        assert outs[j] == want.tobytes(), f"{tag}: group rle_encode block {j}"
+        assert list(res[j].freq) == list(oracle.hist256(want)) and list(res[j].freq_in) == list(oracle.hist256(d)), \
+            f"{tag}: group histograms block {j}"
+        rle.append(want)
+    keep = [j for j in range(k) if np.count_nonzero(np.bincount(rle[j], minlength=256)) >= 2]     # a table with codes
+    if not keep:
+        return
+    otabs = [oracle.sf_build(oracle.hist256(rle[j])) for j in keep]
+    tabs = [table_of(t) for t in otabs]
+    caps = [(rle[j].size * max(1, int(max(t.lens()))) + 7) // 8 + 16 for j, t in zip(keep, tabs)]
+    pipe.submit_group(1, shafa.OP_SF_ENCODE, [rle[j] for j in keep], tables=tabs, out_caps=caps)
+    rc, brc, outs, res = pipe.wait_group(1, len(keep))
+    assert rc == 0 and not any(brc), f"{tag}: group sf_encode rc {rc} {list(brc)}"
+    encs = []
+    for x, j in enumerate(keep):
+        orc, want = oracle.sf_encode(rle[j], otabs[x])
+        assert orc == 0 and outs[x] == want.tobytes(), f"{tag}: group sf_encode block {j}"
+        encs.append(want)
+    for op, wants in ((shafa.OP_SF_DECODE, [rle[j] for j in keep]), (shafa.OP_SF_RLE_DECODE, [datas[j] for j in keep])):
+        pipe.submit_group(0, op, encs, tables=tabs, n_symbols=[rle[j].size for j in keep])
+        rc, brc, outs, res = pipe.wait_group(0, len(keep))
+        assert rc == 0 and not any(brc), f"{tag}: group decode op {op} rc {rc} {list(brc)}"
+        for x, j in enumerate(keep):
+            assert outs[x] == wants[x].tobytes(), f"{tag}: group decode op {op} block {j}"
+
+
 shafa.lib().shafa_hip_init(0)
+gpipe = shafa.Pipe(2)
 t0, rounds, nbytes, kinds = time.time(), 0, 0, {}
 while time.time() - t0 < budget:
+    if rounds % 8 == 7:                            # every eighth round: a launch of several blocks
+        opts = ALTS[int(rng.integers(0, len(ALTS)))]
+        datas = []
+        for _ in range(int(rng.integers(2, 20))):
+            n = min(max(1, size()), 1 << 20)
+            datas.append(np.ascontiguousarray(make(n)[1], dtype=np.uint8))
+        tag = f"seed0={seed0} round={rounds} group of {len(datas)} sizes {[d.size for d in datas]} {opts}"
+        for k, v in opts.items():
+            shafa.set_option(k, v)
+        try:
+            group_chain(tag, gpipe, datas)
+        except Exception:
+            print("FAILED:", tag, flush=True)
+            raise
+        finally:
+            for k, v in DEFAULTS.items():
+                shafa.set_option(k, v)
+        rounds += 1
+        nbytes += sum(d.size for d in datas)
+        kinds["group"] = kinds.get("group", 0) + 1
+        continue
     opts = ALTS[int(rng.integers(0, len(ALTS)))]
     n = size()
     kind, data = make(n)
