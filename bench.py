@@ -460,9 +460,10 @@ def pipeline_leg(args, pkg, torch, dev, st, steps, nb, kind):
     d_dec = torch.empty(nb * dcap, dtype=torch.uint8, device=dev)
     d_dec_n = torch.zeros(nb, dtype=torch.int64, device=dev)
     t_dr = timed(lambda: bt.rle_decode(st, d_sym, roff, rle_n, d_dec, doff, [bs + 1024] * nb, d_dec_n))
-    assert [int(x) for x in d_dec_n.cpu().numpy()] == n, "pipeline round trip: sizes differ"
-    for b in range(nb):
-        assert torch.equal(d_dec[doff[b]:doff[b] + bs], d_in[off[b]:off[b] + bs]), f"pipeline round trip differs in block {b}"
+    if os.environ.get("SHAFA_BENCH_ABLATION") != "2":             # (timing builds with wrong output, tools/dbg: the line says so)
+        assert [int(x) for x in d_dec_n.cpu().numpy()] == n, "pipeline round trip: sizes differ"
+        for b in range(nb):
+            assert torch.equal(d_dec[doff[b]:doff[b] + bs], d_in[off[b]:off[b] + bs]), f"pipeline round trip differs in block {b}"
     tot, rle_tot, enc_tot = float(nb * bs), float(sum(rle_n)), float(sum(enc_bytes))
 
     # HBM traffic per family: the PMC passes (FETCH_SIZE x 2, WRITE_SIZE; separate runs) of a profile of this tree taken with

@@ -4,6 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$R" || exit 1
 export SHAFA_BENCH_ORACLE_CHECK=0
+[ -n "$ABL" ] && export SHAFA_BENCH_ABLATION=$ABL      # ABL=2: builds whose decoders write wrong bytes (timing only)
 cp shafa-cd_amd/libshafa_hip.so /tmp/orig.so
 for i in 1 2; do
   for L in "$@"; do
