@@ -795,27 +795,53 @@ __device__ __forceinline__ u32 sl_region(u8 *smem, const DecBlk &blk, const u32 
 // ------------------------------------------------------------------------------------------------
 constexpr u32 SF_CHUNKS = 8;                       // chunks a repair may walk before it gives up (2048 bits)
 
-// the links into tiles 1 .. t_end - 1 (the tiles of the units the stream ends in are sfd_ends' other workgroup's); tables at smem
+// the links into tiles t_begin .. t_end - 1, at most SF_LINKS of them (the tiles of the units the stream ends in are the ends role's).
+// Checked first — two loads a link, all in flight at once; a slice whose links all hold (nearly every slice) is done then —
+// and only a slice with a link to repair brings the tables into LDS (at smem).
+constexpr u32 SF_LINKS = 2 * DEC_THREADS;          // links per workgroup: a 64 MiB block is 16 workgroups
 template <int LONG>
-__device__ __forceinline__ void sf_links(u8 *smem, const DecBlk &blk, const u32 t_end, u8 *__restrict__ chunk_entry, u16 *__restrict__ chunk_cnt,
-                                         u32 *__restrict__ tile_cnt, u8 *__restrict__ tile_guess, const u8 *__restrict__ tile_exit,
-                                         const u32 tab_bytes)
+__device__ __forceinline__ void sf_links(u8 *smem, const DecBlk &blk, const u32 t_begin, const u32 t_end, u8 *__restrict__ chunk_entry,
+                                         u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt, u8 *__restrict__ tile_guess,
+                                         const u8 *__restrict__ tile_exit, const u32 tab_bytes, const u32 long_bytes)
 {
     const u32 tid = threadIdx.x, KW = blk.KW, mask = (1u << KW) - 1u;
-    const u16 *lt = (const u16 *)(smem + tab_bytes + 32);
+    const u16 *lt = (const u16 *)(smem + tab_bytes + 48);      // tables | wg_any's flags (32 bytes) | gave_up | long-code table
     const u8 *len0 = smem + (1u << KW);
     const u64 end_bit = blk.in_n * 8;
+    u32 turn = 0;
+    u32 xs[SF_LINKS / DEC_THREADS];
+    bool any_bad = false;
+#pragma unroll
+    for (u32 i = 0; i < SF_LINKS / DEC_THREADS; ++i) {
+        const u32 t = t_begin + tid + i * DEC_THREADS;
+        xs[i] = 0xFFFFFFFFu;                            // holds / not this slice's
+        if (t < t_end) {
+            const size_t gt = (size_t)blk.tile_base + t;
+            const u32 x = tile_exit[gt - 1];
+            if (tile_guess[gt] != x) { xs[i] = x; any_bad = true; }
+        }
+    }
+    if (!wg_any(any_bad, (u32 *)(smem + tab_bytes), turn)) return;
+    __syncthreads();                                    // (the flag words lie behind the tables: read by everybody before the fill)
+    fill_lds16((void *)smem, (const void *)blk.cnt3, 2u << KW);
+    if (LONG) {
+        const u16 *src = LONG == 1 ? blk.longtab : blk.long32;
+        if (src) fill_lds16((void *)lt, src, long_bytes);
+        else if (tid == 0) *(u16 *)lt = 0;
+    }
     bool failed = false;
     // (one link that does not heal sends the whole block to the exact kernels: the others stop looking — a table that does not
-    // re-synchronise, forced to speculate, would otherwise walk eight chunks behind most of its 4096 links)
-    volatile u32 *const gave_up = (volatile u32 *)(smem + tab_bytes + 28);      // (the last word of the flag area: the one wg_any call below uses its first four)
+    // re-synchronise, forced to speculate, would otherwise walk eight chunks behind most of its links)
+    volatile u32 *const gave_up = (volatile u32 *)(smem + tab_bytes + 32);
     if (tid == 0) *gave_up = 0;
     __syncthreads();
-    for (u32 t = 1 + tid; t < t_end; t += DEC_THREADS) {
+#pragma unroll 1
+    for (u32 i = 0; i < SF_LINKS / DEC_THREADS; ++i) {
         if (*gave_up) break;
+        const u32 x = xs[i];
+        if (x == 0xFFFFFFFFu) continue;
+        const u32 t = t_begin + tid + i * DEC_THREADS;
         const size_t gt = (size_t)blk.tile_base + t;
-        const u32 x = tile_exit[gt - 1];
-        if (tile_guess[gt] == x) continue;
         const u64 tile_bit0 = (u64)t * DTILE * 8;
         // a "stream ended" mark in front, or the stream's end within reach of the walk: not repaired here
         if (x >= spec_emask<LONG>() || tile_bit0 + (u64)(SF_CHUNKS + 1) * CH_BITS + 64 > end_bit) { failed = true; *gave_up = 1; continue; }
@@ -858,14 +884,14 @@ __device__ __forceinline__ void sf_links(u8 *smem, const DecBlk &blk, const u32 
         tile_guess[gt] = (u8)x;
         tile_cnt[gt] = (u32)((int)tile_cnt[gt] + delta);
     }
-    u32 turn = 0;
     if (wg_any(failed, (u32 *)(smem + tab_bytes), turn) && tid == 0)
         __hip_atomic_store(blk.run_dp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// sfd_ends, behind sfd_scan: grid (2, blocks).  Workgroup 0 of a block: the unit(s) its stream ends in (sl_region; sfd_scan leaves
-// them out), the first lane entered at the exit of the unit in front — final by now, so these units' links hold by construction.
-// Workgroup 1: every other link of the block (sf_links).  Either sets *run_dp when something does not hold.
+// sfd_ends, behind sfd_scan: grid (1 + slices of SF_LINKS links, blocks).  Workgroup 0 of a block: the unit(s) its stream ends in
+// (sl_region; sfd_scan leaves them out), the first lane entered at the exit of the unit in front — final by now, so these units'
+// links hold by construction.  Workgroups 1 ..: the other links of the block, a slice each (sf_links; no link depends on
+// another's repair).  Any of them sets *run_dp when something does not hold.
 template <int LONG>
 __global__ __launch_bounds__(DEC_THREADS) void sfd_ends(const DecBlk *__restrict__ blks, u8 *__restrict__ chunk_entry,
                                                         u16 *__restrict__ chunk_cnt, u32 *__restrict__ tile_cnt,
@@ -880,20 +906,20 @@ __global__ __launch_bounds__(DEC_THREADS) void sfd_ends(const DecBlk *__restrict
     const u32 units = (blk.n_tiles + SC_WTILES - 1) / SC_WTILES;
     u32 first_end = units - 1;
     if (units >= 2 && blk.in_n - (u64)(units - 2) * SC_WTILES * DTILE < (u64)64 * SC_SB + 4) first_end = units - 2;
-    const bool ends_role = blockIdx.x == 0;
-    const u32 tab_at = ends_role ? (u32)SL_LDS_DATA : 0u;
-    fill_lds16((void *)(smem + tab_at), (const void *)blk.cnt3, 2u << blk.KW);
+    if (blockIdx.x > 0) {                               // a slice of the block's links
+        const u32 t_end = first_end * SC_WTILES, t_begin = 1u + (blockIdx.x - 1u) * SF_LINKS;
+        if (t_begin < t_end)
+            sf_links<LONG>(smem, blk, t_begin, t_end, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tab_bytes, long_bytes);
+        return;
+    }
+    fill_lds16((void *)(smem + SL_LDS_DATA), (const void *)blk.cnt3, 2u << blk.KW);
     if (LONG) {
-        u16 *lt = (u16 *)(smem + tab_at + tab_bytes + (ends_role ? (u32)SL_MISC : 32u));
+        u16 *lt = (u16 *)(smem + SL_LDS_DATA + tab_bytes + SL_MISC);
         const u16 *src = LONG == 1 ? blk.longtab : blk.long32;
         if (src) fill_lds16((void *)lt, src, long_bytes);
         else if (threadIdx.x == 0) *lt = 0;
     }
     __syncthreads();
-    if (!ends_role) {
-        sf_links<LONG>(smem, blk, first_end * SC_WTILES, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tab_bytes);
-        return;
-    }
     u32 e0 = first_end ? (u32)tile_exit[(size_t)blk.tile_base + first_end * SC_WTILES - 1] : 0u;
     for (u32 u = first_end; u < units; ++u)
         e0 = sl_region<LONG>(smem, blk, u * SC_WTILES, e0, chunk_entry, chunk_cnt, tile_cnt, tile_guess, tile_exit, tab_bytes);
@@ -1579,7 +1605,7 @@ int sfdec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const u
                                (u32 *)(ws + o_tcnt), tg, tx, tabb, long_used);
         {   // the units the streams end in and the links between all units: checked, repaired, the blocks' verdicts
             const size_t lds_ends = (size_t)SL_LDS_DATA + tabb + SL_MISC + (spec_long ? (size_t)long_used : 0);
-            const dim3 grid_e(2, (u32)nblocks);
+            const dim3 grid_e(1u + (u32)ceil_div_u64(max_tiles, SF_LINKS), (u32)nblocks);
             if (spec_long == 2)
                 hipLaunchKernelGGL((sfd_ends<2>), grid_e, dim3(DEC_THREADS), lds_ends, st, dblk, ws + o_cent, (u16 *)(ws + o_ccnt),
                                    (u32 *)(ws + o_tcnt), tg, tx, tabb, long_used);
