@@ -14,7 +14,7 @@ python3 - "$out" <<'PY'
 import csv, sys, glob
 f = glob.glob(sys.argv[1] + '/**/r_kernel_stats.csv', recursive=True)
 rows = list(csv.DictReader(open(f[0])))
-for r in rows[:9]:
+for r in rows[:int(__import__("os").environ.get("KSTATS_ROWS", "9"))]:
     name = r['Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:40]
     print(f"{name:42s} calls {r['Calls']:>4s} avg_us {float(r['AverageNs'])/1e3:9.1f} min_us {float(r['MinNs'])/1e3:9.1f}")
 PY
