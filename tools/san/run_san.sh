@@ -1,14 +1,14 @@
 #!/bin/bash
 # CPU-side C under AddressSanitizer + UBSan (SURVEY.md §4/§5 "sanitizers"): the oracle restatement, the host's formats,
 # Module T and the module drivers' host logic.  GPU code is out of reach of the sanitizers on this pool; nothing here
-# needs a GPU.  Writes the report to profiles/r5_sanitizers.txt.
+# needs a GPU.  Writes the report to profiles/r6_sanitizers.txt (SAN_OUT: another name).
 #   1. make -C oracle SAN=1, make -C shafa-cd_amd/host SAN=1  (into _san/, next to the normal builds)
 #   2. the parser / Module T corpus (tools/san/san_corpus.c)
 #   3. malformed .freq FILES through the sanitized CLI's Module T (host-only: runs without a GPU)
 #   4. the whole CPU test suite with the sanitized oracle, host library and CLI (runtimes preloaded into python)
 R=$(cd "$(dirname "$0")/../.." && pwd)
 cd "$R" || exit 1
-OUT=$R/profiles/r5_sanitizers.txt
+OUT=$R/profiles/${SAN_OUT:-r6_sanitizers.txt}
 make -C oracle SAN=1 --no-print-directory > /dev/null || exit 1
 make -C shafa-cd_amd/host SAN=1 --no-print-directory > /dev/null || exit 1
 ASAN=$(gcc -print-file-name=libasan.so); UBSAN=$(gcc -print-file-name=libubsan.so)
