@@ -6,6 +6,8 @@
 #   2. the parser / Module T corpus (tools/san/san_corpus.c)
 #   3. malformed .freq FILES through the sanitized CLI's Module T (host-only: runs without a GPU)
 #   4. the whole CPU test suite with the sanitized oracle, host library and CLI (runtimes preloaded into python)
+# The sanitized CLI also runs on the GPU box (the module drivers' group / FIFO / pipe logic needs a device): the recipe and its
+# record are section 5 of the report (tests/test_cli.py -m gpu and tools/soak_cli.py with SHAFA_CLI=shafa-cd_amd/host/_san/shafa).
 R=$(cd "$(dirname "$0")/../.." && pwd)
 cd "$R" || exit 1
 OUT=$R/profiles/${SAN_OUT:-r6_sanitizers.txt}

@@ -21,7 +21,7 @@ import pkgload
 from golden.make_golden import mask_stdout
 
 synth = pkgload.load_submodule("synth")
-OURS = os.path.join(ROOT, "shafa-cd_amd", "bin", "shafa")
+OURS = os.environ.get("SHAFA_CLI") or os.path.join(ROOT, "shafa-cd_amd", "bin", "shafa")      # (SHAFA_CLI: the sanitized build, tools/san)
 REF = os.path.join(ROOT, "oracle", "_ref", "shafa")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
