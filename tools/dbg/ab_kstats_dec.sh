@@ -15,7 +15,7 @@ import csv, sys, glob
 f = glob.glob(sys.argv[1] + '/**/r_kernel_stats.csv', recursive=True)
 for r in csv.DictReader(open(f[0])):
     n = r['Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
-    if n.startswith('sfd_wstage') or n.startswith('sfd_scan<false'):
+    if n.startswith("sfd_wstage") or n.startswith("sfd_scan"):
         print(f"   {n[:30]:32s} avg_us {float(r['AverageNs'])/1e3:9.1f}")
 PY
 done
