@@ -118,7 +118,9 @@ int shafa_hip_rle_encode(const uint8_t *in, size_t n, uint8_t *out, size_t out_c
 
 /* compress_to_buffer + binary_coding (c.c:52-237): concatenate the block's codes MSB-first,
  * zero-pad the last byte; *out_n = ceil(bits/8).  A data symbol with an empty code in a table that
- * holds non-empty codes is SHAFA_FILE_UNRECOGNIZABLE; an all-empty table gives 0 bytes (c.c:156). */
+ * holds non-empty codes is SHAFA_FILE_UNRECOGNIZABLE; an all-empty table gives 0 bytes (c.c:156).
+ * A block with both faults — such a symbol AND an output that does not fit out_cap — is SHAFA_FILE_UNRECOGNIZABLE
+ * (the symbols are looked at first), whichever the device notices first. */
 int shafa_hip_sf_encode(const uint8_t *in, size_t n, const shafa_code_table *table,
                         uint8_t *out, size_t out_cap, size_t *out_n);
 
@@ -128,7 +130,9 @@ int shafa_hip_sf_decode(const uint8_t *in, size_t in_n, const shafa_code_table *
                         uint8_t *out, size_t n_symbols);
 
 /* rle_block_decompressor (d.c:116-197); more than SHAFA_RLE_DECODE_MAX bytes of output is
- * SHAFA_FILE_UNRECOGNIZABLE (d.c:165-168), more than out_cap is SHAFA_LACK_OF_MEMORY. */
+ * SHAFA_FILE_UNRECOGNIZABLE (d.c:165-168), more than out_cap is SHAFA_LACK_OF_MEMORY, a {0, symbol, count} cut by the end
+ * of the block is SHAFA_FILE_UNRECOGNIZABLE.  A block with several of these reports the one a front-to-back decoder stops at
+ * (the first token whose end passes out_cap or the maximum; a cut triple comes last), independent of timing. */
 int shafa_hip_rle_decode(const uint8_t *in, size_t in_n, uint8_t *out, size_t out_cap, size_t *out_n);
 
 /* ------------------------------------------------------------------ layer 2: device buffers, batches
