@@ -429,18 +429,21 @@ __device__ __forceinline__ void rle3_first_tile(RleShared &sh, const RleBlk &blk
 
 // R[t] = length of the run that ends at the last byte of tile t - 1
 constexpr u32 SCAN_EPT = 16;                           // tiles per thread and round of the two per-block scans
-__global__ __launch_bounds__(RLE_THREADS) void rle3_carry(const RleBlk *__restrict__ blks, const u32 *__restrict__ tsum,
+constexpr u32 SCAN_THREADS = 1024;                     // one workgroup per block: a 64 MiB block's 16 K tiles are one round (four rounds
+                                                       //   of 256 threads — a load and three barriers each — took 18 us per kernel)
+constexpr u32 SCAN_WAVES = SCAN_THREADS / 64;
+__global__ __launch_bounds__(SCAN_THREADS) void rle3_carry(const RleBlk *__restrict__ blks, const u32 *__restrict__ tsum,
                                                           u32 *__restrict__ R)
 {
     // one workgroup per block; a thread takes SCAN_EPT consecutive tiles a round, all of its loads issued before the
     // first is used (64 rounds of one tile per thread, a load and three barriers each, took 60 us for 16 K tiles)
-    __shared__ Seg wtot[4];
+    __shared__ Seg wtot[SCAN_WAVES];
     __shared__ Seg carry;
     const RleBlk blk = blks[blockIdx.x];
     const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
     if (tid == 0) carry = Seg{1u, 0u};
     lds_barrier();
-    for (u32 r0 = 0; r0 < blk.n_tiles; r0 += RLE_THREADS * SCAN_EPT) {
+    for (u32 r0 = 0; r0 < blk.n_tiles; r0 += SCAN_THREADS * SCAN_EPT) {
         const u32 t0 = r0 + (u32)tid * SCAN_EPT;
         u32 x[SCAN_EPT];
 #pragma unroll
@@ -469,23 +472,23 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_carry(const RleBlk *__restri
         lds_barrier();
         if (tid == 0) {
             Seg c2 = carry;
-            for (int ww = 0; ww < 4; ++ww) c2 = comb_f(c2, wtot[ww]);
+            for (int ww = 0; ww < (int)SCAN_WAVES; ++ww) c2 = comb_f(c2, wtot[ww]);
             carry = c2;
         }
         lds_barrier();
     }
 }
 
-__global__ __launch_bounds__(RLE_THREADS) void rle3_offsets(const RleBlk *__restrict__ blks, const u32 *__restrict__ T,
+__global__ __launch_bounds__(SCAN_THREADS) void rle3_offsets(const RleBlk *__restrict__ blks, const u32 *__restrict__ T,
                                                             u64 *__restrict__ G)
 {
-    __shared__ u64 wtot[4];
+    __shared__ u64 wtot[SCAN_WAVES];
     __shared__ u64 carry;
     const RleBlk blk = blks[blockIdx.x];
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) carry = 0;
     lds_barrier();
-    for (u32 r0 = 0; r0 < blk.n_tiles; r0 += RLE_THREADS * SCAN_EPT) {      // as rle3_carry: SCAN_EPT tiles per thread
+    for (u32 r0 = 0; r0 < blk.n_tiles; r0 += SCAN_THREADS * SCAN_EPT) {      // as rle3_carry: SCAN_EPT tiles per thread
         const u32 t0 = r0 + tid * SCAN_EPT;
         u32 x[SCAN_EPT];
 #pragma unroll
@@ -505,7 +508,11 @@ __global__ __launch_bounds__(RLE_THREADS) void rle3_offsets(const RleBlk *__rest
         for (u32 j = 0; j < SCAN_EPT; ++j)
             if (t0 + j < blk.n_tiles) G[blk.desc_base + t0 + j] = base + ex[j];
         lds_barrier();
-        if (tid == 0) carry += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        if (tid == 0) {
+            u64 c2 = carry;
+            for (u32 ww = 0; ww < SCAN_WAVES; ++ww) c2 += wtot[ww];
+            carry = c2;
+        }
         lds_barrier();
     }
     if (tid == 0) *blk.out_n = carry;
@@ -1677,9 +1684,9 @@ int rleenc_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
         u32 *tsum = (u32 *)(ws + o_tsum), *Rr = (u32 *)(ws + o_R), *Tt = (u32 *)(ws + o_T);
         u64 *Gg = (u64 *)(ws + o_sum);
         hipLaunchKernelGGL(rle3_first, dim3((max_tiles + 3) / 4, (u32)nblocks), dim3(RLE_THREADS), 0, st, dblk, tsum, Tt);
-        hipLaunchKernelGGL(rle3_carry, grid_b, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)tsum, Rr);
+        hipLaunchKernelGGL(rle3_carry, grid_b, dim3(SCAN_THREADS), 0, st, dblk, (const u32 *)tsum, Rr);
         hipLaunchKernelGGL(rle3_fix, dim3((max_tiles + 63) / 64, (u32)nblocks), dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Rr, Tt);
-        hipLaunchKernelGGL(rle3_offsets, grid_b, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Tt, Gg);
+        hipLaunchKernelGGL(rle3_offsets, grid_b, dim3(SCAN_THREADS), 0, st, dblk, (const u32 *)Tt, Gg);
         hipLaunchKernelGGL(rle3_emit, grid_t, dim3(RLE_THREADS), 0, st, dblk, (const u32 *)Rr, Tt, (const u64 *)Gg);
         HIP_TRY(hipGetLastError());
     }
