@@ -37,6 +37,14 @@ constexpr int RLD_IMG = RLD_IMG_KB * 1024;         // bytes of the output image
 constexpr u32 FN_IDENT = 0u | (1u << 2) | (2u << 4);
 #define RLD_DSTRIDE 4                              // u64 words between the descriptors of consecutive tiles
 #define RLD_SLEEP 1
+// u32 words between the ticket counters of consecutive blocks (256 bytes).  Returning agent-scope atomics are served by the
+// memory side one after the other per cache line, 13-20 ns each, whichever words of the line they hit; the tile needs its ticket
+// before it can load anything, and with every block's counter in one line a launch of 8 blocks took its 46 K tickets one by one:
+// 614 us where the tiles need 450 (2 / 4 / 8 blocks: - 26 .. 28 %; 32 blocks and more: the same; one block: one counter, 20 ns
+// a tile = 115 us per 64 MiB, the kernel's time — the tile index from the grid position would be 77 us, but nothing orders
+// the dispatch of workgroups on this hardware, and a tile that waits for a predecessor that has not started never ends).
+// The chained encoders ask for tickets three tiles ahead and do not notice (A/B: tools/experiments/README.md).
+#define RLD_TSTRIDE 64
 
 
 // per 8-bit zero mask (bit i = byte i is 0) and entry state s: bits [10 s, 10 s + 8) = token starts, [10 s + 8, 10 s + 10) = exit
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(RLD_THREADS) __attribute__((amdgpu_waves_per_eu(RLD
     const int b = blockIdx.x % nblk;
     const RldBlk blk = blks[b];
     if ((u32)(blockIdx.x / nblk) >= blk.n_tiles) return;
-    if (tid == 0) sh.tile = atomicAdd(tickets + blk.ticket, 1u);
+    if (tid == 0) sh.tile = atomicAdd(tickets + (size_t)blk.ticket * RLD_TSTRIDE, 1u);
     sh.fsm[tid] = g_rld_fsm.v[tid];
     if (tid < 2) *(uint4 *)(sh.in + RLD_TILE + 16 * tid) = make_uint4(0, 0, 0, 0);
     lds_barrier();
@@ -484,7 +492,7 @@ int rledec_launch(Batch *bt, hipStream_t st, int nblocks, const u8 *d_in, const 
     size_t off = 0;
     const size_t o_state = off; off += ndesc * 8 * RLD_DSTRIDE;
     const size_t o_sum = off; off += ndesc * 8 * RLD_DSTRIDE;
-    const size_t o_tick = off; off += (size_t)nblocks * 4; off = (off + 15) & ~(size_t)15;
+    const size_t o_tick = off; off += (size_t)nblocks * 4 * RLD_TSTRIDE; off = (off + 15) & ~(size_t)15;
     const size_t o_zero_end = off;
     const size_t o_blk = off; off += (size_t)nblocks * sizeof(RldBlk);
     int rc = batch_reserve(bt, st, off);
