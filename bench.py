@@ -503,11 +503,11 @@ def pipeline_leg(args, pkg, torch, dev, st, steps, nb, kind):
 
 
 def small_launch_rows(args, pkg, torch, dev, st):
-    """The `runs` pipeline leg at the launch sizes a file at -b M really has (1 and 8 blocks): the fixed sequence of a launch
+    """The `runs` pipeline leg at the launch sizes a file at -b M really has (1, 2 and 8 blocks): the fixed sequence of a launch
     weighs most there.  Compact rows: ms and fraction of the HBM peak per family (24 calls back to back,
     the best of three such loops)."""
     rows = {}
-    for nb in (1, 8):
+    for nb in (1, 2, 8):                               # (2: what the CLI launches at -b M — its groups close at 128 MiB)
         leg = pipeline_leg(args, pkg, torch, dev, st, 24, nb, "runs")
         rows[f"{nb}_blocks"] = {k: {"ms": round(v["ms"], 4), "frac": round(v["frac"], 4)} for k, v in leg.items()
                                 if isinstance(v, dict) and "frac" in v}
